@@ -1,0 +1,107 @@
+"""ctypes binding of libbevyray_amd.so (the C ABI in include/bevyray_amd.h).
+
+The shared object is built in-tree by ``bevyray_amd/csrc/Makefile`` (hipcc, gfx950).  If it
+is missing or older than its sources it is rebuilt on import; if that fails the import
+fails -- there is no Python or CPU fallback for the render path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libbevyray_amd.so")
+_SOURCES = ["brt_api.cpp", "brt_host.cpp", "brt_kernels.hip", "brt_host.h", "brt_kernels.h", "brt_layout.h",
+            "brt_device.h", "Makefile"]
+
+_lock = threading.Lock()
+_lib = None
+
+
+class BrtStats(C.Structure):
+    _fields_ = [
+        ("rays", C.c_uint64), ("node_pops", C.c_uint64), ("interior_visits", C.c_uint64),
+        ("sphere_tests", C.c_uint64), ("hits", C.c_uint64), ("paths", C.c_uint64),
+        ("kernel_ms", C.c_double), ("gather_ms", C.c_double), ("total_ms", C.c_double),
+        ("lds_bytes", C.c_uint32), ("scene_in_lds", C.c_uint32), ("n_workgroups", C.c_uint32),
+        ("threads_per_workgroup", C.c_uint32),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    paths = [os.path.join(_CSRC, s) for s in _SOURCES] + [os.path.join(_HERE, "..", "include", "bevyray_amd.h")]
+    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in paths)
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    with _lock:
+        if force or _stale():
+            cmd = ["make", "-C", _CSRC] + (["-B"] if force else [])
+            proc = subprocess.run(cmd, capture_output=True, text=True)
+            if proc.returncode != 0:
+                raise RuntimeError("building libbevyray_amd.so failed:\n" + proc.stdout + proc.stderr)
+    return LIB_PATH
+
+
+_VP, _U32, _I32, _F = C.c_void_p, C.c_uint32, C.c_int32, C.c_float
+_PROTOTYPES = {
+    # name: (restype, argtypes) -- must list every export of include/bevyray_amd.h
+    "brt_abi_version": (_U32, []),
+    "brt_last_error": (C.c_char_p, [_VP]),
+    "brt_create": (_I32, [C.POINTER(_I32), _I32, C.POINTER(_VP)]),
+    "brt_destroy": (_I32, [_VP]),
+    "brt_upload_scene": (_I32, [_VP, _VP, _U32, _VP, _U32, _VP, _U32]),
+    "brt_render": (_I32, [_VP, _VP, _VP, _U32, _U32, _U32, _VP, _VP, _VP, _U32, C.POINTER(BrtStats)]),
+    "brt_render_part_device": (_I32, [_VP, _VP, _VP, _U32, _U32, _U32, _U32, _U32, _VP, _VP, _VP, _VP, _U32,
+                                      C.POINTER(BrtStats)]),
+    "brt_tile_rows": (_U32, [_U32, _U32]),
+    "brt_deinterleave_device": (_I32, [_VP, _VP, _U32, _U32, _U32, _VP, _VP]),
+    "brt_debug_eval": (_I32, [_VP, _U32, _VP, _VP, _U32]),
+    "brt_build_bvh": (_I32, [_VP, _U32, _VP, _U32, C.POINTER(_U32)]),
+    "brt_validate_scene": (_I32, [_VP, _U32, _VP, _U32, _VP, _U32, C.POINTER(_U32)]),
+    "brt_scene_generate": (_I32, [_U32, C.c_uint64, _VP, _VP, _U32, C.POINTER(_U32)]),
+    "brt_host_camera_extract": (_I32, [C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _F, _F, _F, _F, _U32, _U32, _VP]),
+    "brt_host_window_extract": (_I32, [_F, _U32, _VP]),
+    "brt_host_material": (_I32, [C.POINTER(_F), _F, _F, _F, _F, _F, _VP]),
+}
+EXPORTS = tuple(_PROTOTYPES)
+
+
+def load() -> C.CDLL:
+    """Load (building first if needed) the shared library and declare every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.brt_abi_version() != 1:
+        raise RuntimeError("libbevyray_amd.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+class BrtError(RuntimeError):
+    def __init__(self, code: int, text: str):
+        super().__init__(f"bevyray_amd error {code}: {text}")
+        self.code = code
+        self.text = text
+
+
+def check(rc: int, ctx=None) -> None:
+    if rc != 0:
+        msg = load().brt_last_error(ctx)
+        raise BrtError(rc, msg.decode("utf-8", "replace") if msg else "")

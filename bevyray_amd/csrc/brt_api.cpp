@@ -1,0 +1,541 @@
+// brt_api.cpp -- the extern "C" boundary (include/bevyray_amd.h): context, scene upload,
+// frame parameters, kernel launches, strip tiling over devices.
+//
+// What each export replaces in the reference is cited in the header.  This file holds no ray
+// arithmetic: rays are traced only by the HIP kernels (brt_kernels.hip).  Without a usable
+// HIP device brt_create fails with BRT_ERR_NO_DEVICE -- there is no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "brt_host.h"
+#include "brt_kernels.h"
+
+using namespace brt;
+
+namespace {
+
+struct DeviceCtx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int num_cus = 0;
+    size_t max_lds = 0;
+    // scene
+    char* d_scene = nullptr;
+    size_t scene_cap = 0;
+    DeviceSceneView view{};
+    // small control block: 5 x u64 counters @0, queue counter @48
+    char* d_ctrl = nullptr;
+    // frame-sized buffers owned by the context (brt_render)
+    float* d_tile = nullptr;
+    size_t tile_cap = 0;
+    float* d_raster_rgba = nullptr;
+    size_t raster_rgba_cap = 0;
+    float* d_raster_depth = nullptr;
+    size_t raster_depth_cap = 0;
+    float* h_stage = nullptr;  // pinned
+    size_t stage_cap = 0;
+};
+
+}  // namespace
+
+struct brt_ctx {
+    std::vector<DeviceCtx> devs;
+    EncodedScene enc;
+    bool has_scene = false;
+    std::string last_error;
+};
+
+namespace {
+
+int32_t ctx_fail(brt_ctx* ctx, int32_t code, const std::string& msg) {
+    if (ctx) ctx->last_error = msg;
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                              \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+            return ctx_fail(ctx, BRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));       \
+    } while (0)
+
+template <typename T>
+int32_t ensure(brt_ctx* ctx, T** ptr, size_t* cap, size_t bytes) {
+    if (*cap >= bytes && *ptr) return BRT_OK;
+    if (*ptr) HIP_TRY(ctx, hipFree(*ptr));
+    *ptr = nullptr;
+    *cap = 0;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(ptr), bytes));
+    *cap = bytes;
+    return BRT_OK;
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+uint32_t env_u32(const char* name, uint32_t dflt) {
+    const char* v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    return (uint32_t)std::strtoul(v, nullptr, 10);
+}
+
+// Frame-uniform values with the reference's own expressions (raytrace.wgsl:95,141-153,177-182).
+int32_t make_frame_params(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level, uint32_t width,
+                          uint32_t height, uint32_t part, uint32_t n_parts, FrameParams* out) {
+    if (!camera80 || !window16) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "camera/window is null");
+    if (width == 0 || height == 0 || width > 32768u || height > 32768u)
+        return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "width/height must be in [1, 32768]");
+    if (n_parts == 0 || part >= n_parts) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "part >= n_parts");
+    Camera cam;
+    Window win;
+    std::memcpy(&cam, camera80, sizeof cam);
+    std::memcpy(&win, window16, sizeof win);
+    if (cam.projection_type != 0)
+        return ctx_fail(ctx, BRT_ERR_UNSUPPORTED, "only perspective projection (0) is supported (extract.rs:148)");
+    if (cam.bounce_count >= 0x7fffffffu) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "bounce_count too large");
+    FrameParams fp;
+    std::memset(&fp, 0, sizeof fp);
+    fp.width = width;
+    fp.height = height;
+    fp.level = level;
+    fp.sample_count = cam.sample_count;
+    fp.bounce_count = cam.bounce_count;
+    fp.seed_scaled = win.random_seed * 10000.0f;
+    const float heightf = (float)win.height;
+    const float widthf = (float)win.height * cam.aspect;
+    fp.inv_width = 1.0f / widthf;
+    fp.inv_height = 1.0f / heightf;
+    fp.aspect = cam.aspect;
+    fp.tan_half_fov = tan_half_fov(cam.fov);
+    for (int k = 0; k < 3; k++) {
+        fp.cam_pos[k] = cam.position[k];
+        fp.cam_dir[k] = cam.direction[k];
+        fp.cam_up[k] = cam.up[k];
+    }
+    const float* a = cam.direction;
+    const float* b = cam.up;
+    fp.cam_right[0] = a[1] * b[2] - a[2] * b[1];
+    fp.cam_right[1] = a[2] * b[0] - a[0] * b[2];
+    fp.cam_right[2] = a[0] * b[1] - a[1] * b[0];
+    fp.near_ = cam.near_;
+    fp.far_ = cam.far_;
+    fp.fallback_far = (level == 1u) ? cam.far_ + 10.0f : cam.far_ - 1.0f;
+    fp.spp_f = (float)cam.sample_count;
+    fp.part = part;
+    fp.n_parts = n_parts;
+    fp.tiles_x = (width + 7u) / 8u;
+    const uint32_t strips = (height + BRT_STRIP_ROWS - 1u) / BRT_STRIP_ROWS;
+    fp.local_strips = (strips + n_parts - 1u) / n_parts;
+    fp.queue_size = fp.local_strips * fp.tiles_x * 64u;
+    *out = fp;
+    return BRT_OK;
+}
+
+struct LaunchPlan {
+    bool lds_scene;
+    uint32_t block, grid;
+    size_t lds_bytes;
+};
+
+LaunchPlan plan_launch(const DeviceCtx& dc, const FrameParams& fp) {
+    LaunchPlan lp{};
+    const bool force_global = env_u32("BRT_FORCE_GLOBAL_SCENE", 0) != 0;
+    const uint32_t block_env = env_u32("BRT_BLOCK_THREADS", 0);
+    const uint32_t blocks[3] = {1024u, 512u, 256u};
+    lp.lds_scene = false;
+    if (!force_global) {
+        for (uint32_t b : blocks) {
+            if (block_env && b != block_env) continue;
+            const size_t need = trace_lds_bytes(dc.view, true, b);
+            if (need <= dc.max_lds) {
+                lp.lds_scene = true;
+                lp.block = b;
+                lp.lds_bytes = need;
+                lp.grid = (uint32_t)dc.num_cus;  // one resident workgroup per CU
+                break;
+            }
+        }
+    }
+    if (!lp.lds_scene) {
+        lp.block = block_env ? block_env : 256u;
+        lp.lds_bytes = trace_lds_bytes(dc.view, false, lp.block);
+        uint32_t per_cu = (uint32_t)(dc.max_lds / (lp.lds_bytes ? lp.lds_bytes : 1));
+        const uint32_t by_waves = 16u / (lp.block / 64u);  // 16 waves per CU
+        if (per_cu > by_waves) per_cu = by_waves;
+        if (per_cu < 1) per_cu = 1;
+        per_cu = env_u32("BRT_WG_PER_CU", per_cu);
+        lp.grid = (uint32_t)dc.num_cus * per_cu;
+    }
+    const uint32_t useful = (fp.queue_size + lp.block - 1u) / lp.block;
+    if (lp.grid > useful) lp.grid = useful;
+    if (lp.grid < 1) lp.grid = 1;
+    return lp;
+}
+
+// Launch the trace of one part on one device into d_out_tile.  Asynchronous on `stream`.
+int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const float* d_raster_rgba,
+                    const float* d_raster_depth, float* d_out_tile, hipStream_t stream, uint32_t flags, bool timed,
+                    LaunchPlan* plan_out) {
+    HIP_TRY(ctx, hipMemsetAsync(dc.d_ctrl, 0, 64, stream));
+    if (timed) HIP_TRY(ctx, hipEventRecord(dc.ev0, stream));
+    LaunchPlan lp{};
+    if (fp.level == 0u) {
+        HIP_TRY(ctx, launch_passthrough(fp, d_out_tile, d_raster_rgba, stream));
+    } else {
+        TraceLaunch tl{};
+        tl.scene = dc.view;
+        tl.frame = fp;
+        tl.queue_counter = reinterpret_cast<uint32_t*>(dc.d_ctrl + 48);
+        tl.out_tile = d_out_tile;
+        tl.raster_rgba = d_raster_rgba;
+        tl.raster_depth = d_raster_depth;
+        tl.counters = reinterpret_cast<unsigned long long*>(dc.d_ctrl);
+        tl.counters_on = (flags & BRT_FLAG_COUNTERS) != 0;
+        tl.stream = stream;
+        if (flags & BRT_FLAG_KERNEL_SIMPLE) {
+            HIP_TRY(ctx, launch_trace_simple(tl));
+            lp.block = 256;
+            lp.grid = (fp.queue_size + 255u) / 256u;
+        } else {
+            lp = plan_launch(dc, fp);
+            tl.lds_scene = lp.lds_scene;
+            tl.grid = lp.grid;
+            tl.block = lp.block;
+            tl.lds_bytes = lp.lds_bytes;
+            HIP_TRY(ctx, launch_trace_persistent(tl));
+        }
+    }
+    if (timed) HIP_TRY(ctx, hipEventRecord(dc.ev1, stream));
+    if (plan_out) *plan_out = lp;
+    return BRT_OK;
+}
+
+int32_t read_counters(brt_ctx* ctx, DeviceCtx& dc, hipStream_t stream, brt_stats* st) {
+    unsigned long long c[5];
+    HIP_TRY(ctx, hipMemcpyAsync(c, dc.d_ctrl, sizeof c, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    st->rays += c[0];
+    st->node_pops += c[1];
+    st->interior_visits += c[2];
+    st->sphere_tests += c[3];
+    st->hits += c[4];
+    return BRT_OK;
+}
+
+uint64_t part_pixels(const FrameParams& fp) {
+    uint64_t rows = 0;
+    const uint32_t strips = (fp.height + BRT_STRIP_ROWS - 1u) / BRT_STRIP_ROWS;
+    for (uint32_t s = fp.part; s < strips; s += fp.n_parts) {
+        const uint32_t r0 = s * BRT_STRIP_ROWS;
+        rows += (r0 + BRT_STRIP_ROWS <= fp.height) ? BRT_STRIP_ROWS : (fp.height - r0);
+    }
+    return rows * fp.width;
+}
+
+void free_device(DeviceCtx& dc) {
+    if (hipSetDevice(dc.device) != hipSuccess) return;
+    if (dc.d_scene) (void)hipFree(dc.d_scene);
+    if (dc.d_ctrl) (void)hipFree(dc.d_ctrl);
+    if (dc.d_tile) (void)hipFree(dc.d_tile);
+    if (dc.d_raster_rgba) (void)hipFree(dc.d_raster_rgba);
+    if (dc.d_raster_depth) (void)hipFree(dc.d_raster_depth);
+    if (dc.h_stage) (void)hipHostFree(dc.h_stage);
+    if (dc.ev0) (void)hipEventDestroy(dc.ev0);
+    if (dc.ev1) (void)hipEventDestroy(dc.ev1);
+    if (dc.stream) (void)hipStreamDestroy(dc.stream);
+    dc = DeviceCtx();
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t brt_abi_version(void) { return BRT_ABI_VERSION; }
+
+const char* brt_last_error(const brt_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
+
+int32_t brt_create(const int32_t* device_ids, int32_t n_devices, brt_ctx** out_ctx) {
+    if (!out_ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "out_ctx is null");
+    *out_ctx = nullptr;
+    if (!device_ids || n_devices < 1 || n_devices > 64) return fail(BRT_ERR_INVALID_ARGUMENT, "need 1..64 device ids");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count < 1)
+        return fail(BRT_ERR_NO_DEVICE, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count 0") +
+                                           " (this library has no CPU path)");
+    brt_ctx* ctx = new brt_ctx();
+    ctx->devs.resize((size_t)n_devices);
+    for (int i = 0; i < n_devices; i++) {
+        DeviceCtx& dc = ctx->devs[(size_t)i];
+        dc.device = device_ids[i];
+        int32_t rc = BRT_OK;
+        auto body = [&]() -> int32_t {
+            if (dc.device < 0 || dc.device >= count)
+                return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "device id " + std::to_string(dc.device) + " out of range");
+            HIP_TRY(ctx, hipSetDevice(dc.device));
+            hipDeviceProp_t prop;
+            HIP_TRY(ctx, hipGetDeviceProperties(&prop, dc.device));
+            if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+                return ctx_fail(ctx, BRT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950");
+            dc.num_cus = prop.multiProcessorCount;
+            int lds = 0;
+            HIP_TRY(ctx, hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dc.device));
+            dc.max_lds = (size_t)lds;
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&dc.stream, hipStreamNonBlocking));
+            HIP_TRY(ctx, hipEventCreate(&dc.ev0));
+            HIP_TRY(ctx, hipEventCreate(&dc.ev1));
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dc.d_ctrl), 64));
+            return BRT_OK;
+        };
+        rc = body();
+        if (rc != BRT_OK) {
+            g_last_error = ctx->last_error;
+            for (auto& d : ctx->devs) free_device(d);
+            delete ctx;
+            return rc;
+        }
+    }
+    *out_ctx = ctx;
+    return BRT_OK;
+}
+
+int32_t brt_destroy(brt_ctx* ctx) {
+    if (!ctx) return BRT_OK;
+    for (auto& d : ctx->devs) free_device(d);
+    delete ctx;
+    return BRT_OK;
+}
+
+int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, const void* materials, uint32_t n_materials,
+                         const void* bvh_nodes, uint32_t n_nodes) {
+    if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
+    ctx->has_scene = false;
+    std::vector<BVHNode> built;
+    const BVHNode* nodes = static_cast<const BVHNode*>(bvh_nodes);
+    if (n_models > 0 && models && (!bvh_nodes || n_nodes == 0)) {
+        int32_t rc = build_bvh_ploc(static_cast<const Model*>(models), n_models, &built);
+        if (rc != BRT_OK) return ctx_fail(ctx, rc, g_last_error);
+        nodes = built.data();
+        n_nodes = (uint32_t)built.size();
+    }
+    std::string err;
+    int32_t rc = validate_and_encode(static_cast<const Model*>(models), n_models, static_cast<const Material*>(materials),
+                                     n_materials, nodes, n_nodes, &ctx->enc, &err);
+    if (rc != BRT_OK) return ctx_fail(ctx, rc, err);
+    const EncodedScene& e = ctx->enc;
+
+    // one blob per device, sections 256-byte aligned
+    struct Sec { const void* src; size_t bytes; size_t off; };
+    Sec secs[8] = {
+        {e.q0.data(), e.q0.size() * 4, 0}, {e.q1.data(), e.q1.size() * 4, 0}, {e.q2.data(), e.q2.size() * 4, 0},
+        {e.qd.data(), e.qd.size() * 4, 0}, {e.spheres.data(), e.spheres.size() * 4, 0},
+        {e.sphere_material.data(), e.sphere_material.size() * 4, 0}, {e.materials.data(), e.materials.size() * 4, 0},
+        {e.leaf_table.data(), e.leaf_table.size() * 4, 0}};
+    size_t total = 0;
+    for (auto& s : secs) { s.off = total; total += align256(s.bytes ? s.bytes : 16); }
+
+    for (auto& dc : ctx->devs) {
+        HIP_TRY(ctx, hipSetDevice(dc.device));
+        int32_t r2 = ensure(ctx, &dc.d_scene, &dc.scene_cap, total);
+        if (r2 != BRT_OK) return r2;
+        for (auto& s : secs)
+            if (s.bytes) HIP_TRY(ctx, hipMemcpyAsync(dc.d_scene + s.off, s.src, s.bytes, hipMemcpyHostToDevice, dc.stream));
+        DeviceSceneView v{};
+        v.q0 = reinterpret_cast<const float*>(dc.d_scene + secs[0].off);
+        v.q1 = reinterpret_cast<const float*>(dc.d_scene + secs[1].off);
+        v.q2 = reinterpret_cast<const float*>(dc.d_scene + secs[2].off);
+        v.qd = reinterpret_cast<const uint32_t*>(dc.d_scene + secs[3].off);
+        v.spheres = reinterpret_cast<const float*>(dc.d_scene + secs[4].off);
+        v.sphere_material = reinterpret_cast<const uint32_t*>(dc.d_scene + secs[5].off);
+        v.materials = reinterpret_cast<const float*>(dc.d_scene + secs[6].off);
+        v.leaf_table = reinterpret_cast<const uint32_t*>(dc.d_scene + secs[7].off);
+        v.n_pairs = e.n_pairs;
+        v.n_models = e.n_models;
+        v.n_materials = e.n_materials;
+        v.n_leaf_table = (uint32_t)(e.leaf_table.size() / 2);
+        v.root_desc = e.root_desc;
+        v.stack_entries = e.stack_entries;
+        dc.view = v;
+    }
+    for (auto& dc : ctx->devs) {
+        HIP_TRY(ctx, hipSetDevice(dc.device));
+        HIP_TRY(ctx, hipStreamSynchronize(dc.stream));  // the caller's vectors are no longer referenced
+    }
+    ctx->has_scene = true;
+    return BRT_OK;
+}
+
+uint32_t brt_tile_rows(uint32_t height, uint32_t n_parts) {
+    if (n_parts == 0) return 0;
+    const uint32_t strips = (height + BRT_STRIP_ROWS - 1u) / BRT_STRIP_ROWS;
+    return ((strips + n_parts - 1u) / n_parts) * BRT_STRIP_ROWS;
+}
+
+int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level, uint32_t width,
+                               uint32_t height, uint32_t part, uint32_t n_parts, const float* d_raster_rgba,
+                               const float* d_raster_depth, float* d_out_tile, void* hip_stream, uint32_t flags,
+                               brt_stats* stats) {
+    if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (!d_out_tile) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "d_out_tile is null");
+    if (!ctx->has_scene && level != 0u) return ctx_fail(ctx, BRT_ERR_NO_SCENE, "brt_upload_scene has not succeeded yet");
+    const auto t0 = std::chrono::steady_clock::now();
+    FrameParams fp;
+    int32_t rc = make_frame_params(ctx, camera80, window16, level, width, height, part, n_parts, &fp);
+    if (rc != BRT_OK) return rc;
+    DeviceCtx& dc = ctx->devs[0];
+    HIP_TRY(ctx, hipSetDevice(dc.device));
+    const bool own_stream = (hip_stream == nullptr);
+    hipStream_t stream = own_stream ? dc.stream : static_cast<hipStream_t>(hip_stream);
+    LaunchPlan lp{};
+    rc = launch_part(ctx, dc, fp, d_raster_rgba, d_raster_depth, d_out_tile, stream, flags, own_stream, &lp);
+    if (rc != BRT_OK) return rc;
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        stats->paths = part_pixels(fp) * (uint64_t)fp.sample_count;
+        stats->lds_bytes = (uint32_t)lp.lds_bytes;
+        stats->scene_in_lds = lp.lds_scene ? 1u : 0u;
+        stats->n_workgroups = lp.grid;
+        stats->threads_per_workgroup = lp.block;
+    }
+    if (own_stream) {
+        brt_stats tmp{};
+        rc = read_counters(ctx, dc, stream, &tmp);  // synchronises
+        if (rc != BRT_OK) return rc;
+        float ms = 0.0f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, dc.ev0, dc.ev1));
+        if (stats) {
+            stats->rays = tmp.rays; stats->node_pops = tmp.node_pops; stats->interior_visits = tmp.interior_visits;
+            stats->sphere_tests = tmp.sphere_tests; stats->hits = tmp.hits;
+            stats->kernel_ms = ms;
+            stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+    }
+    return BRT_OK;
+}
+
+int32_t brt_render(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level, uint32_t width, uint32_t height,
+                   const float* raster_rgba, const float* raster_depth, float* out_rgba, uint32_t flags, brt_stats* stats) {
+    if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (!out_rgba) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "out_rgba is null");
+    if (!ctx->has_scene && level != 0u) return ctx_fail(ctx, BRT_ERR_NO_SCENE, "brt_upload_scene has not succeeded yet");
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint32_t n_parts = (uint32_t)ctx->devs.size();
+    std::vector<FrameParams> fps(n_parts);
+    for (uint32_t p = 0; p < n_parts; p++) {
+        int32_t rc = make_frame_params(ctx, camera80, window16, level, width, height, p, n_parts, &fps[p]);
+        if (rc != BRT_OK) return rc;
+    }
+    const uint32_t tile_rows = brt_tile_rows(height, n_parts);
+    const size_t tile_bytes = (size_t)tile_rows * width * 16;
+    const size_t frame_px = (size_t)width * height;
+    brt_stats st{};
+    LaunchPlan lp{};
+
+    // launch every device, then collect: the devices trace their strips concurrently
+    for (uint32_t p = 0; p < n_parts; p++) {
+        DeviceCtx& dc = ctx->devs[p];
+        HIP_TRY(ctx, hipSetDevice(dc.device));
+        int32_t rc = ensure(ctx, &dc.d_tile, &dc.tile_cap, tile_bytes);
+        if (rc != BRT_OK) return rc;
+        const float* d_rgba = nullptr;
+        const float* d_depth = nullptr;
+        if (raster_rgba) {
+            rc = ensure(ctx, &dc.d_raster_rgba, &dc.raster_rgba_cap, frame_px * 16);
+            if (rc != BRT_OK) return rc;
+            HIP_TRY(ctx, hipMemcpyAsync(dc.d_raster_rgba, raster_rgba, frame_px * 16, hipMemcpyHostToDevice, dc.stream));
+            d_rgba = dc.d_raster_rgba;
+        }
+        if (raster_depth) {
+            rc = ensure(ctx, &dc.d_raster_depth, &dc.raster_depth_cap, frame_px * 4);
+            if (rc != BRT_OK) return rc;
+            HIP_TRY(ctx, hipMemcpyAsync(dc.d_raster_depth, raster_depth, frame_px * 4, hipMemcpyHostToDevice, dc.stream));
+            d_depth = dc.d_raster_depth;
+        }
+        if (dc.stage_cap < tile_bytes) {
+            if (dc.h_stage) HIP_TRY(ctx, hipHostFree(dc.h_stage));
+            dc.h_stage = nullptr;
+            dc.stage_cap = 0;
+            HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&dc.h_stage), tile_bytes, hipHostMallocDefault));
+            dc.stage_cap = tile_bytes;
+        }
+        rc = launch_part(ctx, dc, fps[p], d_rgba, d_depth, dc.d_tile, dc.stream, flags, true, &lp);
+        if (rc != BRT_OK) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(dc.h_stage, dc.d_tile, tile_bytes, hipMemcpyDeviceToHost, dc.stream));
+    }
+    double kernel_ms = 0.0, gather_ms = 0.0;
+    for (uint32_t p = 0; p < n_parts; p++) {
+        DeviceCtx& dc = ctx->devs[p];
+        HIP_TRY(ctx, hipSetDevice(dc.device));
+        int32_t rc = read_counters(ctx, dc, dc.stream, &st);  // synchronises the stream
+        if (rc != BRT_OK) return rc;
+        float ms = 0.0f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, dc.ev0, dc.ev1));
+        if (ms > kernel_ms) kernel_ms = ms;
+        const auto g0 = std::chrono::steady_clock::now();
+        const uint32_t strips = (height + BRT_STRIP_ROWS - 1u) / BRT_STRIP_ROWS;
+        for (uint32_t s = p, k = 0; s < strips; s += n_parts, k++) {
+            const uint32_t r0 = s * BRT_STRIP_ROWS;
+            const uint32_t rows = (r0 + BRT_STRIP_ROWS <= height) ? BRT_STRIP_ROWS : (height - r0);
+            std::memcpy(out_rgba + (size_t)r0 * width * 4, dc.h_stage + (size_t)k * BRT_STRIP_ROWS * width * 4,
+                        (size_t)rows * width * 16);
+        }
+        gather_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g0).count();
+        st.paths += part_pixels(fps[p]) * (uint64_t)fps[p].sample_count;
+    }
+    if (stats) {
+        *stats = st;
+        stats->kernel_ms = kernel_ms;
+        stats->gather_ms = gather_ms;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        stats->lds_bytes = (uint32_t)lp.lds_bytes;
+        stats->scene_in_lds = lp.lds_scene ? 1u : 0u;
+        stats->n_workgroups = lp.grid;
+        stats->threads_per_workgroup = lp.block;
+    }
+    return BRT_OK;
+}
+
+int32_t brt_deinterleave_device(brt_ctx* ctx, const float* d_tiles, uint32_t n_parts, uint32_t width, uint32_t height,
+                                float* d_frame, void* hip_stream) {
+    if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (!d_tiles || !d_frame || n_parts == 0) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "null buffer / n_parts == 0");
+    DeviceCtx& dc = ctx->devs[0];
+    HIP_TRY(ctx, hipSetDevice(dc.device));
+    hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : dc.stream;
+    HIP_TRY(ctx, launch_deinterleave(d_tiles, d_frame, width, height, n_parts, brt_tile_rows(height, n_parts), stream));
+    if (!hip_stream) HIP_TRY(ctx, hipStreamSynchronize(stream));
+    return BRT_OK;
+}
+
+int32_t brt_debug_eval(brt_ctx* ctx, uint32_t op, const float* in16, float* out8, uint32_t n) {
+    if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (!in16 || !out8) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "null buffer");
+    if (n == 0) return BRT_OK;
+    DeviceCtx& dc = ctx->devs[0];
+    HIP_TRY(ctx, hipSetDevice(dc.device));
+    float* d_in = nullptr;
+    float* d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_in), (size_t)n * 64));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n * 32);
+    if (e != hipSuccess) { (void)hipFree(d_in); return ctx_fail(ctx, BRT_ERR_HIP, hipGetErrorString(e)); }
+    int32_t rc = BRT_OK;
+    auto body = [&]() -> int32_t {
+        HIP_TRY(ctx, hipMemcpyAsync(d_in, in16, (size_t)n * 64, hipMemcpyHostToDevice, dc.stream));
+        HIP_TRY(ctx, launch_debug_eval(op, d_in, d_out, n, dc.stream));
+        HIP_TRY(ctx, hipMemcpyAsync(out8, d_out, (size_t)n * 32, hipMemcpyDeviceToHost, dc.stream));
+        HIP_TRY(ctx, hipStreamSynchronize(dc.stream));
+        return BRT_OK;
+    };
+    rc = body();
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+}  // extern "C"

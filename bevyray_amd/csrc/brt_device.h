@@ -1,0 +1,273 @@
+// brt_device.h -- device-side arithmetic of the ray loop for gfx950.
+//
+// Every function cites the reference lines whose RESULT it reproduces (reference
+// assets/shaders/raytrace.wgsl, random.wgsl).  The structure is not the shader's: invariants
+// are hoisted per ray / per frame, the BVH is walked through re-encoded pair records
+// (brt_layout.h) with the top of the stack in a register, and hits carry (t, sphere id) until
+// the walk ends.  Hoisting never changes a value: each hoisted expression is the same tree of
+// separately rounded f32 operations (build flag -ffp-contract=off; correctly rounded
+// divide/sqrt are hipcc's default).
+//
+// Numeric policy (same as oracle/bevyray_oracle.c):
+//   dot = (x*x' + y*y') + z*z';  normalize(v) = v / sqrt(dot(v,v));
+//   min/max = v_min_f32 / v_max_f32 (IEEE minNum/maxNum, -0 < +0);
+//   pow(x,5) = (x*x)*(x*x)*x;  u32(f32) truncates and saturates.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "brt_layout.h"
+
+namespace brt {
+
+#define BRT_DEV __device__ __forceinline__
+
+constexpr float kInf = 3.40282347e+38f;  // const.wgsl:2 (FLT_MAX, compared with ==)
+
+struct f3 {
+    float x, y, z;
+};
+BRT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+BRT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+BRT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+BRT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+BRT_DEV f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+BRT_DEV f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+BRT_DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+BRT_DEV f3 normalize3(f3 v) {
+    const float len = __builtin_sqrtf(dot3(v, v));
+    return mk3(v.x / len, v.y / len, v.z / len);
+}
+BRT_DEV float min_f(float a, float b) { return __builtin_fminf(a, b); }
+BRT_DEV float max_f(float a, float b) { return __builtin_fmaxf(a, b); }
+
+BRT_DEV uint32_t f32_to_u32_sat(float f) {
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)f;
+}
+
+// random.wgsl:8-15
+BRT_DEV uint32_t rng_next(uint32_t state) {
+    const uint32_t old = state + 747796405u + 2891336453u;
+    const uint32_t word = ((old >> ((old >> 28u) + 4u)) ^ old) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+// random.wgsl:3-6; f32(0xffffffffu) == 2^32, and x / 2^32 == x * 2^-32 exactly
+BRT_DEV float rng_float(uint32_t& state) {
+    state = rng_next(state);
+    return (float)state * 2.3283064365386963e-10f;
+}
+// random.wgsl:17-30 (a point INSIDE the unit ball, not normalised)
+BRT_DEV f3 rng_unit_ball(uint32_t& state) {
+    f3 p;
+    for (;;) {
+        const float x = rng_float(state);
+        const float y = rng_float(state);
+        const float z = rng_float(state);
+        p = mk3(2.0f * x - 1.0f, 2.0f * y - 1.0f, 2.0f * z - 1.0f);
+        if (dot3(p, p) <= 1.0f) break;
+    }
+    return p;
+}
+
+// raytrace.wgsl:387-398 with 1/d hoisted per ray.  Returns whether the child is pushed
+// (raytrace.wgsl:331,338: dst != INF && dst < closest.distance).
+BRT_DEV bool slab_push(f3 o, f3 inv, f3 bmin, f3 bmax, float closest) {
+    const float tminx = (bmin.x - o.x) * inv.x, tmaxx = (bmax.x - o.x) * inv.x;
+    const float tminy = (bmin.y - o.y) * inv.y, tmaxy = (bmax.y - o.y) * inv.y;
+    const float tminz = (bmin.z - o.z) * inv.z, tmaxz = (bmax.z - o.z) * inv.z;
+    const float t_near = max_f(max_f(min_f(tminx, tmaxx), min_f(tminy, tmaxy)), min_f(tminz, tmaxz));
+    const float t_far = min_f(min_f(max_f(tminx, tmaxx), max_f(tminy, tmaxy)), max_f(tminz, tmaxz));
+    const bool hit = (t_far >= t_near) && (t_far > 0.0f);
+    const float dst = hit ? (t_near > 0.0f ? t_near : 0.0f) : kInf;
+    return (dst != kInf) && (dst < closest);
+}
+
+// raytrace.wgsl:371-383 + the accept test of :353-354.  `a` = dot(d,d) hoisted per ray,
+// s.w = radius*radius.  (t != -1.0 is implied by t > 0.001.)
+BRT_DEV void sphere_test(f3 o, f3 d, float a, float4 s, uint32_t idx, float& closest, uint32_t& closest_idx) {
+    const f3 oc = mk3(s.x - o.x, s.y - o.y, s.z - o.z);
+    const float h = dot3(d, oc);
+    const float c = dot3(oc, oc) - s.w;
+    const float disc = h * h - a * c;
+    if (!(disc < 0.0f)) {
+        const float t = (h - __builtin_sqrtf(disc)) / a;
+        if (t > 0.001f && t < closest) {
+            closest = t;
+            closest_idx = idx;
+        }
+    }
+}
+
+// Scene accessors.  The persistent kernel instantiates with LDS pointers, the bring-up
+// kernel and the large-scene variant with global pointers.
+struct ScenePtrs {
+    const float4* q0;
+    const float4* q1;
+    const float4* q2;
+    const uint2* qd;
+    const float4* spheres;
+    const uint32_t* sphere_material;
+    const float4* materials;
+    const uint2* leaf_table;
+};
+
+struct HitCounters {
+    uint32_t node_pops, interior, sphere_tests, hits;
+};
+
+// raytrace.wgsl:313-362: closest hit of one ray.  `stk` points at this lane's column of a
+// [entries][64] u32 array (LDS) or at a private array with stride 1.
+// Reference bookkeeping: stack_index == (entries in stk) + (cur valid ? 1 : 0); the loop
+// condition stack_index > 0 && stack_index < 32 (raytrace.wgsl:320) is `valid && n < 31`.
+template <int STRIDE, bool COUNTERS, typename StackT>
+BRT_DEV void raycast(const ScenePtrs& sc, uint32_t root_desc, StackT* stk, f3 o, f3 d, float& t_out,
+                     uint32_t& idx_out, HitCounters& hc) {
+    const float a = dot3(d, d);
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float closest = kInf;
+    uint32_t closest_idx = 0xffffffffu;
+    uint32_t cur = root_desc;
+    int n = 0;
+    bool valid = true;
+    while (valid && n < 31) {
+        if (COUNTERS) hc.node_pops++;
+        if (cur & DESC_LEAF) {
+            uint32_t first = cur & DESC_INDEX_MASK, count = 1;
+            if (!(cur & 0x40000000u)) {
+                const uint2 lt = sc.leaf_table[first];
+                first = lt.x;
+                count = lt.y;
+            }
+            for (uint32_t i = first; i < first + count; i++) {
+                if (COUNTERS) hc.sphere_tests++;
+                sphere_test(o, d, a, sc.spheres[i], i, closest, closest_idx);
+            }
+            if (n > 0) { n--; cur = stk[n * STRIDE]; } else valid = false;
+        } else {
+            if (COUNTERS) hc.interior++;
+            const float4 A = sc.q0[cur], B = sc.q1[cur], C = sc.q2[cur];
+            const uint2 D = sc.qd[cur];
+            const bool p1 = slab_push(o, inv, mk3(A.x, A.y, A.z), mk3(A.w, B.x, B.y), closest);
+            const bool p2 = slab_push(o, inv, mk3(B.z, B.w, C.x), mk3(C.y, C.z, C.w), closest);
+            // reference pushes `index` then `index+1`; the later push is popped first
+            if (p2) {
+                if (p1) { stk[n * STRIDE] = D.x; n++; }
+                cur = D.y;
+            } else if (p1) {
+                cur = D.x;
+            } else {
+                if (n > 0) { n--; cur = stk[n * STRIDE]; } else valid = false;
+            }
+        }
+    }
+    t_out = closest;
+    idx_out = closest_idx;
+}
+
+// raytrace.wgsl:400-402
+BRT_DEV f3 reflect3(f3 v, f3 n) { return v - (2.0f * dot3(v, n)) * n; }
+// raytrace.wgsl:404-409
+BRT_DEV f3 refract3(f3 v, f3 n, float eta) {
+    const float cos_theta = min_f(dot3(neg3(v), n), 1.0f);
+    const f3 perp = eta * (v + cos_theta * n);
+    const float par = -__builtin_sqrtf(__builtin_fabsf(1.0f - dot3(perp, perp)));
+    return perp + par * n;
+}
+// raytrace.wgsl:411-416
+BRT_DEV float schlick(float cosine, float ri) {
+    float r0 = (1.0f - ri) / (1.0f + ri);
+    r0 = r0 * r0;
+    const float x = 1.0f - cosine;
+    const float x2 = x * x;
+    return r0 + (1.0f - r0) * ((x2 * x2) * x);
+}
+
+// raytrace.wgsl:231-299 applied to the hit (t, idx) of ray (o,d); the HitInfo fields are
+// rebuilt here from (t, idx) exactly as raytrace.wgsl:355-358 builds them.
+// Returns absorbed; writes the scattered ray and the attenuation.
+BRT_DEV bool scatter(const ScenePtrs& sc, f3& o, f3& d, float t, uint32_t idx, uint32_t& rng, f3& attenuation) {
+    const float4 s = sc.spheres[idx];
+    const f3 pos = mk3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);          // ray_at, :130-132
+    const f3 nrm = normalize3(mk3(pos.x - s.x, pos.y - s.y, pos.z - s.z));    // :356
+    const uint32_t mid = sc.sphere_material[idx];
+    const float4 m0 = sc.materials[2 * mid];      // base_color.rgb, metallic
+    const float4 m1 = sc.materials[2 * mid + 1];  // roughness, reflectance, ior, specular_transmission
+    bool absorbed;
+    if (rng_float(rng) < m0.w) {                                              // metal, :234-245
+        const f3 fuzz = m1.x * rng_unit_ball(rng);
+        const f3 refl = normalize3(reflect3(d, nrm)) + fuzz;
+        d = refl;
+        attenuation = mk3(m0.x, m0.y, m0.z);
+        absorbed = dot3(d, nrm) < 0.0f;
+    } else if (rng_float(rng) < m1.w) {                                       // glass, :249-280
+        const bool front_face = dot3(d, nrm) < 0.0f;                          // :358
+        const float ri = front_face ? (1.0f / m1.z) : m1.z;
+        const f3 u = normalize3(d);
+        const float cos_theta = min_f(dot3(neg3(u), nrm), 1.0f);
+        const float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+        const bool cannot_refract = ri * sin_theta > 1.0f;
+        const float refl = schlick(cos_theta, ri);
+        const float draw = rng_float(rng);                                    // always drawn
+        d = (cannot_refract || refl > draw) ? reflect3(u, nrm) : refract3(u, nrm, ri);
+        attenuation = mk3(1.0f, 1.0f, 1.0f);
+        absorbed = false;
+    } else {                                                                  // diffuse, :281-297
+        const f3 b1 = rng_unit_ball(rng);
+        const f3 b2 = rng_unit_ball(rng);
+        f3 sd = (nrm + b1) + m1.x * b2;
+        const float eps = 1e-8f;
+        if (__builtin_fabsf(sd.x) < eps && __builtin_fabsf(sd.y) < eps && __builtin_fabsf(sd.z) < eps) sd = nrm;
+        d = sd;
+        attenuation = mk3(m0.x, m0.y, m0.z);
+        absorbed = dot3(d, nrm) < 0.0f;
+    }
+    o = pos;
+    return absorbed;
+}
+
+// raytrace.wgsl:364-369
+BRT_DEV f3 background_gradient(f3 d) {
+    const f3 u = normalize3(d);
+    const float a = 0.5f * (u.y + 1.0f);
+    const float b = 1.0f - a;
+    return mk3(b * 1.0f + a * 0.5f, b * 1.0f + a * 0.7f, b * 1.0f + a * 1.0f);
+}
+
+// raytrace.wgsl:95 (seed) -- uv at the pixel centre
+BRT_DEV uint32_t pixel_seed(const FrameParams& fp, float uvx, float uvy) {
+    return f32_to_u32_sat((fp.seed_scaled * (uvx * 402.0f)) * (uvy * 31.5f));
+}
+
+// raytrace.wgsl:139-156 with frame-uniform terms hoisted into FrameParams.
+// ndc0x = uv.x*2-1, ndc0y = 1-uv.y*2.
+BRT_DEV f3 camera_ray_dir(const FrameParams& fp, float ndc0x, float ndc0y, uint32_t& rng) {
+    const float rx = rng_float(rng) - 0.5f;
+    const float ry = rng_float(rng) - 0.5f;
+    const float ndc_x = ndc0x + fp.inv_width * rx;
+    const float ndc_y = ndc0y + fp.inv_height * ry;
+    const float sx = (ndc_x * fp.aspect) * fp.tan_half_fov;
+    const float sy = ndc_y * fp.tan_half_fov;
+    const f3 cd = mk3(fp.cam_dir[0], fp.cam_dir[1], fp.cam_dir[2]);
+    const f3 cr = mk3(fp.cam_right[0], fp.cam_right[1], fp.cam_right[2]);
+    const f3 cu = mk3(fp.cam_up[0], fp.cam_up[1], fp.cam_up[2]);
+    return normalize3((cd + sx * cr) + sy * cu);
+}
+
+// raytrace.wgsl:104-122: final colour of a pixel from the averaged sample colour/depth.
+BRT_DEV float4 resolve_pixel(const FrameParams& fp, f3 avg, float avg_depth, const float* raster_rgba,
+                             const float* raster_depth, size_t frame_pix) {
+    if (fp.level == 1u || fp.level == 2u) {
+        const float depth = raster_depth ? raster_depth[frame_pix] : 0.0f;
+        float rd = avg_depth;
+        if (rd > fp.far_) rd = -1.0f;
+        else rd = fp.near_ / rd;
+        if (depth > rd) {
+            if (raster_rgba) return reinterpret_cast<const float4*>(raster_rgba)[frame_pix];
+            return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    }
+    return make_float4(avg.x, avg.y, avg.z, 1.0f);
+}
+
+}  // namespace brt

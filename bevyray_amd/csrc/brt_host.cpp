@@ -1,0 +1,528 @@
+// brt_host.cpp -- host-side (CPU) parts of the render node that run before the kernels:
+//   * scene validation + re-encoding into the device format   (brt_layout.h)
+//   * native PLOC BVH builder                                  (replaces the obvhs call,
+//                                                               reference extract.rs:315-332)
+//   * seeded scene generators                                  (reference main.rs:49-240)
+//   * mirror of the extract stage for non-Rust hosts           (reference extract.rs:63-209)
+// None of this traces rays; there is no CPU rendering path in the product.
+#include "brt_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+
+namespace brt {
+
+thread_local std::string g_last_error;
+
+int32_t fail(int32_t code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+// ---------------------------------------------------------------------------------------
+// Validation + encoding
+// ---------------------------------------------------------------------------------------
+
+int32_t validate_and_encode(const Model* models, uint32_t n_models, const Material* materials, uint32_t n_materials,
+                            const BVHNode* nodes, uint32_t n_nodes, EncodedScene* out, std::string* err) {
+    if (n_models == 0) { *err = "scene has no spheres (the reference skips the pass)"; return BRT_ERR_EMPTY_SCENE; }
+    if (!models || !materials || n_materials == 0) { *err = "null models/materials"; return BRT_ERR_INVALID_ARGUMENT; }
+    if (!nodes || n_nodes == 0) { *err = "null/empty BVH"; return BRT_ERR_INVALID_BVH; }
+    if (n_models > DESC_INDEX_MASK || n_nodes > DESC_INDEX_MASK) { *err = "scene too large for 30-bit descriptors"; return BRT_ERR_UNSUPPORTED; }
+    for (uint32_t i = 0; i < n_models; i++) {
+        if (models[i].material_id >= n_materials) {
+            *err = "model " + std::to_string(i) + ": material_id " + std::to_string(models[i].material_id) +
+                   " >= n_materials " + std::to_string(n_materials);
+            return BRT_ERR_INVALID_SCENE;
+        }
+    }
+
+    // Breadth-first walk from node 0.  Interior nodes get pair-record ids in BFS order, so
+    // the top of the tree has the lowest record ids.
+    std::vector<uint32_t> pair_id(n_nodes, 0xffffffffu);
+    std::vector<uint8_t> seen(n_nodes, 0);
+    std::vector<uint32_t> depth(n_nodes, 0);
+    std::vector<uint32_t> order;  // interior nodes in BFS order
+    order.reserve(n_nodes / 2 + 1);
+    uint32_t max_leaf_depth = 0;
+
+    auto leaf_check = [&](uint32_t n) -> bool {
+        uint64_t end = (uint64_t)nodes[n].index + (uint64_t)nodes[n].model_count;
+        return end <= (uint64_t)n_models;
+    };
+
+    std::vector<uint32_t> frontier{0};
+    seen[0] = 1;
+    size_t head = 0;
+    while (head < frontier.size()) {
+        uint32_t n = frontier[head++];
+        const BVHNode& nd = nodes[n];
+        if (nd.model_count > 0) {
+            if (!leaf_check(n)) {
+                *err = "BVH leaf " + std::to_string(n) + ": models [" + std::to_string(nd.index) + ", +" +
+                       std::to_string(nd.model_count) + ") exceed n_models " + std::to_string(n_models);
+                return BRT_ERR_INVALID_BVH;
+            }
+            max_leaf_depth = std::max(max_leaf_depth, depth[n]);
+            continue;
+        }
+        uint64_t c0 = nd.index, c1 = (uint64_t)nd.index + 1;
+        if (c1 >= n_nodes) {
+            *err = "BVH node " + std::to_string(n) + ": child index " + std::to_string(c1) + " >= n_nodes " + std::to_string(n_nodes);
+            return BRT_ERR_INVALID_BVH;
+        }
+        if (seen[c0] || seen[c1]) {
+            *err = "BVH node " + std::to_string(n) + ": child " + std::to_string(seen[c0] ? c0 : c1) +
+                   " is reachable twice (cycle or shared subtree)";
+            return BRT_ERR_INVALID_BVH;
+        }
+        seen[c0] = seen[c1] = 1;
+        depth[c0] = depth[c1] = depth[n] + 1;
+        pair_id[n] = (uint32_t)order.size();
+        order.push_back(n);
+        frontier.push_back((uint32_t)c0);
+        frontier.push_back((uint32_t)c1);
+    }
+
+    EncodedScene& e = *out;
+    e = EncodedScene();
+    e.n_pairs = (uint32_t)order.size();
+    e.q0.resize(4 * (size_t)e.n_pairs);
+    e.q1.resize(4 * (size_t)e.n_pairs);
+    e.q2.resize(4 * (size_t)e.n_pairs);
+    e.qd.resize(2 * (size_t)e.n_pairs);
+
+    auto desc_of = [&](uint32_t n) -> uint32_t {
+        const BVHNode& nd = nodes[n];
+        if (nd.model_count == 0) return pair_id[n];
+        if (nd.model_count == 1) return DESC_LEAF1 | nd.index;
+        uint32_t id = (uint32_t)(e.leaf_table.size() / 2);
+        e.leaf_table.push_back(nd.index);
+        e.leaf_table.push_back(nd.model_count);
+        return DESC_LEAF | id;
+    };
+
+    e.root_desc = desc_of(0);
+    for (uint32_t i = 0; i < e.n_pairs; i++) {
+        const BVHNode& nd = nodes[order[i]];
+        const BVHNode& L = nodes[nd.index];
+        const BVHNode& R = nodes[nd.index + 1];
+        float* a = &e.q0[4 * (size_t)i];
+        float* b = &e.q1[4 * (size_t)i];
+        float* c = &e.q2[4 * (size_t)i];
+        a[0] = L.bounds_min[0]; a[1] = L.bounds_min[1]; a[2] = L.bounds_min[2]; a[3] = L.bounds_max[0];
+        b[0] = L.bounds_max[1]; b[1] = L.bounds_max[2]; b[2] = R.bounds_min[0]; b[3] = R.bounds_min[1];
+        c[0] = R.bounds_min[2]; c[1] = R.bounds_max[0]; c[2] = R.bounds_max[1]; c[3] = R.bounds_max[2];
+        e.qd[2 * (size_t)i] = desc_of(nd.index);
+        e.qd[2 * (size_t)i + 1] = desc_of(nd.index + 1);
+    }
+
+    e.n_models = n_models;
+    e.spheres.resize(4 * (size_t)n_models);
+    e.sphere_material.resize(n_models);
+    for (uint32_t i = 0; i < n_models; i++) {
+        e.spheres[4 * (size_t)i + 0] = models[i].position[0];
+        e.spheres[4 * (size_t)i + 1] = models[i].position[1];
+        e.spheres[4 * (size_t)i + 2] = models[i].position[2];
+        e.spheres[4 * (size_t)i + 3] = models[i].radius * models[i].radius;  // raytrace.wgsl:375
+        e.sphere_material[i] = models[i].material_id;
+    }
+    e.n_materials = n_materials;
+    e.materials.resize(8 * (size_t)n_materials);
+    std::memcpy(e.materials.data(), materials, 32 * (size_t)n_materials);
+    e.max_leaf_depth = max_leaf_depth;
+    // After popping a node of depth k the stack holds at most k entries and receives at
+    // most two pushes, so the deepest write index is max_leaf_depth (entries needed: +1).
+    e.stack_entries = std::min<uint32_t>(32u, max_leaf_depth + 1u);
+    if (e.stack_entries < 2) e.stack_entries = 2;
+    return BRT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// PLOC builder (Meister & Bittner 2018), search radius 24, 63-bit Morton codes.
+// Restates the published algorithm; obvhs 0.1.x itself is not available here, so the
+// topology is this builder's own (pixels do not depend on it).
+// ---------------------------------------------------------------------------------------
+
+namespace {
+
+struct Box {
+    float mn[3], mx[3];
+};
+inline Box merge(const Box& a, const Box& b) {
+    Box r;
+    for (int k = 0; k < 3; k++) { r.mn[k] = std::min(a.mn[k], b.mn[k]); r.mx[k] = std::max(a.mx[k], b.mx[k]); }
+    return r;
+}
+inline float half_area(const Box& b) {
+    float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+inline uint64_t spread21(uint64_t x) {
+    x &= 0x1fffffull;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+struct TmpNode {
+    Box box;
+    int32_t left, right;   // children in tmp array, or -1
+    uint32_t prim;         // for leaves
+};
+
+}  // namespace
+
+int32_t build_bvh_ploc(const Model* models, uint32_t n_models, std::vector<BVHNode>* out) {
+    out->clear();
+    if (n_models == 0) return BRT_OK;
+    constexpr int SEARCH = 24;  // build_ploc::<24>, extract.rs:316
+
+    std::vector<TmpNode> tmp;
+    tmp.reserve(2 * (size_t)n_models);
+    Box scene;
+    for (int k = 0; k < 3; k++) { scene.mn[k] = std::numeric_limits<float>::infinity(); scene.mx[k] = -scene.mn[k]; }
+    for (uint32_t i = 0; i < n_models; i++) {
+        TmpNode t;
+        const float pad = models[i].radius + 0.1f;  // Model::aabb, extract.rs:220-227
+        for (int k = 0; k < 3; k++) { t.box.mn[k] = models[i].position[k] - pad; t.box.mx[k] = models[i].position[k] + pad; }
+        t.left = t.right = -1;
+        t.prim = i;
+        tmp.push_back(t);
+        scene = merge(scene, t.box);
+    }
+    // Morton codes of the AABB centres, 21 bits per axis
+    std::vector<std::pair<uint64_t, uint32_t>> keys(n_models);
+    double ext[3];
+    for (int k = 0; k < 3; k++) ext[k] = std::max(1e-30, (double)scene.mx[k] - (double)scene.mn[k]);
+    for (uint32_t i = 0; i < n_models; i++) {
+        uint64_t q[3];
+        for (int k = 0; k < 3; k++) {
+            double c = 0.5 * ((double)tmp[i].box.mn[k] + (double)tmp[i].box.mx[k]);
+            double u = (c - (double)scene.mn[k]) / ext[k];
+            if (!(u > 0.0)) u = 0.0;
+            if (u > 1.0) u = 1.0;
+            q[k] = (uint64_t)(u * 2097151.0);
+        }
+        keys[i] = {spread21(q[0]) | (spread21(q[1]) << 1) | (spread21(q[2]) << 2), i};
+    }
+    std::stable_sort(keys.begin(), keys.end());
+
+    std::vector<int32_t> cur(n_models), next;
+    for (uint32_t i = 0; i < n_models; i++) cur[i] = (int32_t)keys[i].second;
+    std::vector<int32_t> nn;
+    while (cur.size() > 1) {
+        const int32_t n = (int32_t)cur.size();
+        nn.assign(n, -1);
+        for (int32_t i = 0; i < n; i++) {
+            // Nearest neighbour under the strict total order (area, min(i,j), max(i,j)): the
+            // globally smallest pair is then always mutual, so every round merges something.
+            float best = std::numeric_limits<float>::infinity();
+            int32_t bj = -1;
+            const int32_t lo = std::max(0, i - SEARCH), hi = std::min(n - 1, i + SEARCH);
+            for (int32_t j = lo; j <= hi; j++) {
+                if (j == i) continue;
+                float a = half_area(merge(tmp[cur[i]].box, tmp[cur[j]].box));
+                bool better = a < best;
+                if (!better && a == best && bj >= 0) {
+                    const int32_t p0 = std::min(i, j), p1 = std::max(i, j), q0 = std::min(i, bj), q1 = std::max(i, bj);
+                    better = p0 < q0 || (p0 == q0 && p1 < q1);
+                }
+                if (better || bj < 0) { best = a; bj = j; }
+            }
+            nn[i] = bj;
+        }
+        next.clear();
+        for (int32_t i = 0; i < n; i++) {
+            const int32_t j = nn[i];
+            if (nn[j] == i) {
+                if (i < j) {
+                    TmpNode t;
+                    t.box = merge(tmp[cur[i]].box, tmp[cur[j]].box);
+                    t.left = cur[i];
+                    t.right = cur[j];
+                    t.prim = 0;
+                    tmp.push_back(t);
+                    next.push_back((int32_t)tmp.size() - 1);
+                }
+            } else {
+                next.push_back(cur[i]);
+            }
+        }
+        cur.swap(next);
+    }
+
+    // Flatten breadth-first: node 0 = root, the two children of an interior node adjacent.
+    out->resize(tmp.size());
+    std::vector<std::pair<int32_t, uint32_t>> queue;  // (tmp index, output slot)
+    queue.reserve(tmp.size());
+    queue.push_back({cur[0], 0u});
+    uint32_t next_slot = 1;
+    for (size_t head = 0; head < queue.size(); head++) {
+        const TmpNode& t = tmp[queue[head].first];
+        BVHNode& o = (*out)[queue[head].second];
+        std::memset(&o, 0, sizeof o);
+        for (int k = 0; k < 3; k++) { o.bounds_min[k] = t.box.mn[k]; o.bounds_max[k] = t.box.mx[k]; }
+        if (t.left < 0) {
+            o.index = t.prim;      // indexes the model buffer directly (extract.rs:318,329)
+            o.model_count = 1;
+        } else {
+            o.index = next_slot;
+            o.model_count = 0;
+            queue.push_back({t.left, next_slot});
+            queue.push_back({t.right, next_slot + 1});
+            next_slot += 2;
+        }
+    }
+    return BRT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Seeded scenes
+// ---------------------------------------------------------------------------------------
+
+namespace {
+
+struct SplitMix64 {
+    uint64_t s;
+    explicit SplitMix64(uint64_t seed) : s(seed) {}
+    uint64_t next() {
+        uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return z ^ (z >> 31);
+    }
+    float uniform() { return (float)(next() >> 40) * (1.0f / 16777216.0f); }  // [0,1), like rand::random::<f32>()
+    float uniform(float lo, float hi) { return lo + (hi - lo) * uniform(); }
+};
+
+// bevy_color Srgba -> LinearRgba per channel (Color::to_linear, extract.rs:201)
+inline float srgb_to_linear(float c) {
+    if (c <= 0.0f) return c;
+    if (c <= 0.04045f) return c / 12.92f;
+    return std::pow((c + 0.055f) / 1.055f, 2.4f);
+}
+
+// bevy 0.14 StandardMaterial::default(): base_color WHITE, metallic 0, perceptual_roughness
+// 0.5, reflectance 0.5, ior 1.5, specular_transmission 0.
+struct StdMat {
+    float base[3] = {1.0f, 1.0f, 1.0f};
+    bool srgb = true;
+    float metallic = 0.0f, perceptual_roughness = 0.5f, reflectance = 0.5f, ior = 1.5f, specular_transmission = 0.0f;
+};
+
+inline Material prepare_asset(const StdMat& m) {  // RaytraceMaterial::prepare_asset, extract.rs:196-208
+    Material r;
+    for (int k = 0; k < 3; k++) r.base_color[k] = m.srgb ? srgb_to_linear(m.base[k]) : m.base[k];
+    r.metallic = m.metallic;
+    r.roughness = m.perceptual_roughness;
+    r.reflectance = m.reflectance;
+    r.ior = m.ior;
+    r.specular_transmission = m.specular_transmission;
+    return r;
+}
+
+struct SceneOut {
+    std::vector<Model> models;
+    std::vector<Material> materials;
+    void add(float x, float y, float z, float radius, const StdMat& m) {
+        Model md;
+        std::memset(&md, 0, sizeof md);
+        md.position[0] = x; md.position[1] = y; md.position[2] = z;
+        md.radius = radius;
+        md.material_id = (uint32_t)models.size();  // one material entry per sphere, extract.rs:301-310
+        models.push_back(md);
+        materials.push_back(prepare_asset(m));
+    }
+};
+
+// main.rs:105-182: small spheres over a grid, material lottery on choose_mat
+void small_spheres(SceneOut& s, SplitMix64& rng, int a0, int a1, int b0, int b1, bool srgb, bool rtiow, bool skip_rule) {
+    for (int a = a0; a < a1; a++) {
+        for (int b = b0; b < b1; b++) {
+            const float choose_mat = rng.uniform();
+            const float cx = (float)a + 0.9f * rng.uniform();
+            const float cy = 0.2f;
+            const float cz = (float)b + 0.9f * rng.uniform();
+            const float dx = cx - 4.0f, dy = cy - 0.2f, dz = cz - 0.0f;
+            if (skip_rule && !(std::sqrt(dx * dx + dy * dy + dz * dz) > 0.9f)) continue;  // main.rs:115
+            StdMat m;
+            m.srgb = srgb;
+            if (choose_mat < 0.8f) {            // diffuse, main.rs:116-124
+                float r0 = rng.uniform(), g0 = rng.uniform(), b0_ = rng.uniform();
+                float r1 = rng.uniform(), g1 = rng.uniform(), b1_ = rng.uniform();
+                m.base[0] = r0 * r1; m.base[1] = g0 * g1; m.base[2] = b0_ * b1_;
+                m.metallic = 0.0f;
+                if (rtiow) m.perceptual_roughness = 0.0f;
+            } else if (choose_mat < 0.95f) {    // metal, main.rs:137-146
+                if (rtiow) {
+                    m.base[0] = rng.uniform(0.5f, 1.0f); m.base[1] = rng.uniform(0.5f, 1.0f); m.base[2] = rng.uniform(0.5f, 1.0f);
+                    m.perceptual_roughness = rng.uniform(0.0f, 0.5f);
+                } else {
+                    m.base[0] = rng.uniform(); m.base[1] = rng.uniform(); m.base[2] = rng.uniform();
+                    m.perceptual_roughness = rng.uniform();
+                }
+                m.metallic = 1.0f;
+            } else {                            // glass, main.rs:159-166
+                m.metallic = 0.0f;
+                m.ior = 1.5f;
+                m.specular_transmission = 1.0f;
+                if (rtiow) m.perceptual_roughness = 0.0f;
+            }
+            s.add(cx, cy, cz, 0.2f, m);
+        }
+    }
+}
+
+void big_spheres(SceneOut& s, bool srgb, bool rtiow) {  // main.rs:184-239
+    StdMat glass; glass.srgb = srgb; glass.metallic = 0.0f; glass.ior = 1.5f; glass.specular_transmission = 1.0f;
+    if (rtiow) glass.perceptual_roughness = 0.0f;
+    s.add(0.0f, 1.0f, 0.0f, 1.0f, glass);
+    StdMat diffuse; diffuse.srgb = srgb; diffuse.base[0] = 0.4f; diffuse.base[1] = 0.2f; diffuse.base[2] = 0.1f; diffuse.metallic = 0.0f;
+    if (rtiow) diffuse.perceptual_roughness = 0.0f;
+    s.add(-4.0f, 1.0f, 0.0f, 1.0f, diffuse);
+    StdMat metal; metal.srgb = srgb; metal.base[0] = 0.7f; metal.base[1] = 0.6f; metal.base[2] = 0.5f; metal.metallic = 1.0f;
+    metal.perceptual_roughness = 0.0f;
+    s.add(4.0f, 1.0f, 0.0f, 1.0f, metal);
+}
+
+}  // namespace
+
+int32_t scene_generate(uint32_t kind, uint64_t seed, std::vector<Model>* models, std::vector<Material>* materials) {
+    SceneOut s;
+    SplitMix64 rng(seed);
+    StdMat ground;
+    ground.base[0] = ground.base[1] = ground.base[2] = 0.5f;
+    ground.metallic = 0.0f;
+    switch (kind) {
+        case BRT_SCENE_COVER:   // main.rs:87-239; grid a in -11..=11 (23), b in -11..11 (22)
+            ground.srgb = true;
+            s.add(0.0f, -1000.0f, 0.0f, 1000.0f, ground);
+            small_spheres(s, rng, -11, 12, -11, 11, true, false, true);
+            big_spheres(s, true, false);
+            break;
+        case BRT_SCENE_RTIOW_FINAL:  // the book's final scene: 22 x 22, linear albedos, no extra roughness on diffuse
+            ground.srgb = false;
+            ground.perceptual_roughness = 0.0f;
+            s.add(0.0f, -1000.0f, 0.0f, 1000.0f, ground);
+            small_spheres(s, rng, -11, 11, -11, 11, false, true, true);
+            big_spheres(s, false, true);
+            break;
+        case BRT_SCENE_STRESS_GRID:  // 100 x 100 small spheres, cover-scene lottery
+            ground.srgb = true;
+            s.add(0.0f, -1000.0f, 0.0f, 1000.0f, ground);
+            small_spheres(s, rng, -50, 50, -50, 50, true, false, false);
+            big_spheres(s, true, false);
+            break;
+        default:
+            return fail(BRT_ERR_INVALID_ARGUMENT, "unknown scene kind");
+    }
+    models->swap(s.models);
+    materials->swap(s.materials);
+    return BRT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Extract-stage mirror
+// ---------------------------------------------------------------------------------------
+
+float tan_half_fov(float fov) { return (float)std::tan((double)(fov * 0.5f)); }
+
+}  // namespace brt
+
+using namespace brt;
+
+extern "C" {
+
+int32_t brt_build_bvh(const void* models, uint32_t n_models, void* out_nodes, uint32_t capacity, uint32_t* out_n_nodes) {
+    if (!out_n_nodes) return fail(BRT_ERR_INVALID_ARGUMENT, "out_n_nodes is null");
+    *out_n_nodes = 0;
+    if (n_models == 0) return BRT_OK;
+    if (!models) return fail(BRT_ERR_INVALID_ARGUMENT, "models is null");
+    std::vector<BVHNode> nodes;
+    int32_t rc = build_bvh_ploc((const Model*)models, n_models, &nodes);
+    if (rc != BRT_OK) return rc;
+    *out_n_nodes = (uint32_t)nodes.size();
+    if (nodes.size() > capacity || !out_nodes)
+        return fail(BRT_ERR_CAPACITY, "BVH needs " + std::to_string(nodes.size()) + " nodes, capacity " + std::to_string(capacity));
+    std::memcpy(out_nodes, nodes.data(), nodes.size() * sizeof(BVHNode));
+    return BRT_OK;
+}
+
+int32_t brt_validate_scene(const void* models, uint32_t n_models, const void* materials, uint32_t n_materials,
+                           const void* bvh_nodes, uint32_t n_nodes, uint32_t* out_max_depth) {
+    EncodedScene e;
+    std::string err;
+    int32_t rc = validate_and_encode((const Model*)models, n_models, (const Material*)materials, n_materials,
+                                     (const BVHNode*)bvh_nodes, n_nodes, &e, &err);
+    if (rc != BRT_OK) return fail(rc, err);
+    if (out_max_depth) *out_max_depth = e.max_leaf_depth;
+    return BRT_OK;
+}
+
+int32_t brt_scene_generate(uint32_t kind, uint64_t seed, void* out_models, void* out_materials, uint32_t capacity,
+                           uint32_t* out_n_models) {
+    if (!out_n_models) return fail(BRT_ERR_INVALID_ARGUMENT, "out_n_models is null");
+    std::vector<Model> models;
+    std::vector<Material> materials;
+    int32_t rc = scene_generate(kind, seed, &models, &materials);
+    if (rc != BRT_OK) return rc;
+    *out_n_models = (uint32_t)models.size();
+    if (models.size() > capacity || !out_models || !out_materials)
+        return fail(BRT_ERR_CAPACITY, "scene has " + std::to_string(models.size()) + " spheres, capacity " + std::to_string(capacity));
+    std::memcpy(out_models, models.data(), models.size() * sizeof(Model));
+    std::memcpy(out_materials, materials.data(), materials.size() * sizeof(Material));
+    return BRT_OK;
+}
+
+// CameraExtract::extract_component (extract.rs:118-157) for
+// Transform::from_translation(t).looking_at(target, up): direction = forward(), up = up().
+int32_t brt_host_camera_extract(const float* t, const float* target, const float* up, float fov, float aspect_ratio,
+                                float near_, float far_, uint32_t sample_count, uint32_t bounces, void* out_camera80) {
+    if (!t || !target || !up || !out_camera80) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
+    auto norm = [](float* v) { float l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); v[0] /= l; v[1] /= l; v[2] /= l; };
+    float back[3] = {t[0] - target[0], t[1] - target[1], t[2] - target[2]};
+    norm(back);
+    float right[3] = {up[1] * back[2] - up[2] * back[1], up[2] * back[0] - up[0] * back[2], up[0] * back[1] - up[1] * back[0]};
+    norm(right);
+    float up2[3] = {back[1] * right[2] - back[2] * right[1], back[2] * right[0] - back[0] * right[2], back[0] * right[1] - back[1] * right[0]};
+    Camera c;
+    std::memset(&c, 0, sizeof c);
+    c.sample_count = sample_count;
+    c.bounce_count = bounces;
+    c.projection_type = 0;
+    c.near_ = near_; c.far_ = far_; c.fov = fov; c.aspect = aspect_ratio;
+    for (int k = 0; k < 3; k++) { c.position[k] = t[k]; c.direction[k] = -back[k]; c.up[k] = up2[k]; }
+    std::memcpy(out_camera80, &c, sizeof c);
+    return BRT_OK;
+}
+
+int32_t brt_host_window_extract(float random_seed, uint32_t physical_height, void* out_window16) {
+    if (!out_window16) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
+    Window w;
+    std::memset(&w, 0, sizeof w);
+    w.random_seed = random_seed;
+    w.height = physical_height;
+    std::memcpy(out_window16, &w, sizeof w);
+    return BRT_OK;
+}
+
+int32_t brt_host_material(const float* base_color_srgb3, float metallic, float perceptual_roughness, float reflectance,
+                          float ior, float specular_transmission, void* out_material32) {
+    if (!base_color_srgb3 || !out_material32) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
+    StdMat m;
+    for (int k = 0; k < 3; k++) m.base[k] = base_color_srgb3[k];
+    m.metallic = metallic; m.perceptual_roughness = perceptual_roughness; m.reflectance = reflectance;
+    m.ior = ior; m.specular_transmission = specular_transmission;
+    Material r = prepare_asset(m);
+    std::memcpy(out_material32, &r, sizeof r);
+    return BRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,35 @@
+// brt_host.h -- internal interface of the host-side (CPU) parts; see brt_host.cpp.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/bevyray_amd.h"
+#include "brt_layout.h"
+
+namespace brt {
+
+extern thread_local std::string g_last_error;
+int32_t fail(int32_t code, const std::string& msg);
+
+// Scene in the device encoding (brt_layout.h), still in host vectors.
+struct EncodedScene {
+    std::vector<float> q0, q1, q2;       // 4 floats per pair record each
+    std::vector<uint32_t> qd;            // 2 per pair record
+    std::vector<float> spheres;          // 4 per model
+    std::vector<uint32_t> sphere_material;
+    std::vector<float> materials;        // 8 per material
+    std::vector<uint32_t> leaf_table;    // 2 per general leaf
+    uint32_t n_pairs = 0, n_models = 0, n_materials = 0;
+    uint32_t root_desc = 0;
+    uint32_t max_leaf_depth = 0;
+    uint32_t stack_entries = 2;
+};
+
+int32_t validate_and_encode(const Model* models, uint32_t n_models, const Material* materials, uint32_t n_materials,
+                            const BVHNode* nodes, uint32_t n_nodes, EncodedScene* out, std::string* err);
+int32_t build_bvh_ploc(const Model* models, uint32_t n_models, std::vector<BVHNode>* out);
+int32_t scene_generate(uint32_t kind, uint64_t seed, std::vector<Model>* models, std::vector<Material>* materials);
+float tan_half_fov(float fov);
+
+}  // namespace brt

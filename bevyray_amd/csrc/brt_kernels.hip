@@ -1,0 +1,447 @@
+// brt_kernels.hip -- HIP kernels of the path-tracing render node, written for gfx950
+// (MI355X: 256 CUs, wave64, 160 KB LDS per CU).
+//
+// k_trace_persistent  the production kernel: persistent threads, one path per lane.
+//     * One 1024-thread workgroup per CU (16 waves, 4 per SIMD) stays resident for the whole
+//       frame.  When the encoded scene fits, the workgroup first copies pair records,
+//       spheres and materials into LDS (cover scene: ~53 KB); the per-lane traversal stack
+//       also lives in LDS as a [entry][lane] array (conflict-free: bank = lane).
+//     * Each lane owns one pixel at a time and walks that pixel's samples and bounces as a
+//       flat state machine, one ray segment per outer iteration, because the reference
+//       threads ONE RNG state through all samples of a pixel (raytrace.wgsl:161-163): the
+//       samples of a pixel are sequentially dependent, the pixels are not.
+//     * Finished lanes are refilled from a global pixel queue: __ballot of the empty lanes,
+//       one wave-aggregated atomicAdd, mbcnt prefix sum to hand out consecutive queue slots.
+//       Queue slots map to 8x8 pixel tiles so that a wave starts on coherent primary rays.
+//     * No ray state ever goes to HBM; the only HBM traffic is the scene load per workgroup
+//       and one 16-byte store per pixel.
+// k_trace_simple      bring-up kernel: one thread per pixel, scene in global memory, private
+//                     stack.  Kept as an independent second implementation for debugging.
+// k_deinterleave      root side of the multi-GPU gather.
+// k_debug_eval        evaluates single device functions for per-function parity tests.
+#include <hip/hip_runtime.h>
+
+#include "brt_device.h"
+#include "brt_kernels.h"
+
+namespace brt {
+
+// ---- queue slot -> pixel -------------------------------------------------------------------
+// Slot q: tile = q / 64, inside the tile row-major 8x8.  Tiles run along x inside a strip of
+// BRT_STRIP_ROWS (= 8) rows; local strip k of part p is frame strip k * n_parts + p.
+struct PixelCoord {
+    uint32_t px, py;        // frame coordinates
+    uint32_t local_row;     // row in the dense tile buffer
+    bool inside;
+};
+BRT_DEV PixelCoord slot_to_pixel(const FrameParams& fp, uint32_t q) {
+    const uint32_t tile = q >> 6, t = q & 63u;
+    const uint32_t strip = tile / fp.tiles_x, tx = tile - strip * fp.tiles_x;
+    PixelCoord c;
+    c.px = tx * 8u + (t & 7u);
+    const uint32_t r = t >> 3;
+    c.local_row = strip * 8u + r;
+    c.py = (strip * fp.n_parts + fp.part) * 8u + r;
+    c.inside = (c.px < fp.width) && (c.py < fp.height);
+    return c;
+}
+
+BRT_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+BRT_DEV uint32_t mbcnt64(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+BRT_DEV uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Per-pixel state of a lane
+struct PixelState {
+    float ndc0x, ndc0y;     // uv.x*2-1, 1-uv.y*2   (raytrace.wgsl:146-147)
+    f3 sum;                 // running colour sum    (raytrace.wgsl:165)
+    float dsum;             // running depth sum     (raytrace.wgsl:166)
+    uint32_t rng;
+    uint32_t sample;
+    uint32_t out_index;     // pixel index in the tile buffer
+    uint32_t frame_index;   // pixel index in the frame (raster inputs)
+};
+
+BRT_DEV void pixel_begin(const FrameParams& fp, const PixelCoord& c, PixelState& ps) {
+    const float uvx = ((float)c.px + 0.5f) / (float)fp.width;
+    const float uvy = ((float)c.py + 0.5f) / (float)fp.height;
+    ps.rng = pixel_seed(fp, uvx, uvy);
+    ps.ndc0x = uvx * 2.0f - 1.0f;
+    ps.ndc0y = 1.0f - uvy * 2.0f;
+    ps.sum = mk3(0.0f, 0.0f, 0.0f);
+    ps.dsum = 0.0f;
+    ps.sample = 0;
+    ps.out_index = c.local_row * fp.width + c.px;
+    ps.frame_index = c.py * fp.width + c.px;
+}
+
+BRT_DEV void pixel_finish(const FrameParams& fp, const PixelState& ps, float* out_tile, const float* raster_rgba,
+                          const float* raster_depth) {
+    const f3 avg = mk3(ps.sum.x / fp.spp_f, ps.sum.y / fp.spp_f, ps.sum.z / fp.spp_f);   // :169
+    const float avg_depth = ps.dsum / fp.spp_f;                                           // :170
+    reinterpret_cast<float4*>(out_tile)[ps.out_index] =
+        resolve_pixel(fp, avg, avg_depth, raster_rgba, raster_depth, ps.frame_index);
+}
+
+// One ray segment of the bounce loop, raytrace.wgsl:189-212, after raycast returned (t, idx).
+// Returns true when the sample has ended; then `color` is its gamma-encoded colour (:223).
+BRT_DEV bool shade_segment(const ScenePtrs& sc, const FrameParams& fp, f3& o, f3& d, f3& tput, uint32_t& bounce,
+                           float& first_depth, float t, uint32_t idx, uint32_t& rng, f3& color, uint32_t& hits) {
+    if (bounce == 0) first_depth = t;                               // :193-195
+    f3 light = mk3(0.0f, 0.0f, 0.0f);
+    bool ended;
+    if (t == kInf) {                                                // :198-201
+        light = background_gradient(d);
+        ended = true;
+    } else {
+        hits++;
+        f3 att;
+        const bool absorbed = scatter(sc, o, d, t, idx, rng, att);  // :204
+        if (absorbed) {
+            ended = true;                                           // :207-209, light stays 0
+        } else {
+            tput = tput * att;                                      // :211
+            bounce++;
+            ended = bounce > fp.bounce_count;                       // loop exit, :189
+            if (ended) tput = mk3(0.0f, 0.0f, 0.0f);                // :215-217
+        }
+    }
+    if (ended) {
+        const f3 c = tput * light;
+        color = mk3(__builtin_sqrtf(c.x), __builtin_sqrtf(c.y), __builtin_sqrtf(c.z));  // :223
+    }
+    return ended;
+}
+
+// ---- persistent kernel -----------------------------------------------------------------------
+
+template <bool LDS_SCENE, bool COUNTERS>
+__global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView sv, FrameParams fp,
+                                                                uint32_t* __restrict__ queue_counter,
+                                                                float* __restrict__ out_tile,
+                                                                const float* __restrict__ raster_rgba,
+                                                                const float* __restrict__ raster_depth,
+                                                                unsigned long long* __restrict__ counters) {
+    extern __shared__ uint4 smem[];
+    ScenePtrs sc;
+    uint32_t* stacks;
+    if (LDS_SCENE) {
+        // carve: q0 | q1 | q2 | spheres | materials | qd | leaf_table | sphere_material | stacks
+        float4* p = reinterpret_cast<float4*>(smem);
+        float4* l_q0 = p; p += sv.n_pairs;
+        float4* l_q1 = p; p += sv.n_pairs;
+        float4* l_q2 = p; p += sv.n_pairs;
+        float4* l_sp = p; p += sv.n_models;
+        float4* l_mt = p; p += 2 * sv.n_materials;
+        uint2* p2 = reinterpret_cast<uint2*>(p);
+        uint2* l_qd = p2; p2 += sv.n_pairs;
+        uint2* l_lt = p2; p2 += sv.n_leaf_table;
+        uint32_t* p1 = reinterpret_cast<uint32_t*>(p2);
+        uint32_t* l_sm = p1; p1 += sv.n_models;
+        p1 += (4u - (sv.n_models & 3u)) & 3u;   // keep the stacks 16-byte aligned
+        stacks = p1;
+        const float4* g_q0 = reinterpret_cast<const float4*>(sv.q0);
+        const float4* g_q1 = reinterpret_cast<const float4*>(sv.q1);
+        const float4* g_q2 = reinterpret_cast<const float4*>(sv.q2);
+        const float4* g_sp = reinterpret_cast<const float4*>(sv.spheres);
+        const float4* g_mt = reinterpret_cast<const float4*>(sv.materials);
+        const uint2* g_qd = reinterpret_cast<const uint2*>(sv.qd);
+        const uint2* g_lt = reinterpret_cast<const uint2*>(sv.leaf_table);
+        for (uint32_t i = threadIdx.x; i < sv.n_pairs; i += blockDim.x) {
+            l_q0[i] = g_q0[i]; l_q1[i] = g_q1[i]; l_q2[i] = g_q2[i]; l_qd[i] = g_qd[i];
+        }
+        for (uint32_t i = threadIdx.x; i < sv.n_models; i += blockDim.x) { l_sp[i] = g_sp[i]; l_sm[i] = sv.sphere_material[i]; }
+        for (uint32_t i = threadIdx.x; i < 2 * sv.n_materials; i += blockDim.x) l_mt[i] = g_mt[i];
+        for (uint32_t i = threadIdx.x; i < sv.n_leaf_table; i += blockDim.x) l_lt[i] = g_lt[i];
+        sc.q0 = l_q0; sc.q1 = l_q1; sc.q2 = l_q2; sc.qd = l_qd;
+        sc.spheres = l_sp; sc.sphere_material = l_sm; sc.materials = l_mt; sc.leaf_table = l_lt;
+        __syncthreads();
+    } else {
+        sc.q0 = reinterpret_cast<const float4*>(sv.q0);
+        sc.q1 = reinterpret_cast<const float4*>(sv.q1);
+        sc.q2 = reinterpret_cast<const float4*>(sv.q2);
+        sc.qd = reinterpret_cast<const uint2*>(sv.qd);
+        sc.spheres = reinterpret_cast<const float4*>(sv.spheres);
+        sc.sphere_material = sv.sphere_material;
+        sc.materials = reinterpret_cast<const float4*>(sv.materials);
+        sc.leaf_table = reinterpret_cast<const uint2*>(sv.leaf_table);
+        stacks = reinterpret_cast<uint32_t*>(smem);
+    }
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t* stk = stacks + wave * (sv.stack_entries * 64u) + lane;
+
+    PixelState ps;
+    ps.sample = 0; ps.rng = 0; ps.out_index = 0; ps.frame_index = 0;
+    ps.ndc0x = ps.ndc0y = 0.0f; ps.sum = mk3(0.0f, 0.0f, 0.0f); ps.dsum = 0.0f;
+    f3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f), tput = mk3(1.0f, 1.0f, 1.0f);
+    uint32_t bounce = 0;
+    float first_depth = kInf;
+    bool active = false, exhausted = false;
+    uint32_t n_rays = 0;
+    HitCounters hc = {0u, 0u, 0u, 0u};
+
+    for (;;) {
+        // ---- refill empty lanes from the pixel queue (wave-aggregated) ----
+        for (;;) {
+            const bool need = !active && !exhausted;
+            const uint64_t m = __ballot(need);
+            if (m == 0) break;
+            uint32_t base = 0;
+            if (need && mbcnt64(m) == 0) base = atomicAdd(queue_counter, (uint32_t)__popcll(m));
+            base = __shfl(base, (int)(__ffsll((long long)m) - 1), 64);
+            if (need) {
+                const uint32_t q = base + mbcnt64(m);
+                if (q >= fp.queue_size) {
+                    exhausted = true;
+                } else {
+                    const PixelCoord c = slot_to_pixel(fp, q);
+                    if (c.inside) {
+                        pixel_begin(fp, c, ps);
+                        if (fp.sample_count == 0) pixel_finish(fp, ps, out_tile, raster_rgba, raster_depth);  // 0/0
+                        else { active = true; bounce = 0; }
+                    }
+                }
+            }
+        }
+        if (__ballot(active) == 0) break;
+
+        if (active) {
+            if (bounce == 0) {
+                // new sample: raytrace.wgsl:162 + :175-186
+                d = camera_ray_dir(fp, ps.ndc0x, ps.ndc0y, ps.rng);
+                o = mk3(fp.cam_pos[0], fp.cam_pos[1], fp.cam_pos[2]);
+                tput = mk3(1.0f, 1.0f, 1.0f);
+                first_depth = kInf;
+            }
+            float t;
+            uint32_t idx;
+            raycast<64, COUNTERS>(sc, sv.root_desc, stk, o, d, t, idx, hc);
+            n_rays++;
+            f3 color;
+            if (shade_segment(sc, fp, o, d, tput, bounce, first_depth, t, idx, ps.rng, color, hc.hits)) {
+                ps.sum = ps.sum + color;                                                   // :165
+                ps.dsum = ps.dsum + (first_depth == kInf ? fp.fallback_far : first_depth); // :166,219-221
+                ps.sample++;
+                bounce = 0;
+                if (ps.sample == fp.sample_count) {
+                    pixel_finish(fp, ps, out_tile, raster_rgba, raster_depth);
+                    active = false;
+                }
+            }
+        }
+    }
+
+    // ---- counters: one atomic per wave ----
+    const uint32_t r = wave_sum(n_rays);
+    if (lane == 0) atomicAdd(&counters[0], (unsigned long long)r);
+    if (COUNTERS) {
+        const uint32_t a = wave_sum(hc.node_pops), b = wave_sum(hc.interior), c = wave_sum(hc.sphere_tests);
+        if (lane == 0) {
+            atomicAdd(&counters[1], (unsigned long long)a);
+            atomicAdd(&counters[2], (unsigned long long)b);
+            atomicAdd(&counters[3], (unsigned long long)c);
+        }
+    }
+    const uint32_t h = wave_sum(hc.hits);
+    if (COUNTERS && lane == 0) atomicAdd(&counters[4], (unsigned long long)h);
+}
+
+// ---- bring-up kernel ---------------------------------------------------------------------------
+
+template <bool COUNTERS>
+__global__ __launch_bounds__(256) void k_trace_simple(DeviceSceneView sv, FrameParams fp, float* __restrict__ out_tile,
+                                                      const float* __restrict__ raster_rgba,
+                                                      const float* __restrict__ raster_depth,
+                                                      unsigned long long* __restrict__ counters) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    ScenePtrs sc;
+    sc.q0 = reinterpret_cast<const float4*>(sv.q0);
+    sc.q1 = reinterpret_cast<const float4*>(sv.q1);
+    sc.q2 = reinterpret_cast<const float4*>(sv.q2);
+    sc.qd = reinterpret_cast<const uint2*>(sv.qd);
+    sc.spheres = reinterpret_cast<const float4*>(sv.spheres);
+    sc.sphere_material = sv.sphere_material;
+    sc.materials = reinterpret_cast<const float4*>(sv.materials);
+    sc.leaf_table = reinterpret_cast<const uint2*>(sv.leaf_table);
+    uint32_t n_rays = 0;
+    HitCounters hc = {0u, 0u, 0u, 0u};
+    if (q < fp.queue_size) {
+        const PixelCoord c = slot_to_pixel(fp, q);
+        if (c.inside) {
+            PixelState ps;
+            pixel_begin(fp, c, ps);
+            uint32_t stack[32];
+            for (uint32_t s = 0; s < fp.sample_count; s++) {          // raytrace.wgsl:161
+                f3 d = camera_ray_dir(fp, ps.ndc0x, ps.ndc0y, ps.rng);
+                f3 o = mk3(fp.cam_pos[0], fp.cam_pos[1], fp.cam_pos[2]);
+                f3 tput = mk3(1.0f, 1.0f, 1.0f);
+                float first_depth = kInf;
+                uint32_t bounce = 0;
+                f3 color;
+                for (;;) {
+                    float t;
+                    uint32_t idx;
+                    raycast<1, COUNTERS>(sc, sv.root_desc, stack, o, d, t, idx, hc);
+                    n_rays++;
+                    if (shade_segment(sc, fp, o, d, tput, bounce, first_depth, t, idx, ps.rng, color, hc.hits)) break;
+                }
+                ps.sum = ps.sum + color;
+                ps.dsum = ps.dsum + (first_depth == kInf ? fp.fallback_far : first_depth);
+            }
+            pixel_finish(fp, ps, out_tile, raster_rgba, raster_depth);
+        }
+    }
+    const uint32_t lane = lane_id();
+    const uint32_t r = wave_sum(n_rays);
+    if (lane == 0) atomicAdd(&counters[0], (unsigned long long)r);
+    if (COUNTERS) {
+        const uint32_t a = wave_sum(hc.node_pops), b = wave_sum(hc.interior), c = wave_sum(hc.sphere_tests),
+                       h = wave_sum(hc.hits);
+        if (lane == 0) {
+            atomicAdd(&counters[1], (unsigned long long)a);
+            atomicAdd(&counters[2], (unsigned long long)b);
+            atomicAdd(&counters[3], (unsigned long long)c);
+            atomicAdd(&counters[4], (unsigned long long)h);
+        }
+    }
+}
+
+// ---- level 0: passthrough of the raster colour (raytrace.wgsl:97-99) -----------------------------
+
+__global__ void k_passthrough(FrameParams fp, float4* __restrict__ out_tile, const float4* __restrict__ raster_rgba) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= fp.queue_size) return;
+    const PixelCoord c = slot_to_pixel(fp, q);
+    if (!c.inside) return;
+    out_tile[c.local_row * fp.width + c.px] =
+        raster_rgba ? raster_rgba[c.py * fp.width + c.px] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// ---- gather root: tiles of all parts -> frame -----------------------------------------------------
+
+__global__ void k_deinterleave(const float4* __restrict__ tiles, float4* __restrict__ frame, uint32_t width,
+                               uint32_t height, uint32_t n_parts, uint32_t tile_rows) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t y = blockIdx.y;
+    if (x >= width || y >= height) return;
+    const uint32_t strip = y / 8u, r = y - strip * 8u;
+    const uint32_t part = strip % n_parts, k = strip / n_parts;
+    frame[(size_t)y * width + x] = tiles[((size_t)part * tile_rows + (k * 8u + r)) * width + x];
+}
+
+// ---- per-function probes ----------------------------------------------------------------------------
+
+__global__ void k_debug_eval(uint32_t op, const float* __restrict__ in, float* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* a = in + (size_t)i * 16;
+    float* r = out + (size_t)i * 8;
+    for (int k = 0; k < 8; k++) r[k] = 0.0f;
+    switch (op) {
+        case BRT_DBG_MINMAX: r[0] = min_f(a[0], a[1]); r[1] = max_f(a[0], a[1]); break;
+        case BRT_DBG_SQRT_DIV: r[0] = __builtin_sqrtf(a[0]); r[1] = a[0] / a[1]; break;
+        case BRT_DBG_RNG: {
+            uint32_t s = __float_as_uint(a[0]);
+            r[0] = rng_float(s);
+            r[1] = __uint_as_float(s);
+            const f3 p = rng_unit_ball(s);
+            r[2] = p.x; r[3] = p.y; r[4] = p.z; r[5] = __uint_as_float(s);
+            break;
+        }
+        case BRT_DBG_SLAB: {  // o, d, bmin, bmax, closest -> pushed?
+            const f3 o = mk3(a[0], a[1], a[2]), d = mk3(a[3], a[4], a[5]);
+            const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            r[0] = slab_push(o, inv, mk3(a[6], a[7], a[8]), mk3(a[9], a[10], a[11]), a[12]) ? 1.0f : 0.0f;
+            break;
+        }
+        case BRT_DBG_SPHERE: {  // o, d, center, radius -> accepted t (or INF)
+            const f3 o = mk3(a[0], a[1], a[2]), d = mk3(a[3], a[4], a[5]);
+            float closest = kInf;
+            uint32_t idx = 0xffffffffu;
+            sphere_test(o, d, dot3(d, d), make_float4(a[6], a[7], a[8], a[9] * a[9]), 0u, closest, idx);
+            r[0] = closest;
+            break;
+        }
+        case BRT_DBG_SEED: {  // seed, px, py, W, H (as floats holding integers)
+            FrameParams fp;
+            fp.seed_scaled = a[0] * 10000.0f;
+            const float uvx = (a[1] + 0.5f) / a[3], uvy = (a[2] + 0.5f) / a[4];
+            r[0] = __uint_as_float(pixel_seed(fp, uvx, uvy));
+            break;
+        }
+        default: break;
+    }
+}
+
+// ---- host-callable launchers ----------------------------------------------------------------------
+
+size_t trace_lds_bytes(const DeviceSceneView& sv, bool lds_scene, uint32_t block) {
+    size_t bytes = 0;
+    if (lds_scene) {
+        bytes += (size_t)sv.n_pairs * 48 + (size_t)sv.n_models * 16 + (size_t)sv.n_materials * 32;
+        bytes += (size_t)sv.n_pairs * 8 + (size_t)sv.n_leaf_table * 8;
+        bytes += (((size_t)sv.n_models + 3) & ~(size_t)3) * 4;
+    }
+    bytes += (size_t)(block / 64) * sv.stack_entries * 64 * 4;
+    return bytes;
+}
+
+template <bool L, bool C>
+static hipError_t launch_persistent_t(const TraceLaunch& tl) {
+    auto kern = k_trace_persistent<L, C>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)tl.lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(tl.grid), dim3(tl.block), tl.lds_bytes, tl.stream, tl.scene, tl.frame, tl.queue_counter,
+                       tl.out_tile, tl.raster_rgba, tl.raster_depth, tl.counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_trace_persistent(const TraceLaunch& tl) {
+    if (tl.lds_scene) return tl.counters_on ? launch_persistent_t<true, true>(tl) : launch_persistent_t<true, false>(tl);
+    return tl.counters_on ? launch_persistent_t<false, true>(tl) : launch_persistent_t<false, false>(tl);
+}
+
+hipError_t launch_trace_simple(const TraceLaunch& tl) {
+    const uint32_t grid = (tl.frame.queue_size + 255u) / 256u;
+    if (grid == 0) return hipSuccess;
+    if (tl.counters_on)
+        hipLaunchKernelGGL(k_trace_simple<true>, dim3(grid), dim3(256), 0, tl.stream, tl.scene, tl.frame, tl.out_tile,
+                           tl.raster_rgba, tl.raster_depth, tl.counters);
+    else
+        hipLaunchKernelGGL(k_trace_simple<false>, dim3(grid), dim3(256), 0, tl.stream, tl.scene, tl.frame, tl.out_tile,
+                           tl.raster_rgba, tl.raster_depth, tl.counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_passthrough(const FrameParams& fp, float* out_tile, const float* raster_rgba, hipStream_t stream) {
+    const uint32_t grid = (fp.queue_size + 255u) / 256u;
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_passthrough, dim3(grid), dim3(256), 0, stream, fp, reinterpret_cast<float4*>(out_tile),
+                       reinterpret_cast<const float4*>(raster_rgba));
+    return hipGetLastError();
+}
+
+hipError_t launch_deinterleave(const float* tiles, float* frame, uint32_t width, uint32_t height, uint32_t n_parts,
+                               uint32_t tile_rows, hipStream_t stream) {
+    if (width == 0 || height == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_deinterleave, dim3((width + 255u) / 256u, height), dim3(256), 0, stream,
+                       reinterpret_cast<const float4*>(tiles), reinterpret_cast<float4*>(frame), width, height, n_parts,
+                       tile_rows);
+    return hipGetLastError();
+}
+
+hipError_t launch_debug_eval(uint32_t op, const float* in, float* out, uint32_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_debug_eval, dim3((n + 255u) / 256u), dim3(256), 0, stream, op, in, out, n);
+    return hipGetLastError();
+}
+
+}  // namespace brt

@@ -1,0 +1,128 @@
+// brt_layout.h -- wire formats of the reference's extract stage and the device-side
+// scene encoding.  Shared by the host code and the HIP kernels.
+//
+// Wire structs follow the WGSL declarations (reference assets/shaders/raytrace.wgsl:30-87)
+// and their Rust twins (reference src/raytracing/extract.rs:56-61, 83-104, 181-189,
+// 213-218, 229-237): vec3 aligns to 16 bytes and has size 12; a struct's size rounds up to
+// its alignment.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace brt {
+
+struct Model {             // raytrace.wgsl:57-61
+    float position[3];
+    float radius;
+    uint32_t material_id;
+    uint32_t _pad[3];
+};
+struct Material {          // raytrace.wgsl:64-77
+    float base_color[3];
+    float metallic;
+    float roughness;
+    float reflectance;     // never read by the shader (raytrace.wgsl:72)
+    float ior;
+    float specular_transmission;
+};
+struct BVHNode {           // raytrace.wgsl:80-87
+    float bounds_min[3];
+    float _pad0;
+    float bounds_max[3];
+    uint32_t index;
+    uint32_t model_count;
+    uint32_t _pad1[3];
+};
+struct Camera {            // raytrace.wgsl:35-47
+    uint32_t sample_count;
+    uint32_t bounce_count;
+    uint32_t projection_type;
+    float near_;
+    float far_;
+    float fov;
+    float aspect;
+    float _pad0;
+    float position[3];
+    float _pad1;
+    float direction[3];
+    float _pad2;
+    float up[3];
+    float _pad3;
+};
+struct Window {            // raytrace.wgsl:50-54
+    float random_seed;
+    uint32_t height;
+    float _pad[2];
+};
+
+static_assert(sizeof(Model) == 32 && offsetof(Model, radius) == 12 && offsetof(Model, material_id) == 16, "Model");
+static_assert(sizeof(Material) == 32 && offsetof(Material, metallic) == 12 &&
+              offsetof(Material, specular_transmission) == 28, "Material");
+static_assert(sizeof(BVHNode) == 48 && offsetof(BVHNode, bounds_max) == 16 && offsetof(BVHNode, index) == 28 &&
+              offsetof(BVHNode, model_count) == 32, "BVHNode");
+static_assert(sizeof(Camera) == 80 && offsetof(Camera, near_) == 12 && offsetof(Camera, aspect) == 24 &&
+              offsetof(Camera, position) == 32 && offsetof(Camera, direction) == 48 && offsetof(Camera, up) == 64, "Camera");
+static_assert(sizeof(Window) == 16 && offsetof(Window, height) == 4, "Window");
+
+// ---- device-side scene encoding ------------------------------------------------------
+//
+// The reference re-reads a 48-byte node on every pop and then fetches both children
+// (raytrace.wgsl:323,329,336): three dependent fetches per interior visit.  At upload the
+// tree is re-encoded so that one interior visit is ONE record fetch and a pop needs no
+// fetch at all: the traversal stack holds 32-bit child descriptors instead of node ids, and
+// each interior node becomes a "pair record" with both children's boxes and descriptors.
+// The push/pop ORDER is the reference's, so results (ties, stack-overflow rule) are the same.
+//
+// Descriptor:
+//   bit31 = 0                 interior: bits[30:0] = pair-record index
+//   bit31 = 1, bit30 = 1      leaf with exactly one sphere: bits[29:0] = model index
+//   bit31 = 1, bit30 = 0      general leaf: bits[29:0] = index into the leaf table {first, count}
+constexpr uint32_t DESC_LEAF = 0x80000000u;
+constexpr uint32_t DESC_LEAF1 = 0xC0000000u;
+constexpr uint32_t DESC_INDEX_MASK = 0x3FFFFFFFu;
+
+// Pair records are stored as four parallel arrays of 16-byte (12 for the last) granules so
+// that 64 lanes reading 64 different records spread over all LDS banks (a 64-byte
+// array-of-structs stride would alias to 4 bank groups).
+//   q0[i] = { L.min.x, L.min.y, L.min.z, L.max.x }
+//   q1[i] = { L.max.y, L.max.z, R.min.x, R.min.y }
+//   q2[i] = { R.min.z, R.max.x, R.max.y, R.max.z }
+//   qd[i] = { descL, descR }            (L = node `index`, R = node `index + 1`)
+// Spheres: { center.x, center.y, center.z, radius*radius } (hit_sphere only uses r*r,
+// raytrace.wgsl:375), material ids in a parallel u32 array.
+// Materials: two float4 per material, as on the wire.
+
+struct DeviceSceneView {
+    const float* q0;         // float4[n_pairs]
+    const float* q1;
+    const float* q2;
+    const uint32_t* qd;      // uint2[n_pairs]
+    const float* spheres;    // float4[n_models]
+    const uint32_t* sphere_material;  // u32[n_models]
+    const float* materials;  // float4[2*n_materials]
+    const uint32_t* leaf_table;       // uint2[n_leaf_table]
+    uint32_t n_pairs, n_models, n_materials, n_leaf_table;
+    uint32_t root_desc;
+    uint32_t stack_entries;  // min(32, max leaf depth + 1)
+};
+
+// Frame-uniform values, evaluated once on the host with the reference's expressions
+// (raytrace.wgsl:95,141-153,177-182).
+struct FrameParams {
+    uint32_t width, height;          // render target size (uv = (p + 0.5) / size)
+    uint32_t level;
+    uint32_t sample_count, bounce_count;
+    float seed_scaled;               // window.random_seed * 10000.0
+    float inv_width, inv_height;     // 1.0 / (f32(window.height) * aspect), 1.0 / f32(window.height)
+    float aspect, tan_half_fov;
+    float cam_pos[3], cam_dir[3], cam_up[3], cam_right[3];  // right = cross(direction, up)
+    float near_, far_, fallback_far;
+    float spp_f;                     // f32(sample_count)
+    // work decomposition
+    uint32_t part, n_parts;          // interleaved strips: strip s -> part s % n_parts
+    uint32_t tiles_x;                // ceil(width / 8)
+    uint32_t local_strips;           // strips owned by this part (padded count)
+    uint32_t queue_size;             // local_strips * tiles_x * 64
+};
+
+}  // namespace brt

@@ -1,0 +1,64 @@
+"""Row tiling of one frame over ranks and the single collective of the path.
+
+The frame is cut into strips of STRIP_ROWS (= 8) rows; strip s belongs to part s % n_parts
+(interleaved, because contiguous bands are badly imbalanced: sky rows end after one ray).
+Every rank traces its strips into a dense tile (bevyray_amd.h: brt_render_part_device) and the
+tiles meet on rank 0 in ONE gather over RCCL/xGMI (torch.distributed backend "nccl"); rank 0
+de-interleaves with a copy kernel.  Pixels are independent (seeds depend on absolute pixel
+coordinates only, reference raytrace.wgsl:95), so there is no other exchange.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from .raytracing import STRIP_ROWS, tile_rows
+
+
+def frame_rows_of_part(height: int, part: int, n_parts: int) -> np.ndarray:
+    """Frame row of every tile row of `part` (-1 for padding rows past the frame)."""
+    rows = np.full(tile_rows(height, n_parts), -1, np.int64)
+    strips = (height + STRIP_ROWS - 1) // STRIP_ROWS
+    k = 0
+    for s in range(part, strips, n_parts):
+        for r in range(STRIP_ROWS):
+            y = s * STRIP_ROWS + r
+            if y < height:
+                rows[k * STRIP_ROWS + r] = y
+        k += 1
+    return rows
+
+
+def gather_frame(tile, height: int, rank: int, world: int, node=None, group=None):
+    """Gathers the per-rank tiles (torch tensors [tile_rows, W, 4] f32, same shape on every
+    rank) on rank 0 and returns the de-interleaved frame [height, W, 4] there (None elsewhere).
+
+    CUDA tensors: one RCCL gather, then the de-interleave HIP kernel of `node`
+    (brt_deinterleave_device).  CPU tensors (gloo, used by the world_size-2 tests): one gloo
+    gather, then an index copy -- the row mapping under test is the same."""
+    import torch
+    import torch.distributed as dist
+
+    width = tile.shape[1]
+    if world == 1:
+        tiles = tile.unsqueeze(0)
+    else:
+        gather_list = [torch.empty_like(tile) for _ in range(world)] if rank == 0 else None
+        dist.gather(tile, gather_list, dst=0, group=group)
+        if rank != 0:
+            return None
+        tiles = torch.stack(gather_list, 0)
+    if tiles.is_cuda:
+        if node is None:
+            raise RuntimeError("gather_frame on CUDA tensors needs the RayTracingNode (de-interleave kernel)")
+        frame = torch.empty((height, width, 4), dtype=torch.float32, device=tiles.device)
+        node.deinterleave_device(tiles.data_ptr(), world, width, height, frame.data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream)
+        return frame
+    frame = torch.empty((height, width, 4), dtype=torch.float32)
+    for p in range(world):
+        rows = frame_rows_of_part(height, p, world)
+        valid = rows >= 0
+        frame[torch.from_numpy(rows[valid])] = tiles[p][torch.from_numpy(np.flatnonzero(valid))]
+    return frame

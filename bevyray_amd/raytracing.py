@@ -1,0 +1,331 @@
+"""Host-side mirror of bevyray's plugin surface for the ray-tracing pass.
+
+Names, fields and error behaviour follow the reference's Rust (reference
+src/raytracing/mod.rs, extract.rs, pipeline.rs) so that tests read like tests of the
+reference would; the arithmetic lives in the C++/HIP library behind the C ABI
+(include/bevyray_amd.h).  Nothing here traces rays.
+
+    RaytracePlugin            mod.rs:24-84      owns the GPU context (RaytracingPipeline::from_world)
+    RaytracedCamera           mod.rs:86-91      {level, sample_count, bounces}
+    Raytracing                mod.rs:94-101     Skip/FallbackRaster/FallbackRaytraced/Pure = 0..3
+    RaytracedSphere           mod.rs:103-106    {radius}
+    StandardMaterial          bevy 0.14 defaults of the fields extract.rs:200-207 reads
+    CameraExtract / WindowExtract / RaytraceLevelExtract / RaytraceMaterial / Model / BVHNode
+                              extract.rs:56-237 byte layouts (numpy structured dtypes)
+    prepare_buffers           extract.rs:280-337
+    RayTracingNode.run        pipeline.rs:58-220
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import math
+from dataclasses import dataclass, field
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import BrtError, BrtStats
+
+# ---- wire formats (extract.rs:56-61, 83-104, 181-189, 213-218, 229-237) ---------------------
+
+MODEL_DTYPE = np.dtype({"names": ["position", "radius", "material_id"],
+                        "formats": [("<f4", 3), "<f4", "<u4"], "offsets": [0, 12, 16], "itemsize": 32})
+MATERIAL_DTYPE = np.dtype({"names": ["base_color", "metallic", "roughness", "reflectance", "ior", "specular_transmission"],
+                           "formats": [("<f4", 3), "<f4", "<f4", "<f4", "<f4", "<f4"],
+                           "offsets": [0, 12, 16, 20, 24, 28], "itemsize": 32})
+BVH_NODE_DTYPE = np.dtype({"names": ["bounds_min", "bounds_max", "index", "model_count"],
+                           "formats": [("<f4", 3), ("<f4", 3), "<u4", "<u4"], "offsets": [0, 16, 28, 32], "itemsize": 48})
+CAMERA_DTYPE = np.dtype({"names": ["sample_count", "bounce_count", "projection", "near", "far", "fov", "aspect",
+                                   "position", "direction", "up"],
+                         "formats": ["<u4", "<u4", "<u4", "<f4", "<f4", "<f4", "<f4", ("<f4", 3), ("<f4", 3), ("<f4", 3)],
+                         "offsets": [0, 4, 8, 12, 16, 20, 24, 32, 48, 64], "itemsize": 80})
+WINDOW_DTYPE = np.dtype({"names": ["random_seed", "height"], "formats": ["<f4", "<u4"], "offsets": [0, 4], "itemsize": 16})
+LEVEL_DTYPE = np.dtype({"names": ["level"], "formats": ["<u4"], "offsets": [0], "itemsize": 32})
+
+STRIP_ROWS = 8
+FLAG_COUNTERS = 1
+FLAG_KERNEL_SIMPLE = 2
+
+SCENE_COVER, SCENE_RTIOW_FINAL, SCENE_STRESS_GRID = 0, 1, 2
+
+
+class Raytracing(enum.IntEnum):
+    """mod.rs:94-101, #[repr(u32)]"""
+    Skip = 0
+    FallbackRaster = 1
+    FallbackRaytraced = 2
+    Pure = 3
+
+
+@dataclass
+class RaytracedCamera:
+    """mod.rs:86-91"""
+    level: Raytracing = Raytracing.FallbackRaytraced
+    sample_count: int = 4
+    bounces: int = 4
+
+
+@dataclass
+class RaytracedSphere:
+    """mod.rs:103-106"""
+    radius: float = 1.0
+
+
+@dataclass
+class StandardMaterial:
+    """The StandardMaterial fields extract.rs:200-207 reads, with bevy 0.14's defaults.
+    base_color is sRGB (Color::srgb), decoded to linear by RaytraceMaterial.prepare_asset."""
+    base_color: Tuple[float, float, float] = (1.0, 1.0, 1.0)
+    metallic: float = 0.0
+    perceptual_roughness: float = 0.5
+    reflectance: float = 0.5
+    ior: float = 1.5
+    specular_transmission: float = 0.0
+
+
+@dataclass
+class PerspectiveProjection:
+    fov: float = math.pi / 4.0
+    aspect_ratio: float = 1.0
+    near: float = 0.1
+    far: float = 1000.0
+
+
+@dataclass
+class OrthographicProjection:
+    """Unsupported by the reference: CameraExtract returns None (extract.rs:148)."""
+    scale: float = 1.0
+
+
+@dataclass
+class Transform:
+    """Transform::from_translation(t).looking_at(target, up)"""
+    translation: Tuple[float, float, float] = (0.0, 0.0, 5.0)
+    target: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    up: Tuple[float, float, float] = (0.0, 1.0, 0.0)
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def _trim(arr: np.ndarray, n: int) -> np.ndarray:
+    """First n records as an owned array, copied bytewise (padding bytes stay zero)."""
+    raw = arr.view(np.uint8).reshape(len(arr), arr.dtype.itemsize)[:n].copy()
+    return raw.view(arr.dtype).reshape(n)
+
+
+class CameraExtract:
+    """extract.rs:83-158"""
+
+    @staticmethod
+    def extract_component(camera: RaytracedCamera, transform: Transform, projection):
+        if not isinstance(projection, PerspectiveProjection):
+            return None  # extract.rs:148
+        lib = _lib.load()
+        cam = np.zeros(1, CAMERA_DTYPE)
+        _lib.check(lib.brt_host_camera_extract(_f3(transform.translation), _f3(transform.target), _f3(transform.up),
+                                               projection.fov, projection.aspect_ratio, projection.near, projection.far,
+                                               int(camera.sample_count), int(camera.bounces), cam.ctypes.data))
+        level = np.zeros(1, LEVEL_DTYPE)
+        level["level"] = int(camera.level)
+        return level, cam
+
+
+class WindowExtract:
+    """extract.rs:56-81.  The reference draws random_seed from thread_rng every frame; here
+    it is an explicit input."""
+
+    @staticmethod
+    def extract_component(physical_height: int, random_seed: float):
+        lib = _lib.load()
+        win = np.zeros(1, WINDOW_DTYPE)
+        _lib.check(lib.brt_host_window_extract(float(random_seed), int(physical_height), win.ctypes.data))
+        return win
+
+
+class RaytraceMaterial:
+    """extract.rs:181-209"""
+
+    @staticmethod
+    def prepare_asset(source: StandardMaterial) -> np.ndarray:
+        lib = _lib.load()
+        out = np.zeros(1, MATERIAL_DTYPE)
+        _lib.check(lib.brt_host_material(_f3(source.base_color), source.metallic, source.perceptual_roughness,
+                                         source.reflectance, source.ior, source.specular_transmission, out.ctypes.data))
+        return out
+
+
+def build_bvh(models: np.ndarray) -> np.ndarray:
+    """The build_ploc call + flatten of extract.rs:315-332 (native PLOC builder)."""
+    lib = _lib.load()
+    models = np.ascontiguousarray(models, MODEL_DTYPE)
+    n = len(models)
+    cap = max(1, 2 * n)
+    nodes = np.zeros(cap, BVH_NODE_DTYPE)
+    out_n = C.c_uint32(0)
+    _lib.check(lib.brt_build_bvh(models.ctypes.data, n, nodes.ctypes.data, cap, C.byref(out_n)))
+    return _trim(nodes, out_n.value)
+
+
+def validate_scene(models, materials, bvh) -> int:
+    """Returns the maximum leaf depth; raises BrtError for what brt_upload_scene would reject."""
+    lib = _lib.load()
+    models = np.ascontiguousarray(models, MODEL_DTYPE)
+    materials = np.ascontiguousarray(materials, MATERIAL_DTYPE)
+    bvh = np.ascontiguousarray(bvh, BVH_NODE_DTYPE)
+    depth = C.c_uint32(0)
+    _lib.check(lib.brt_validate_scene(models.ctypes.data, len(models), materials.ctypes.data, len(materials),
+                                      bvh.ctypes.data, len(bvh), C.byref(depth)))
+    return depth.value
+
+
+@dataclass
+class Buffers:
+    """ModelBuffer / MaterialBuffer / BVHBuffer (extract.rs:252-262)."""
+    models: np.ndarray
+    materials: np.ndarray
+    bvh: np.ndarray
+
+
+def prepare_buffers(data: Sequence[Tuple[Tuple[float, float, float], RaytracedSphere, StandardMaterial]]) -> Buffers:
+    """extract.rs:280-337: one Model + one material entry per sphere (material_id = enumerate
+    index), AABBs padded by 0.1, PLOC BVH, flattened nodes."""
+    n = len(data)
+    models = np.zeros(n, MODEL_DTYPE)
+    materials = np.zeros(n, MATERIAL_DTYPE)
+    for i, (position, sphere, material) in enumerate(data):
+        materials[i] = RaytraceMaterial.prepare_asset(material)[0]
+        models[i]["position"] = position
+        models[i]["radius"] = sphere.radius
+        models[i]["material_id"] = i
+    return Buffers(models, materials, build_bvh(models))
+
+
+def generate_scene(kind: int, seed: int = 1) -> Buffers:
+    """Seeded version of the demo scene setup (main.rs:49-240) and the other benchmark scenes."""
+    lib = _lib.load()
+    cap = 16384
+    models = np.zeros(cap, MODEL_DTYPE)
+    materials = np.zeros(cap, MATERIAL_DTYPE)
+    n = C.c_uint32(0)
+    _lib.check(lib.brt_scene_generate(kind, seed, models.ctypes.data, materials.ctypes.data, cap, C.byref(n)))
+    models, materials = _trim(models, n.value), _trim(materials, n.value)
+    return Buffers(models, materials, build_bvh(models))
+
+
+def cover_camera(width: int, height: int, sample_count: int, bounces: int,
+                 level: Raytracing = Raytracing.Pure, seed: float = 0.5):
+    """The 'cover' view: position (13,2,3) looking at the origin, fov 0.4 rad,
+    near 0.1, far 1000.  Returns (level, camera, window) extracts."""
+    cam = RaytracedCamera(level=level, sample_count=sample_count, bounces=bounces)
+    proj = PerspectiveProjection(fov=0.4, aspect_ratio=width / height, near=0.1, far=1000.0)
+    lvl, cex = CameraExtract.extract_component(cam, Transform((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)), proj)
+    return lvl, cex, WindowExtract.extract_component(height, seed)
+
+
+def tile_rows(height: int, n_parts: int) -> int:
+    return int(_lib.load().brt_tile_rows(height, n_parts))
+
+
+class RaytracePlugin:
+    """mod.rs:24-84.  build()/finish() create the GPU context (the reference queues the
+    render pipeline in RaytracingPipeline::from_world, pipeline.rs:233-331)."""
+
+    def __init__(self, device_ids: Sequence[int] = (0,)):
+        lib = _lib.load()
+        ids = (C.c_int32 * len(device_ids))(*device_ids)
+        ctx = C.c_void_p()
+        _lib.check(lib.brt_create(ids, len(device_ids), C.byref(ctx)))
+        self._lib = lib
+        self._ctx = ctx
+        self.node = RayTracingNode(self)
+
+    def close(self):
+        if self._ctx:
+            self._lib.brt_destroy(self._ctx)
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def debug_eval(self, op: int, inputs: np.ndarray) -> np.ndarray:
+        inputs = np.ascontiguousarray(inputs, np.float32)
+        assert inputs.ndim == 2 and inputs.shape[1] == 16
+        out = np.zeros((inputs.shape[0], 8), np.float32)
+        _lib.check(self._lib.brt_debug_eval(self._ctx, op, inputs.ctypes.data, out.ctypes.data, inputs.shape[0]), self._ctx)
+        return out
+
+
+class RayTracingNode:
+    """pipeline.rs:29-221.  `run` uploads the three storage buffers and draws the frame."""
+
+    def __init__(self, plugin: RaytracePlugin):
+        self._p = plugin
+        self.last_stats: Optional[dict] = None
+
+    def write_buffers(self, buffers: Buffers) -> None:
+        """pipeline.rs:136-138"""
+        p = self._p
+        models = np.ascontiguousarray(buffers.models, MODEL_DTYPE)
+        materials = np.ascontiguousarray(buffers.materials, MATERIAL_DTYPE)
+        bvh = None if buffers.bvh is None else np.ascontiguousarray(buffers.bvh, BVH_NODE_DTYPE)
+        _lib.check(p._lib.brt_upload_scene(p._ctx, models.ctypes.data, len(models), materials.ctypes.data, len(materials),
+                                           None if bvh is None else bvh.ctypes.data, 0 if bvh is None else len(bvh)), p._ctx)
+
+    def run(self, level, camera, window, width: int, height: int, buffers: Optional[Buffers] = None,
+            raster_rgba: Optional[np.ndarray] = None, raster_depth: Optional[np.ndarray] = None,
+            flags: int = 0) -> Optional[np.ndarray]:
+        """Returns the RGBA f32 frame (height, width, 4), or None when the pass is skipped the
+        way the reference skips it (missing camera extract, empty buffers)."""
+        if camera is None or window is None or level is None:
+            return None  # pipeline.rs:88-102
+        p = self._p
+        if buffers is not None:
+            try:
+                self.write_buffers(buffers)
+            except BrtError as e:
+                if e.code == -6:  # BRT_ERR_EMPTY_SCENE: no binding -> skip (pipeline.rs:141-151)
+                    return None
+                raise
+        out = np.empty((height, width, 4), np.float32)
+        stats = BrtStats()
+        rr = None if raster_rgba is None else np.ascontiguousarray(raster_rgba, np.float32)
+        rd = None if raster_depth is None else np.ascontiguousarray(raster_depth, np.float32)
+        if rr is not None:
+            assert rr.shape == (height, width, 4)
+        if rd is not None:
+            assert rd.shape == (height, width)
+        _lib.check(p._lib.brt_render(p._ctx, camera.ctypes.data, window.ctypes.data, int(level["level"][0]), width, height,
+                                     None if rr is None else rr.ctypes.data, None if rd is None else rd.ctypes.data,
+                                     out.ctypes.data, flags, C.byref(stats)), p._ctx)
+        self.last_stats = stats.as_dict()
+        return out
+
+    # -- device-pointer entry points (used by bench.py with torch tensors) ------------------------
+
+    def render_part_device(self, level, camera, window, width: int, height: int, part: int, n_parts: int,
+                           d_out_tile: int, d_raster_rgba: int = 0, d_raster_depth: int = 0, stream: int = 0,
+                           flags: int = 0) -> dict:
+        p = self._p
+        stats = BrtStats()
+        _lib.check(p._lib.brt_render_part_device(p._ctx, camera.ctypes.data, window.ctypes.data, int(level["level"][0]),
+                                                 width, height, part, n_parts, d_raster_rgba or None,
+                                                 d_raster_depth or None, d_out_tile, stream or None, flags,
+                                                 C.byref(stats)), p._ctx)
+        return stats.as_dict()
+
+    def deinterleave_device(self, d_tiles: int, n_parts: int, width: int, height: int, d_frame: int, stream: int = 0):
+        p = self._p
+        _lib.check(p._lib.brt_deinterleave_device(p._ctx, d_tiles, n_parts, width, height, d_frame, stream or None), p._ctx)

@@ -1,0 +1,208 @@
+/*
+ * bevyray_amd.h -- C ABI of the MI355X path-tracing render node.
+ *
+ * This is the drop-in boundary for ONE path of GrandmasterB42/bevyray: the wgpu
+ * fragment pass that `RayTracingNode::run` encodes
+ * (reference src/raytracing/pipeline.rs:58-220) together with the per-pixel ray
+ * loop it dispatches (reference assets/shaders/raytrace.wgsl:93-421,
+ * random.wgsl:3-30, const.wgsl:1-2).  The Rust node keeps its registration,
+ * ViewQuery and extract stage; the body of `run` calls these functions instead
+ * of `write_buffer` x3 + bind groups + `draw(0..3, 0..1)`.  INTEGRATION.md shows
+ * the Rust `extern "C"` block and the replacement body.
+ *
+ * Conventions
+ *   - Every function returns int32: BRT_OK (0) or a negative BRT_ERR_* code; none
+ *     throws or aborts across the boundary.  brt_last_error() gives the text.
+ *     (Reference: every "not ready" condition returns Ok(()) and skips the pass,
+ *     pipeline.rs:82-85,89-102,113-115,141-151; the Rust side maps non-zero to a
+ *     logged warning + Ok(()).)
+ *   - The caller owns every pointer it passes; the callee copies during the call
+ *     and retains nothing.  All device memory lives in the opaque context.
+ *   - A context is single-caller (not re-entrant), like a render-graph node that
+ *     the runner executes sequentially.
+ *   - Wire formats are the encase/WGSL layouts the reference's extract stage
+ *     already produces (extract.rs:56-61, 83-104, 181-189, 213-218, 229-237):
+ *       Model            32 B  position vec3 @0, radius f32 @12, material_id u32 @16
+ *       RaytraceMaterial 32 B  base_color vec3 @0, metallic @12, roughness @16,
+ *                              reflectance @20, ior @24, specular_transmission @28
+ *       BVHNode          48 B  bounds_min vec3 @0, bounds_max vec3 @16, index u32 @28,
+ *                              model_count u32 @32
+ *       CameraExtract    80 B  sample_count u32 @0, bounce_count @4, projection @8,
+ *                              near f32 @12, far @16, fov @20, aspect @24,
+ *                              position vec3 @32, direction vec3 @48, up vec3 @64
+ *       WindowExtract    16 B  random_seed f32 @0, height u32 @4
+ *   - Frames are RGBA f32, row-major, top row first, width*height*16 bytes.
+ */
+#ifndef BEVYRAY_AMD_H
+#define BEVYRAY_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BRT_ABI_VERSION 1u
+
+/* Rows per strip of the interleaved row tiling. */
+#define BRT_STRIP_ROWS 8u
+
+enum {
+    BRT_OK = 0,
+    BRT_ERR_INVALID_ARGUMENT = -1,
+    BRT_ERR_NO_DEVICE = -2,        /* no HIP device / HIP runtime failure at create */
+    BRT_ERR_HIP = -3,              /* a HIP call failed; text in brt_last_error */
+    BRT_ERR_INVALID_BVH = -4,      /* node index out of range, cycle, leaf range out of range */
+    BRT_ERR_INVALID_SCENE = -5,    /* material_id out of range, non-finite sphere */
+    BRT_ERR_EMPTY_SCENE = -6,      /* zero spheres: the reference skips the pass (pipeline.rs:141-151) */
+    BRT_ERR_NO_SCENE = -7,         /* render before upload */
+    BRT_ERR_UNSUPPORTED = -8,      /* e.g. orthographic projection (extract.rs:148) */
+    BRT_ERR_CAPACITY = -9          /* caller buffer too small */
+};
+
+/* Raytracing level, reference src/raytracing/mod.rs:94-101 (#[repr(u32)]). */
+enum {
+    BRT_LEVEL_SKIP = 0,
+    BRT_LEVEL_FALLBACK_RASTER = 1,
+    BRT_LEVEL_FALLBACK_RAYTRACED = 2,
+    BRT_LEVEL_PURE = 3
+};
+
+/* brt_render* flags */
+enum {
+    BRT_FLAG_COUNTERS = 1u,        /* also count node pops / interior visits / sphere tests / hits */
+    BRT_FLAG_KERNEL_SIMPLE = 2u    /* one-thread-per-pixel bring-up kernel instead of the persistent one */
+};
+
+typedef struct brt_ctx brt_ctx;
+
+/* Per-call statistics.  `rays` (one per raycast() call, raytrace.wgsl:190) is always
+ * counted; the other four only with BRT_FLAG_COUNTERS (else 0). */
+typedef struct brt_stats {
+    uint64_t rays;
+    uint64_t node_pops;        /* raytrace.wgsl:321-323 */
+    uint64_t interior_visits;  /* raytrace.wgsl:327-341 */
+    uint64_t sphere_tests;     /* raytrace.wgsl:350-352 */
+    uint64_t hits;             /* scatter() calls, raytrace.wgsl:204 */
+    uint64_t paths;            /* pixels * sample_count rendered by this call */
+    double   kernel_ms;        /* HIP-event time of the trace kernel on its own stream (max over devices) */
+    double   gather_ms;        /* tile copy-out / gather time */
+    double   total_ms;         /* host wall time of the call */
+    uint32_t lds_bytes;        /* dynamic LDS per workgroup of the trace kernel */
+    uint32_t scene_in_lds;     /* 1 if spheres + BVH + materials are LDS-resident */
+    uint32_t n_workgroups;
+    uint32_t threads_per_workgroup;
+} brt_stats;
+
+uint32_t brt_abi_version(void);
+
+/* Text of the last error on this context (ctx may be NULL: last error of brt_create /
+ * the host-only helpers on this thread).  The pointer stays valid until the next call. */
+const char* brt_last_error(const brt_ctx* ctx);
+
+/* Replaces: RaytracingPipeline::from_world (pipeline.rs:233-331) -- one-time GPU setup.
+ * device_ids[n_devices] are HIP ordinals; the frame is row-tiled over them in strips of
+ * BRT_STRIP_ROWS rows (strip s -> device s % n_devices).  An ordinal may repeat. */
+int32_t brt_create(const int32_t* device_ids, int32_t n_devices, brt_ctx** out_ctx);
+int32_t brt_destroy(brt_ctx* ctx);
+
+/* Replaces: model_buffer / material_buffer / bvh_buffer .write_buffer (pipeline.rs:136-138).
+ * Takes the three CPU vectors that prepare_buffers builds (extract.rs:299-336), validates
+ * them (indices in range, BVH reachable from node 0 without cycles) and copies them to
+ * every device of the context.  If bvh_nodes == NULL / n_nodes == 0 the callee builds the
+ * BVH itself with the native PLOC builder (see brt_build_bvh). */
+int32_t brt_upload_scene(brt_ctx* ctx,
+                         const void* models, uint32_t n_models,
+                         const void* materials, uint32_t n_materials,
+                         const void* bvh_nodes, uint32_t n_nodes);
+
+/* Replaces: set_bind_group x2 + draw(0..3, 0..1) (pipeline.rs:160-217) and the whole
+ * fragment() invocation grid (raytrace.wgsl:93-123).  Renders a width x height frame into
+ * out_rgba (HOST pointer).  raster_rgba / raster_depth (host, width*height*4 / width*height
+ * floats, reverse-Z depth) are the `screen_texture` and depth prepass the shader samples
+ * (raytrace.wgsl:98,106,116); either may be NULL = cleared to 0.  Synchronous. */
+int32_t brt_render(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level,
+                   uint32_t width, uint32_t height,
+                   const float* raster_rgba, const float* raster_depth,
+                   float* out_rgba, uint32_t flags, brt_stats* stats_or_null);
+
+/* Same frame, but only the strips of `part` out of `n_parts` (strip s belongs to part
+ * s % n_parts), written densely into a DEVICE tile buffer of brt_tile_rows() rows on the
+ * context's first device: tile row (k*BRT_STRIP_ROWS + r) is frame row
+ * ((k*n_parts + part)*BRT_STRIP_ROWS + r).  d_raster_* are optional DEVICE full-frame
+ * buffers.  Asynchronous on `hip_stream` (a hipStream_t; NULL = the context's stream);
+ * kernel_ms in stats is only filled when `hip_stream` is NULL (the call then synchronises). */
+int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level,
+                               uint32_t width, uint32_t height, uint32_t part, uint32_t n_parts,
+                               const float* d_raster_rgba, const float* d_raster_depth,
+                               float* d_out_tile, void* hip_stream, uint32_t flags,
+                               brt_stats* stats_or_null);
+
+/* Rows in the dense tile of `part` (same for every part: padded to whole strips). */
+uint32_t brt_tile_rows(uint32_t height, uint32_t n_parts);
+
+/* Root side of the gather: d_tiles holds n_parts tiles back to back (each
+ * brt_tile_rows()*width*4 floats, i.e. the receive buffer of a gather); writes the
+ * de-interleaved width x height frame to d_frame.  Asynchronous on hip_stream. */
+int32_t brt_deinterleave_device(brt_ctx* ctx, const float* d_tiles, uint32_t n_parts,
+                                uint32_t width, uint32_t height, float* d_frame, void* hip_stream);
+
+/* Diagnostic: evaluates one device function of the ray loop on n inputs (16 floats in,
+ * 8 floats out per element; op codes BRT_DBG_* below) so that tests can compare single
+ * reference functions (rngNextFloat, ray_bounding_dst, hit_sphere, the seed formula,
+ * min/max/sqrt/divide) bit for bit.  Host pointers, synchronous. */
+enum {
+    BRT_DBG_MINMAX = 0,    /* in: a, b            out: min(a,b), max(a,b) */
+    BRT_DBG_SQRT_DIV = 1,  /* in: a, b            out: sqrt(a), a / b */
+    BRT_DBG_RNG = 2,       /* in: state (bits)    out: float, state', ball.xyz, state'' (bits) */
+    BRT_DBG_SLAB = 3,      /* in: o3 d3 bmin3 bmax3 closest   out: child pushed (0/1) */
+    BRT_DBG_SPHERE = 4,    /* in: o3 d3 center3 radius        out: accepted t or INF */
+    BRT_DBG_SEED = 5       /* in: seed px py W H (floats)     out: rng seed (bits) */
+};
+int32_t brt_debug_eval(brt_ctx* ctx, uint32_t op, const float* in16, float* out8, uint32_t n);
+
+/* ---- host-only helpers (no GPU needed) --------------------------------------------- */
+
+/* Replaces: obvhs::ploc::build_ploc::<24>(aabbs, identity, SortPrecision::U64, 0) and the
+ * flatten into BVHNode (extract.rs:315-332), including Model::aabb's 0.1 pad
+ * (extract.rs:220-227).  Writes up to `capacity` 48-byte nodes; contract: node 0 is the
+ * root, an interior node's children are `index` and `index+1`, leaf iff model_count > 0 and
+ * then `index` addresses the model buffer directly.  2*n_models-1 nodes for n_models >= 1. */
+int32_t brt_build_bvh(const void* models, uint32_t n_models,
+                      void* out_nodes, uint32_t capacity, uint32_t* out_n_nodes);
+
+/* Checks what brt_upload_scene checks, without a context. */
+int32_t brt_validate_scene(const void* models, uint32_t n_models,
+                           const void* materials, uint32_t n_materials,
+                           const void* bvh_nodes, uint32_t n_nodes, uint32_t* out_max_depth);
+
+/* Seeded, deterministic versions of the demo scene (reference src/main.rs:49-240 uses an
+ * unseeded RNG) and of the other BASELINE.json scenes.  Writes 32-byte Models and one
+ * 32-byte RaytraceMaterial per model (material_id = index, extract.rs:301-310). */
+enum {
+    BRT_SCENE_COVER = 0,       /* main.rs:87-239, sRGB colours decoded like extract.rs:201 */
+    BRT_SCENE_RTIOW_FINAL = 1, /* "Ray Tracing in One Weekend" final scene, linear albedos */
+    BRT_SCENE_STRESS_GRID = 2  /* ground + 100 x 100 grid of r=0.2 spheres + 3 big spheres */
+};
+int32_t brt_scene_generate(uint32_t kind, uint64_t seed,
+                           void* out_models, void* out_materials, uint32_t capacity,
+                           uint32_t* out_n_models);
+
+/* Host-side mirror of the reference's extract stage, so that a non-Rust host (the C++ /
+ * Python harnesses in this repo) produces the same bytes the Rust plugin would:
+ *   brt_host_camera_extract  = CameraExtract::extract_component (extract.rs:118-157) for a
+ *                              Transform::from_translation(t).looking_at(target, up)
+ *   brt_host_window_extract  = WindowExtract::extract_component (extract.rs:70-80), seed explicit
+ *   brt_host_material        = RaytraceMaterial::prepare_asset (extract.rs:196-208) */
+int32_t brt_host_camera_extract(const float* translation3, const float* target3, const float* up3,
+                                float fov, float aspect_ratio, float near_, float far_,
+                                uint32_t sample_count, uint32_t bounces, void* out_camera80);
+int32_t brt_host_window_extract(float random_seed, uint32_t physical_height, void* out_window16);
+int32_t brt_host_material(const float* base_color_srgb3, float metallic, float perceptual_roughness,
+                          float reflectance, float ior, float specular_transmission,
+                          void* out_material32);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEVYRAY_AMD_H */

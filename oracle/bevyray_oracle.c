@@ -1,0 +1,550 @@
+/*
+ * bevyray_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A scalar, plain-C restatement of the reference's per-pixel path-tracing loop:
+ *   /root/reference/assets/shaders/raytrace.wgsl  (lines 93-421)
+ *   /root/reference/assets/shaders/random.wgsl    (lines 3-30)
+ *   /root/reference/assets/shaders/const.wgsl     (lines 1-2)
+ * fed with the byte layouts produced by /root/reference/src/raytracing/extract.rs
+ * (Model :213-218, RaytraceMaterial :181-189, BVHNode :229-237, CameraExtract
+ * :83-97, WindowExtract :56-61, RaytraceLevelExtract :100-104).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this file's shared object.  The product (bevyray_amd/) never links, imports or
+ * calls it: the product is the HIP path and fails loudly without a GPU.
+ *
+ * PARITY UNPINNED.  The reference holds no tests, golden vectors or fixtures
+ *  and cannot be compiled or executed in this environment
+ * (no Rust toolchain, no WGSL compiler, no Vulkan ICD).  What pins this oracle
+ * instead: (1) integer known-answer vectors for the RNG and the seed formula,
+ * produced by an independent numpy restatement (tests/golden/make_golden.py);
+ * (2) analytic single-ray cases derived from the WGSL (tests/test_oracle.py);
+ * (3) brute-force (single-leaf BVH) == BVH traversal on this same code.
+ *
+ * Numeric policy (the WGSL leaves these implementation
+ * defined, the oracle and the HIP kernels make the same choice):
+ *   - every f32 operation is a separately rounded IEEE-754 binary32 operation,
+ *     no FMA contraction (build with -ffp-contract=off), round-to-nearest-even;
+ *   - sqrt and divide are correctly rounded;
+ *   - dot(a,b)   = (a.x*b.x + a.y*b.y) + a.z*b.z
+ *   - length(v)  = sqrt(dot(v,v));  normalize(v) = v / length(v) per component
+ *   - cross      = (a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x)
+ *   - min/max    = IEEE-754-2008 minNum/maxNum with -0 < +0 (the semantics of the
+ *                  gfx950 v_min_f32/v_max_f32 instructions): a NaN operand yields
+ *                  the other operand.  (WGSL: implementation defined for NaN.)
+ *   - pow(x,5.0) = (x*x)*(x*x)*x        (raytrace.wgsl:415)
+ *   - tan(fov*0.5) is evaluated on the host in double precision and rounded to
+ *     f32 once per frame (raytrace.wgsl:151 evaluates it per ray on the GPU; it
+ *     is frame-uniform)
+ *   - u32(f32) truncates toward zero and saturates to [0, 2^32-1]; NaN -> 0
+ *   - uv = ((px + 0.5)/W, (py + 0.5)/H), y down (bevy fullscreen triangle,
+ *     raytrace.wgsl:20)
+ *   - `a || b` (raytrace.wgsl:269) evaluates both operands: the RNG draw on
+ *     the right-hand side always happens.
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "bevyray_oracle.h"
+
+/* const.wgsl:1-2 */
+static const float INF = 3.40282347e+38f;
+
+typedef struct { float x, y, z; } vec3;
+
+static inline vec3 V(float x, float y, float z) { vec3 r = {x, y, z}; return r; }
+static inline vec3 vadd(vec3 a, vec3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline vec3 vsub(vec3 a, vec3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline vec3 vmul(vec3 a, vec3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline vec3 vscale(float s, vec3 a) { return V(s * a.x, s * a.y, s * a.z); }
+static inline vec3 vneg(vec3 a) { return V(-a.x, -a.y, -a.z); }
+static inline float dot(vec3 a, vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline vec3 cross(vec3 a, vec3 b) {
+    return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline vec3 normalize(vec3 v) {
+    float len = sqrtf(dot(v, v));
+    return V(v.x / len, v.y / len, v.z / len);
+}
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* IEEE-754-2008 minNum / maxNum, -0 ordered below +0 */
+static inline float min_f(float a, float b) {
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == b) return u2f(f2u(a) | f2u(b));   /* equal values or +-0: keep a sign bit */
+    return a < b ? a : b;
+}
+static inline float max_f(float a, float b) {
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == b) return u2f(f2u(a) & f2u(b));   /* +-0: +0 wins */
+    return a > b ? a : b;
+}
+
+/* WGSL u32(f32): truncate, saturate */
+static inline uint32_t f32_to_u32(float f) {
+    if (!(f > 0.0f)) return 0u;                /* negatives, -0, NaN */
+    if (f >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)f;
+}
+
+/* ---- random.wgsl ------------------------------------------------------- */
+
+/* random.wgsl:8-15 */
+static inline void rngNextInt(uint32_t* state) {
+    uint32_t oldState = *state + 747796405u + 2891336453u;
+    uint32_t word = ((oldState >> ((oldState >> 28u) + 4u)) ^ oldState) * 277803737u;
+    *state = (word >> 22u) ^ word;
+}
+
+/* random.wgsl:3-6 */
+static inline float rngNextFloat(uint32_t* state) {
+    rngNextInt(state);
+    return (float)(*state) / (float)0xffffffffu;
+}
+
+/* random.wgsl:17-26 */
+static inline vec3 randomVec3InUnitSphere(uint32_t* state) {
+    vec3 p;
+    for (;;) {
+        float x = rngNextFloat(state);
+        float y = rngNextFloat(state);
+        float z = rngNextFloat(state);
+        p = vsub(vscale(2.0f, V(x, y, z)), V(1.0f, 1.0f, 1.0f));
+        if (dot(p, p) <= 1.0f) break;
+    }
+    return p;
+}
+
+/* random.wgsl:28-30 (not normalised, despite the name) */
+static inline vec3 randomUnitVec3(uint32_t* state) { return randomVec3InUnitSphere(state); }
+
+/* ---- byte layouts (extract.rs) ----------------------------------------- */
+
+typedef struct { float px, py, pz, radius; uint32_t material_id; uint32_t pad[3]; } Model;          /* 32 B */
+typedef struct { float r, g, b, metallic, roughness, reflectance, ior, specular_transmission; } Material; /* 32 B */
+typedef struct { float minx, miny, minz, pad0, maxx, maxy, maxz; uint32_t index, model_count, pad1[3]; } BVHNode; /* 48 B */
+typedef struct {
+    uint32_t sample_count, bounce_count, projection;
+    float near_, far_, fov, aspect, pad0;
+    float px, py, pz, pad1;
+    float dx, dy, dz, pad2;
+    float ux, uy, uz, pad3;
+} Camera;  /* 80 B */
+typedef struct { float random_seed; uint32_t height; float pad[2]; } Window; /* 16 B */
+
+_Static_assert(sizeof(Model) == 32, "Model stride");
+_Static_assert(sizeof(Material) == 32, "Material stride");
+_Static_assert(sizeof(BVHNode) == 48, "BVHNode stride");
+_Static_assert(sizeof(Camera) == 80, "Camera size");
+_Static_assert(sizeof(Window) == 16, "Window size");
+
+typedef struct {
+    const Model* models; uint32_t n_models;
+    const Material* materials; uint32_t n_materials;
+    const BVHNode* bvh; uint32_t n_nodes;
+    Camera camera;
+    Window window;
+    uint32_t level;
+    float tan_half_fov;       /* tan(camera.fov * 0.5), host evaluated */
+} Scene;
+
+typedef struct { vec3 origin, direction; } Ray;
+typedef struct { vec3 color; float depth; } RaytraceResult;
+typedef struct { float distance; vec3 position, normal; uint32_t material; int front_face; } HitInfo;
+
+typedef struct { uint64_t rays, node_pops, interior, sphere_tests, hits; } Counters;
+
+/* raytrace.wgsl:130-132 */
+static inline vec3 ray_at(Ray ray, float t) { return vadd(ray.origin, vscale(t, ray.direction)); }
+
+/* raytrace.wgsl:371-383 */
+static inline float hit_sphere(const Model* sphere, Ray ray) {
+    vec3 oc = vsub(V(sphere->px, sphere->py, sphere->pz), ray.origin);
+    float a = dot(ray.direction, ray.direction);
+    float h = dot(ray.direction, oc);
+    float c = dot(oc, oc) - sphere->radius * sphere->radius;
+    float discriminant = h * h - a * c;
+    if (discriminant < 0.0f) return -1.0f;
+    return (h - sqrtf(discriminant)) / a;
+}
+
+/* raytrace.wgsl:387-398 */
+static inline float ray_bounding_dst(Ray ray, vec3 box_min, vec3 box_max) {
+    vec3 inv = V(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
+    vec3 t_min = vmul(vsub(box_min, ray.origin), inv);
+    vec3 t_max = vmul(vsub(box_max, ray.origin), inv);
+    vec3 t1 = V(min_f(t_min.x, t_max.x), min_f(t_min.y, t_max.y), min_f(t_min.z, t_max.z));
+    vec3 t2 = V(max_f(t_min.x, t_max.x), max_f(t_min.y, t_max.y), max_f(t_min.z, t_max.z));
+    float t_near = max_f(max_f(t1.x, t1.y), t1.z);
+    float t_far = min_f(min_f(t2.x, t2.y), t2.z);
+    int hit = (t_far >= t_near) && (t_far > 0.0f);
+    /* select(INF, select(0.0, t_near, t_near > 0.0), hit) */
+    return hit ? (t_near > 0.0f ? t_near : 0.0f) : INF;
+}
+
+/* raytrace.wgsl:348-362 */
+static inline void raycast_against_range(const Scene* s, Ray ray, uint32_t start_index, uint32_t amount,
+                                         HitInfo* closest, Counters* cnt) {
+    for (uint32_t model_index = start_index; model_index < start_index + amount; model_index++) {
+        const Model* model = &s->models[model_index];
+        cnt->sphere_tests++;
+        float hit_distance = hit_sphere(model, ray);
+        if (hit_distance != -1.0f && hit_distance > 0.001f) {
+            if (hit_distance < closest->distance) {
+                vec3 hit_position = ray_at(ray, hit_distance);
+                vec3 normal = normalize(vsub(hit_position, V(model->px, model->py, model->pz)));
+                closest->distance = hit_distance;
+                closest->position = hit_position;
+                closest->normal = normal;
+                closest->material = model->material_id;
+                closest->front_face = dot(ray.direction, normal) < 0.0f;
+            }
+        }
+    }
+}
+
+#define STACKSIZE 32  /* raytrace.wgsl:310 */
+
+/* raytrace.wgsl:313-346 */
+static HitInfo raycast(const Scene* s, Ray ray, Counters* cnt) {
+    HitInfo closest;
+    closest.distance = INF;
+    closest.position = V(0, 0, 0);
+    closest.normal = V(0, 0, 0);
+    closest.material = 0;
+    closest.front_face = 1;
+
+    uint32_t stack[STACKSIZE];
+    memset(stack, 0, sizeof stack);
+    int stack_index = 1;
+    cnt->rays++;
+
+    while (stack_index > 0 && stack_index < STACKSIZE) {
+        stack_index--;
+        uint32_t next = stack[stack_index];
+        const BVHNode* bvh_node = &s->bvh[next];
+        cnt->node_pops++;
+
+        if (bvh_node->model_count > 0) {
+            raycast_against_range(s, ray, bvh_node->index, bvh_node->model_count, &closest, cnt);
+        } else {
+            cnt->interior++;
+            const BVHNode* node_1 = &s->bvh[bvh_node->index];
+            float dst_1 = ray_bounding_dst(ray, V(node_1->minx, node_1->miny, node_1->minz),
+                                           V(node_1->maxx, node_1->maxy, node_1->maxz));
+            if (dst_1 != INF && dst_1 < closest.distance) {
+                stack[stack_index] = bvh_node->index;
+                stack_index++;
+            }
+            const BVHNode* node_2 = &s->bvh[bvh_node->index + 1];
+            float dst_2 = ray_bounding_dst(ray, V(node_2->minx, node_2->miny, node_2->minz),
+                                           V(node_2->maxx, node_2->maxy, node_2->maxz));
+            if (dst_2 != INF && dst_2 < closest.distance) {
+                stack[stack_index] = bvh_node->index + 1;
+                stack_index++;
+            }
+        }
+    }
+    return closest;
+}
+
+/* raytrace.wgsl:364-369 */
+static inline vec3 background_gradient(Ray ray) {
+    vec3 unit = normalize(ray.direction);
+    float a = 0.5f * (unit.y + 1.0f);
+    return vadd(vscale(1.0f - a, V(1.0f, 1.0f, 1.0f)), vscale(a, V(0.5f, 0.7f, 1.0f)));
+}
+
+/* raytrace.wgsl:400-402 */
+static inline vec3 reflect_(vec3 vector, vec3 normal) {
+    return vsub(vector, vscale(2.0f * dot(vector, normal), normal));
+}
+
+/* raytrace.wgsl:404-409 */
+static inline vec3 refract_(vec3 vector, vec3 normal, float etai_over_etat) {
+    float cos_theta = min_f(dot(vneg(vector), normal), 1.0f);
+    vec3 r_out_perp = vscale(etai_over_etat, vadd(vector, vscale(cos_theta, normal)));
+    vec3 r_out_parallel = vscale(-sqrtf(fabsf(1.0f - dot(r_out_perp, r_out_perp))), normal);
+    return vadd(r_out_perp, r_out_parallel);
+}
+
+/* raytrace.wgsl:411-416, pow(x,5) restated as multiplies (R14) */
+static inline float reflectance_(float cosine, float refraction_index) {
+    float r0 = (1.0f - refraction_index) / (1.0f + refraction_index);
+    r0 = r0 * r0;
+    float x = 1.0f - cosine;
+    float x2 = x * x;
+    return r0 + (1.0f - r0) * ((x2 * x2) * x);
+}
+
+/* raytrace.wgsl:418-421 */
+static inline int vec3_near_zero(vec3 v) {
+    const float s = 1e-8f;
+    return fabsf(v.x) < s && fabsf(v.y) < s && fabsf(v.z) < s;
+}
+
+/* raytrace.wgsl:231-299; returns whether the ray was absorbed */
+static int scatter(const Scene* s, Ray* scattered, vec3* attenuation, const HitInfo* hit, uint32_t* state) {
+    const Material* material = &s->materials[hit->material];
+    vec3 base_color = V(material->r, material->g, material->b);
+
+    if (rngNextFloat(state) < material->metallic) {
+        vec3 fuzz = vscale(material->roughness, randomUnitVec3(state));
+        vec3 reflected = vadd(normalize(reflect_(scattered->direction, hit->normal)), fuzz);
+        scattered->origin = hit->position;
+        scattered->direction = reflected;
+        *attenuation = base_color;
+        return dot(scattered->direction, hit->normal) < 0.0f;
+    } else {
+        if (rngNextFloat(state) < material->specular_transmission) {
+            float ri;
+            if (hit->front_face) ri = 1.0f / material->ior;
+            else ri = material->ior;
+
+            vec3 unit_direction = normalize(scattered->direction);
+            float cos_theta = min_f(dot(vneg(unit_direction), hit->normal), 1.0f);
+            float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+            int cannot_refract = ri * sin_theta > 1.0f;
+            /* both operands of || are evaluated: the draw always happens */
+            float refl = reflectance_(cos_theta, ri);
+            float draw = rngNextFloat(state);
+            vec3 direction;
+            if (cannot_refract || refl > draw) direction = reflect_(unit_direction, hit->normal);
+            else direction = refract_(unit_direction, hit->normal, ri);
+
+            scattered->origin = hit->position;
+            scattered->direction = direction;
+            *attenuation = V(1.0f, 1.0f, 1.0f);
+            return 0;
+        } else {
+            /* hit.normal + randomUnitVec3 + (roughness * randomUnitVec3), left to right */
+            vec3 b1 = randomUnitVec3(state);
+            vec3 b2 = randomUnitVec3(state);
+            vec3 scatter_direction = vadd(vadd(hit->normal, b1), vscale(material->roughness, b2));
+            if (vec3_near_zero(scatter_direction)) scatter_direction = hit->normal;
+            scattered->origin = hit->position;
+            scattered->direction = scatter_direction;
+            *attenuation = base_color;
+            return dot(scattered->direction, hit->normal) < 0.0f;
+        }
+    }
+}
+
+/* raytrace.wgsl:226-228 */
+static inline vec3 linear_to_gamma_Vec3(vec3 in) { return V(sqrtf(in.x), sqrtf(in.y), sqrtf(in.z)); }
+
+/* raytrace.wgsl:174-224 */
+static RaytraceResult raytrace(const Scene* s, Ray base_ray, uint32_t* state, Counters* cnt) {
+    Ray ray = base_ray;
+    float fallback_far;
+    if (s->level == 1) fallback_far = s->camera.far_ + 10.0f;
+    else fallback_far = s->camera.far_ - 1.0f;
+
+    float first_depth = INF;
+    vec3 ray_color = V(1.0f, 1.0f, 1.0f);
+    vec3 lightSourceColor = V(0.0f, 0.0f, 0.0f);
+
+    uint32_t bounce_count = 0;
+    for (; bounce_count <= s->camera.bounce_count; bounce_count++) {
+        HitInfo hit = raycast(s, ray, cnt);
+        if (bounce_count == 0) first_depth = hit.distance;
+        if (hit.distance == INF) {
+            lightSourceColor = background_gradient(ray);
+            break;
+        }
+        vec3 attenuation;
+        cnt->hits++;
+        int absorbed = scatter(s, &ray, &attenuation, &hit, state);
+        if (absorbed) break;
+        ray_color = vmul(ray_color, attenuation);
+    }
+    if (bounce_count == s->camera.bounce_count + 1u) ray_color = V(0.0f, 0.0f, 0.0f);
+    if (first_depth == INF) first_depth = fallback_far;
+
+    RaytraceResult r;
+    r.color = linear_to_gamma_Vec3(vmul(ray_color, lightSourceColor));
+    r.depth = first_depth;
+    return r;
+}
+
+/* raytrace.wgsl:139-156 */
+static Ray random_ray_from_uv(const Scene* s, float uvx, float uvy, uint32_t* state) {
+    float rx = rngNextFloat(state) - 0.5f;
+    float ry = rngNextFloat(state) - 0.5f;
+    float height = (float)s->window.height;
+    float width = (float)s->window.height * s->camera.aspect;
+    float delta_u = (1.0f / width) * rx;
+    float delta_v = (1.0f / height) * ry;
+
+    float ndc_x = (uvx * 2.0f - 1.0f) + delta_u;
+    float ndc_y = (1.0f - uvy * 2.0f) + delta_v;
+
+    vec3 cdir = V(s->camera.dx, s->camera.dy, s->camera.dz);
+    vec3 cup = V(s->camera.ux, s->camera.uy, s->camera.uz);
+    vec3 right = cross(cdir, cup);
+    float scale = s->tan_half_fov;
+
+    vec3 d = vadd(vadd(cdir, vscale(ndc_x * s->camera.aspect * scale, right)), vscale(ndc_y * scale, cup));
+    Ray r;
+    r.origin = V(s->camera.px, s->camera.py, s->camera.pz);
+    r.direction = normalize(d);
+    return r;
+}
+
+/* raytrace.wgsl:159-172 */
+static RaytraceResult trace_multisampled(const Scene* s, float uvx, float uvy, uint32_t* state, Counters* cnt) {
+    RaytraceResult total = { {0.0f, 0.0f, 0.0f}, 0.0f };
+    for (uint32_t sample_index = 0; sample_index < s->camera.sample_count; sample_index++) {
+        Ray ray = random_ray_from_uv(s, uvx, uvy, state);
+        RaytraceResult sample_result = raytrace(s, ray, state, cnt);
+        total.color = vadd(total.color, sample_result.color);
+        total.depth += sample_result.depth;
+    }
+    float n = (float)s->camera.sample_count;
+    RaytraceResult r;
+    r.color = V(total.color.x / n, total.color.y / n, total.color.z / n);
+    r.depth = total.depth / n;
+    return r;
+}
+
+/* raytrace.wgsl:93-123.  textureSample at a pixel centre of a same-size texture is the texel. */
+static void fragment(const Scene* s, uint32_t px, uint32_t py, uint32_t W, uint32_t H,
+                     const float* raster_rgba, const float* raster_depth, float* out4, Counters* cnt) {
+    float uvx = ((float)px + 0.5f) / (float)W;
+    float uvy = ((float)py + 0.5f) / (float)H;
+    uint32_t rng_state = f32_to_u32((s->window.random_seed * 10000.0f) * (uvx * 402.0f) * (uvy * 31.5f));
+
+    size_t pix = (size_t)py * W + px;
+    float raster[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (raster_rgba) memcpy(raster, raster_rgba + 4 * pix, sizeof raster);
+
+    if (s->level == 0) { memcpy(out4, raster, sizeof raster); return; }
+
+    RaytraceResult rr = trace_multisampled(s, uvx, uvy, &rng_state, cnt);
+
+    if (s->level == 1 || s->level == 2) {
+        float depth = raster_depth ? raster_depth[pix] : 0.0f;
+        float raytraced_depth = rr.depth;
+        if (raytraced_depth > s->camera.far_) raytraced_depth = -1.0f;
+        else raytraced_depth = s->camera.near_ / raytraced_depth;
+        if (depth > raytraced_depth) { memcpy(out4, raster, sizeof raster); return; }
+    }
+    out4[0] = rr.color.x; out4[1] = rr.color.y; out4[2] = rr.color.z; out4[3] = 1.0f;
+}
+
+/* ---- public entry points ---------------------------------------------- */
+
+float oracle_tan_half_fov(float fov) { return (float)tan((double)(fov * 0.5f)); }
+
+typedef struct {
+    const Scene* s;
+    uint32_t W, H, row_begin, row_end;
+    const float* raster_rgba; const float* raster_depth;
+    float* out_rgba;
+    uint32_t* next_row;     /* shared work counter */
+    pthread_mutex_t* mu;
+    Counters cnt;
+} Job;
+
+static void* worker(void* arg) {
+    Job* j = (Job*)arg;
+    for (;;) {
+        pthread_mutex_lock(j->mu);
+        uint32_t row = (*j->next_row)++;
+        pthread_mutex_unlock(j->mu);
+        if (row >= j->row_end) break;
+        for (uint32_t px = 0; px < j->W; px++)
+            fragment(j->s, px, row, j->W, j->H, j->raster_rgba, j->raster_depth,
+                     j->out_rgba + 4 * ((size_t)row * j->W + px), &j->cnt);
+    }
+    return NULL;
+}
+
+int oracle_render(const void* models, uint32_t n_models, const void* materials, uint32_t n_materials,
+                  const void* bvh_nodes, uint32_t n_nodes, const void* camera80, const void* window16,
+                  uint32_t level, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end,
+                  const float* raster_rgba, const float* raster_depth, float* out_rgba,
+                  uint64_t* counters5, int n_threads) {
+    if (!camera80 || !window16 || !out_rgba) return -1;
+    if (n_nodes == 0 || !bvh_nodes) return -2;
+    if (row_end > height) row_end = height;
+    Scene s;
+    s.models = (const Model*)models; s.n_models = n_models;
+    s.materials = (const Material*)materials; s.n_materials = n_materials;
+    s.bvh = (const BVHNode*)bvh_nodes; s.n_nodes = n_nodes;
+    memcpy(&s.camera, camera80, 80);
+    memcpy(&s.window, window16, 16);
+    s.level = level;
+    s.tan_half_fov = oracle_tan_half_fov(s.camera.fov);
+
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    uint32_t next_row = row_begin;
+    Job* jobs = (Job*)calloc((size_t)n_threads, sizeof(Job));
+    pthread_t* th = (pthread_t*)calloc((size_t)n_threads, sizeof(pthread_t));
+    for (int i = 0; i < n_threads; i++) {
+        jobs[i].s = &s; jobs[i].W = width; jobs[i].H = height;
+        jobs[i].row_begin = row_begin; jobs[i].row_end = row_end;
+        jobs[i].raster_rgba = raster_rgba; jobs[i].raster_depth = raster_depth;
+        jobs[i].out_rgba = out_rgba; jobs[i].next_row = &next_row; jobs[i].mu = &mu;
+    }
+    if (n_threads == 1) worker(&jobs[0]);
+    else {
+        for (int i = 0; i < n_threads; i++) pthread_create(&th[i], NULL, worker, &jobs[i]);
+        for (int i = 0; i < n_threads; i++) pthread_join(th[i], NULL);
+    }
+    if (counters5) {
+        memset(counters5, 0, 5 * sizeof(uint64_t));
+        for (int i = 0; i < n_threads; i++) {
+            counters5[0] += jobs[i].cnt.rays; counters5[1] += jobs[i].cnt.node_pops;
+            counters5[2] += jobs[i].cnt.interior; counters5[3] += jobs[i].cnt.sphere_tests;
+            counters5[4] += jobs[i].cnt.hits;
+        }
+    }
+    free(jobs); free(th);
+    return 0;
+}
+
+/* Small probes so tests can pin individual functions against the numpy mirror. */
+uint32_t oracle_rng_next(uint32_t state) { rngNextInt(&state); return state; }
+float oracle_rng_float(uint32_t* state) { return rngNextFloat(state); }
+uint32_t oracle_seed(float random_seed, uint32_t px, uint32_t py, uint32_t W, uint32_t H) {
+    float uvx = ((float)px + 0.5f) / (float)W;
+    float uvy = ((float)py + 0.5f) / (float)H;
+    return f32_to_u32((random_seed * 10000.0f) * (uvx * 402.0f) * (uvy * 31.5f));
+}
+void oracle_unit_ball(uint32_t* state, float* out3) {
+    vec3 p = randomUnitVec3(state); out3[0] = p.x; out3[1] = p.y; out3[2] = p.z;
+}
+float oracle_min(float a, float b) { return min_f(a, b); }
+float oracle_max(float a, float b) { return max_f(a, b); }
+float oracle_ray_bounding_dst(const float* o3, const float* d3, const float* bmin3, const float* bmax3) {
+    Ray r; r.origin = V(o3[0], o3[1], o3[2]); r.direction = V(d3[0], d3[1], d3[2]);
+    return ray_bounding_dst(r, V(bmin3[0], bmin3[1], bmin3[2]), V(bmax3[0], bmax3[1], bmax3[2]));
+}
+float oracle_hit_sphere(const float* o3, const float* d3, const float* center3, float radius) {
+    Model m; memset(&m, 0, sizeof m); m.px = center3[0]; m.py = center3[1]; m.pz = center3[2]; m.radius = radius;
+    Ray r; r.origin = V(o3[0], o3[1], o3[2]); r.direction = V(d3[0], d3[1], d3[2]);
+    return hit_sphere(&m, r);
+}
+/* One raycast through the given scene; out8 = distance, position xyz, normal xyz, material (as float bits of u32) */
+int oracle_raycast(const void* models, uint32_t n_models, const void* bvh_nodes, uint32_t n_nodes,
+                   const float* o3, const float* d3, float* out7, uint32_t* out_material, int* out_front) {
+    Scene s; memset(&s, 0, sizeof s);
+    s.models = (const Model*)models; s.n_models = n_models; s.bvh = (const BVHNode*)bvh_nodes; s.n_nodes = n_nodes;
+    Ray r; r.origin = V(o3[0], o3[1], o3[2]); r.direction = V(d3[0], d3[1], d3[2]);
+    Counters c; memset(&c, 0, sizeof c);
+    HitInfo h = raycast(&s, r, &c);
+    out7[0] = h.distance; out7[1] = h.position.x; out7[2] = h.position.y; out7[3] = h.position.z;
+    out7[4] = h.normal.x; out7[5] = h.normal.y; out7[6] = h.normal.z;
+    *out_material = h.material; *out_front = h.front_face;
+    return 0;
+}

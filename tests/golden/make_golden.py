@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Generates the committed fixtures under tests/golden/.
+
+1. rng_kat.json -- known-answer vectors for the integer RNG (reference
+   assets/shaders/random.wgsl:3-15) and the per-pixel seed formula (reference
+   assets/shaders/raytrace.wgsl:95), computed HERE with numpy uint32/float32 arithmetic,
+   independently of the C oracle and of the HIP kernels.  The reference has no tests or golden
+   vectors of its own, and it cannot be executed in this environment, so
+   these are derived from reading the WGSL.
+2. cover_64x36.npz -- a small regression fixture: scene bytes + uniforms (inputs) and the
+   frame + counters the C oracle produced for them (expected outputs).  It pins the oracle and
+   the kernels against silent drift; it is NOT reference output ("parity unpinned").
+
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+U32 = np.uint32
+F32 = np.float32
+
+
+def rng_next_int(state: int) -> int:
+    """random.wgsl:8-15, wrapping u32"""
+    with np.errstate(over="ignore"):
+        old = U32(state) + U32(747796405) + U32(2891336453)
+        word = ((old >> ((old >> U32(28)) + U32(4))) ^ old) * U32(277803737)
+        return int((word >> U32(22)) ^ word)
+
+
+def rng_next_float(state: int):
+    """random.wgsl:3-6 -> (float32 value, new state)"""
+    s = rng_next_int(state)
+    return F32(s) / F32(0xFFFFFFFF), s
+
+
+def seed(random_seed: float, px: int, py: int, w: int, h: int) -> int:
+    """raytrace.wgsl:95 with uv = ((px+0.5)/W, (py+0.5)/H), all f32, left-assoc, truncating"""
+    uvx = (F32(px) + F32(0.5)) / F32(w)
+    uvy = (F32(py) + F32(0.5)) / F32(h)
+    v = (F32(random_seed) * F32(10000.0)) * (uvx * F32(402.0)) * (uvy * F32(31.5))
+    if not (v > 0):
+        return 0
+    if v >= F32(4294967296.0):
+        return 0xFFFFFFFF
+    return int(np.floor(v))
+
+
+def main():
+    rng = np.random.default_rng(20241022)
+    starts = [0, 1, 12345, 0xFFFFFFFF, 0x80000000, 0xFFFFFF80, 0xFFFFFF7F] + [int(x) for x in rng.integers(0, 2**32, 24)]
+    chains = []
+    for s0 in starts:
+        states, floats = [], []
+        s = s0
+        for _ in range(8):
+            f, s = rng_next_float(s)
+            states.append(s)
+            floats.append(float(f))
+        chains.append({"start": s0, "states": states, "floats": floats})
+    seeds = []
+    cases = [(0.5, 0, 0, 400, 225), (0.5, 199, 112, 400, 225), (0.5, 399, 224, 400, 225), (0.5, 960, 540, 1920, 1080),
+             (0.999, 1919, 1079, 1920, 1080), (0.25, 100, 50, 1920, 1080), (0.0, 7, 9, 64, 36), (1.0, 3839, 2159, 3840, 2160)]
+    for _ in range(24):
+        w, h = int(rng.integers(1, 4000)), int(rng.integers(1, 2200))
+        cases.append((float(F32(rng.random())), int(rng.integers(0, w)), int(rng.integers(0, h)), w, h))
+    for c in cases:
+        seeds.append({"random_seed": c[0], "px": c[1], "py": c[2], "w": c[3], "h": c[4], "seed": seed(*c)})
+    with open(os.path.join(HERE, "rng_kat.json"), "w") as f:
+        json.dump({"chains": chains, "seeds": seeds}, f, indent=1)
+    print("wrote rng_kat.json")
+
+    # regression fixture from the C oracle
+    import bevyray_amd as brt
+    import oracle_loader
+    o = oracle_loader.load()
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    lvl, cam, win = brt.cover_camera(64, 36, 3, 4, brt.Raytracing.Pure, 0.5)
+    frame, cnt = o.render(b, lvl, cam, win, 64, 36, threads=1)
+    np.savez_compressed(os.path.join(HERE, "cover_64x36.npz"), models=b.models.view(np.uint8), materials=b.materials.view(np.uint8),
+                        bvh=b.bvh.view(np.uint8), level=lvl.view(np.uint8), camera=cam.view(np.uint8),
+                        window=win.view(np.uint8), frame=frame,
+                        counters=np.array([cnt[k] for k in ("rays", "node_pops", "interior_visits", "sphere_tests", "hits")], np.uint64))
+    print("wrote cover_64x36.npz", cnt)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,139 @@
+"""Shared test helpers: hand-made BVHs (single leaf, median split, caterpillar chain), uniform
+builders and a numpy-f32 restatement of the camera/sky arithmetic for analytic checks."""
+import os
+
+import numpy as np
+
+import bevyray_amd as brt
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+F32 = np.float32
+
+
+def _padded_boxes(models):
+    pos = models["position"].astype(np.float32)
+    pad = (models["radius"].astype(np.float32) + F32(0.1))[:, None]   # Model::aabb, extract.rs:220-227
+    return pos - pad, pos + pad
+
+
+def single_leaf_bvh(models):
+    """One leaf holding every model: the reference's own loop then tests all spheres
+    (raytrace.wgsl:325-326,349) -- the brute-force truth."""
+    lo, hi = _padded_boxes(models)
+    nodes = np.zeros(1, brt.BVH_NODE_DTYPE)
+    nodes[0]["bounds_min"], nodes[0]["bounds_max"] = lo.min(0), hi.max(0)
+    nodes[0]["index"], nodes[0]["model_count"] = 0, len(models)
+    return nodes
+
+
+def median_split_bvh(models, leaf_size=2):
+    """Splits the model ARRAY at its midpoint (no reordering, so leaves are contiguous model
+    ranges); leaves hold up to leaf_size models -> exercises multi-model leaves."""
+    lo, hi = _padded_boxes(models)
+    nodes = [None]
+
+    def build(slot, a, b):
+        box = (lo[a:b].min(0), hi[a:b].max(0))
+        if b - a <= leaf_size:
+            nodes[slot] = (box, a, b - a)
+            return
+        first = len(nodes)
+        nodes.extend([None, None])
+        nodes[slot] = (box, first, 0)
+        mid = (a + b) // 2
+        build(first, a, mid)
+        build(first + 1, mid, b)
+
+    build(0, 0, len(models))
+    out = np.zeros(len(nodes), brt.BVH_NODE_DTYPE)
+    for i, (box, index, count) in enumerate(nodes):
+        out[i]["bounds_min"], out[i]["bounds_max"] = box
+        out[i]["index"], out[i]["model_count"] = index, count
+    return out
+
+
+def chain_bvh(models, far_first=False):
+    """Caterpillar: level k has leaf `2k+1` (popped LAST, raytrace.wgsl:332-340) and interior
+    `2k+2`; the bottom holds two leaves.  Leaf at level k = model n-1-k, so model 0 is at the
+    bottom.  Every interior box is the union box.  Depth n-1."""
+    n = len(models)
+    assert n >= 2
+    lo, hi = _padded_boxes(models)
+    order = list(range(n - 1, -1, -1))
+    if far_first:
+        order = order[::-1]
+    nodes = np.zeros(2 * n - 1, brt.BVH_NODE_DTYPE)
+    union = (lo.min(0), hi.max(0))
+    cur = 0
+    for k in range(n - 1):
+        nodes[cur]["bounds_min"], nodes[cur]["bounds_max"] = union
+        nodes[cur]["index"], nodes[cur]["model_count"] = 2 * k + 1, 0
+        m = order[k]
+        leaf = 2 * k + 1
+        nodes[leaf]["bounds_min"], nodes[leaf]["bounds_max"] = lo[m], hi[m]
+        nodes[leaf]["index"], nodes[leaf]["model_count"] = m, 1
+        cur = 2 * k + 2
+    m = order[n - 1]
+    nodes[cur]["bounds_min"], nodes[cur]["bounds_max"] = lo[m], hi[m]
+    nodes[cur]["index"], nodes[cur]["model_count"] = m, 1
+    return nodes
+
+
+def make_buffers(data, bvh_fn=None):
+    """data = [(position, radius, StandardMaterial)] -> Buffers; bvh_fn(models) or the PLOC builder."""
+    b = brt.prepare_buffers([(p, brt.RaytracedSphere(r), m) for p, r, m in data])
+    if bvh_fn is not None:
+        b = brt.Buffers(b.models, b.materials, bvh_fn(b.models))
+    return b
+
+
+def uniforms(w, h, spp, bounces, pos, target, fov, seed, level=brt.Raytracing.Pure, near=0.1, far=1000.0,
+             up=(0.0, 1.0, 0.0), window_height=None):
+    cam = brt.RaytracedCamera(level=level, sample_count=spp, bounces=bounces)
+    proj = brt.PerspectiveProjection(fov=fov, aspect_ratio=w / h, near=near, far=far)
+    lvl, cex = brt.CameraExtract.extract_component(cam, brt.Transform(pos, target, up), proj)
+    return lvl, cex, brt.WindowExtract.extract_component(h if window_height is None else window_height, seed)
+
+
+def fixture_buffers():
+    z = np.load(os.path.join(GOLDEN, "cover_64x36.npz"))
+    b = brt.Buffers(z["models"].view(brt.MODEL_DTYPE), z["materials"].view(brt.MATERIAL_DTYPE), z["bvh"].view(brt.BVH_NODE_DTYPE))
+    return (b, z["level"].view(brt.LEVEL_DTYPE), z["camera"].view(brt.CAMERA_DTYPE), z["window"].view(brt.WINDOW_DTYPE),
+            z["frame"], [int(x) for x in z["counters"]])
+
+
+def sky_color(oracle, cam, win, w, h, spp):
+    """Expected frame when EVERY ray misses, restated in numpy f32 from raytrace.wgsl:95,
+    139-156,161-170,198-201,223,364-369 (RNG draws taken from the pinned oracle RNG)."""
+    c = cam[0]
+    seed = F32(win[0]["random_seed"])
+    height = F32(win[0]["height"])
+    aspect = F32(c["aspect"])
+    width = height * aspect
+    cd, cu = c["direction"].astype(F32), c["up"].astype(F32)
+    right = np.array([cd[1] * cu[2] - cd[2] * cu[1], cd[2] * cu[0] - cd[0] * cu[2], cd[0] * cu[1] - cd[1] * cu[0]], F32)
+    scale = F32(oracle.lib.oracle_tan_half_fov(float(c["fov"])))
+    out = np.zeros((h, w, 3), F32)
+    for py in range(h):
+        for px in range(w):
+            uvx = (F32(px) + F32(0.5)) / F32(w)
+            uvy = (F32(py) + F32(0.5)) / F32(h)
+            state = oracle.lib.oracle_seed(float(seed), px, py, w, h)
+            total = np.zeros(3, F32)
+            for _ in range(spp):
+                r, state = oracle.rng_floats(state, 2)
+                rx, ry = r[0] - F32(0.5), r[1] - F32(0.5)
+                du, dv = (F32(1.0) / width) * rx, (F32(1.0) / height) * ry
+                ndc_x = (uvx * F32(2.0) - F32(1.0)) + du
+                ndc_y = (F32(1.0) - uvy * F32(2.0)) + dv
+                d = (cd + (ndc_x * aspect * scale) * right) + (ndc_y * scale) * cu
+                d = d.astype(F32)
+                ln = np.sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2], dtype=F32)
+                rd = (d / ln).astype(F32)                     # ray direction, raytrace.wgsl:153
+                ln2 = np.sqrt((rd[0] * rd[0] + rd[1] * rd[1]) + rd[2] * rd[2], dtype=F32)
+                u = (rd / ln2).astype(F32)                   # background_gradient normalises again, :365
+                a = F32(0.5) * (u[1] + F32(1.0))
+                col = (F32(1.0) - a) * np.ones(3, F32) + a * np.array([0.5, 0.7, 1.0], F32)
+                total = (total + np.sqrt(col.astype(F32), dtype=F32)).astype(F32)
+            out[py, px] = total / F32(spp)
+    return out

@@ -1,0 +1,94 @@
+"""Loads the CPU oracle (oracle/libbevyray_oracle.so).  TEST INFRASTRUCTURE ONLY: this module
+lives under tests/ and is imported by tests, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the bevyray_amd package."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "libbevyray_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(ORACLE_DIR, "bevyray_oracle.c")
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        proc = subprocess.run(["make", "-C", ORACLE_DIR] + (["-B"] if force else []), capture_output=True, text=True)
+        if proc.returncode != 0:
+            raise RuntimeError("oracle build failed:\n" + proc.stdout + proc.stderr)
+    return LIB
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        VP, U32, F = C.c_void_p, C.c_uint32, C.c_float
+        lib.oracle_render.restype = C.c_int
+        lib.oracle_render.argtypes = [VP, U32, VP, U32, VP, U32, VP, VP, U32, U32, U32, U32, U32, VP, VP, VP, VP, C.c_int]
+        lib.oracle_tan_half_fov.restype = F
+        lib.oracle_tan_half_fov.argtypes = [F]
+        lib.oracle_rng_next.restype = U32
+        lib.oracle_rng_next.argtypes = [U32]
+        lib.oracle_rng_float.restype = F
+        lib.oracle_rng_float.argtypes = [C.POINTER(U32)]
+        lib.oracle_seed.restype = U32
+        lib.oracle_seed.argtypes = [F, U32, U32, U32, U32]
+        lib.oracle_unit_ball.restype = None
+        lib.oracle_unit_ball.argtypes = [C.POINTER(U32), C.POINTER(F)]
+        lib.oracle_min.restype = F
+        lib.oracle_min.argtypes = [F, F]
+        lib.oracle_max.restype = F
+        lib.oracle_max.argtypes = [F, F]
+        lib.oracle_ray_bounding_dst.restype = F
+        lib.oracle_ray_bounding_dst.argtypes = [C.POINTER(F)] * 4
+        lib.oracle_hit_sphere.restype = F
+        lib.oracle_hit_sphere.argtypes = [C.POINTER(F)] * 3 + [F]
+        lib.oracle_raycast.restype = C.c_int
+        lib.oracle_raycast.argtypes = [VP, U32, VP, U32, C.POINTER(F), C.POINTER(F), C.POINTER(F), C.POINTER(U32),
+                                       C.POINTER(C.c_int)]
+
+    def render(self, buffers, level, camera, window, width, height, raster_rgba=None, raster_depth=None,
+               rows=None, threads=None):
+        """Full frame (or rows [r0,r1)) -> (frame (H,W,4) f32, counters dict)."""
+        models = np.ascontiguousarray(buffers.models)
+        materials = np.ascontiguousarray(buffers.materials)
+        bvh = np.ascontiguousarray(buffers.bvh)
+        out = np.zeros((height, width, 4), np.float32)
+        cnt = (C.c_uint64 * 5)()
+        r0, r1 = (0, height) if rows is None else rows
+        rr = None if raster_rgba is None else np.ascontiguousarray(raster_rgba, np.float32)
+        rd = None if raster_depth is None else np.ascontiguousarray(raster_depth, np.float32)
+        if threads is None:
+            threads = os.cpu_count() or 1
+        rc = self.lib.oracle_render(models.ctypes.data, len(models), materials.ctypes.data, len(materials),
+                                    bvh.ctypes.data, len(bvh), camera.ctypes.data, window.ctypes.data,
+                                    int(level["level"][0]), width, height, r0, r1,
+                                    None if rr is None else rr.ctypes.data, None if rd is None else rd.ctypes.data,
+                                    out.ctypes.data, cnt, threads)
+        if rc != 0:
+            raise RuntimeError(f"oracle_render failed: {rc}")
+        names = ["rays", "node_pops", "interior_visits", "sphere_tests", "hits"]
+        return out, dict(zip(names, [int(x) for x in cnt]))
+
+    def rng_floats(self, state, n):
+        s = C.c_uint32(state)
+        vals = [self.lib.oracle_rng_float(C.byref(s)) for _ in range(n)]
+        return np.array(vals, np.float32), s.value
+
+    def unit_ball(self, state):
+        s = C.c_uint32(state)
+        out = (C.c_float * 3)()
+        self.lib.oracle_unit_ball(C.byref(s), out)
+        return np.array(list(out), np.float32), s.value
+
+
+_oracle = None
+
+
+def load():
+    global _oracle
+    if _oracle is None:
+        _oracle = Oracle(C.CDLL(build()))
+    return _oracle

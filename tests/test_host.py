@@ -1,0 +1,200 @@
+"""Host-side logic and the C-ABI surface -- runs without a GPU (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import bevyray_amd as brt
+from bevyray_amd import _lib
+from helpers import chain_bvh, make_buffers, median_split_bvh, single_leaf_bvh
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "bevyray_amd.h")).read()
+    declared = set(re.findall(r"\b(brt_[a-z0-9_]+)\s*\(", header))
+    declared -= {"brt_ctx", "brt_stats"}
+    assert len(declared) >= 16
+    lib = C.CDLL(_lib.build())
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/bevyray_amd.h but not exported"
+    assert declared == set(_lib.EXPORTS), "ctypes prototypes out of sync with the header"
+    assert _lib.load().brt_abi_version() == 1
+
+
+def test_wire_layouts_match_the_wgsl_structs():
+    # raytrace.wgsl:30-87 / extract.rs:56-237
+    assert brt.MODEL_DTYPE.itemsize == 32 and brt.MODEL_DTYPE.fields["radius"][1] == 12 and brt.MODEL_DTYPE.fields["material_id"][1] == 16
+    assert brt.MATERIAL_DTYPE.itemsize == 32 and brt.MATERIAL_DTYPE.fields["specular_transmission"][1] == 28
+    assert brt.BVH_NODE_DTYPE.itemsize == 48 and brt.BVH_NODE_DTYPE.fields["bounds_max"][1] == 16
+    assert brt.BVH_NODE_DTYPE.fields["index"][1] == 28 and brt.BVH_NODE_DTYPE.fields["model_count"][1] == 32
+    assert brt.CAMERA_DTYPE.itemsize == 80 and brt.CAMERA_DTYPE.fields["position"][1] == 32
+    assert brt.CAMERA_DTYPE.fields["direction"][1] == 48 and brt.CAMERA_DTYPE.fields["up"][1] == 64
+    assert brt.WINDOW_DTYPE.itemsize == 16 and brt.LEVEL_DTYPE.itemsize == 32
+    assert [int(x) for x in brt.Raytracing] == [0, 1, 2, 3]   # mod.rs:94-101
+
+
+def test_material_prepare_asset_decodes_srgb():
+    # extract.rs:201 base_color.to_linear(); values from SURVEY.md H4
+    want = {0.5: 0.21404114, 0.4: 0.13286832, 0.2: 0.033104766, 0.1: 0.010022826, 0.7: 0.44798842, 0.6: 0.31854677}
+    for srgb, lin in want.items():
+        m = brt.RaytraceMaterial.prepare_asset(brt.StandardMaterial(base_color=(srgb, srgb, srgb)))
+        assert np.allclose(m["base_color"][0], lin, rtol=2e-7, atol=0)
+    m = brt.RaytraceMaterial.prepare_asset(brt.StandardMaterial())[0]
+    assert tuple(m["base_color"]) == (1.0, 1.0, 1.0) and m["metallic"] == 0.0 and m["roughness"] == 0.5
+    assert m["reflectance"] == 0.5 and m["ior"] == 1.5 and m["specular_transmission"] == 0.0
+    m = brt.RaytraceMaterial.prepare_asset(brt.StandardMaterial(metallic=1.0, perceptual_roughness=0.25, ior=1.33, specular_transmission=1.0))[0]
+    assert m["metallic"] == 1.0 and m["roughness"] == 0.25 and m["ior"] == np.float32(1.33) and m["specular_transmission"] == 1.0
+
+
+def test_camera_extract_is_forward_and_up_of_looking_at():
+    cam = brt.RaytracedCamera(brt.Raytracing.FallbackRaytraced, 4, 4)   # main.rs:66-70
+    proj = brt.PerspectiveProjection(fov=0.4, aspect_ratio=16 / 9, near=0.1, far=1000.0)
+    lvl, c = brt.CameraExtract.extract_component(cam, brt.Transform((0, 0, 5), (0, 0, 0), (0, 1, 0)), proj)  # main.rs:57-58
+    c = c[0]
+    assert lvl["level"][0] == 2 and c["sample_count"] == 4 and c["bounce_count"] == 4 and c["projection"] == 0
+    assert np.allclose(c["direction"], [0, 0, -1]) and np.allclose(c["up"], [0, 1, 0]) and np.allclose(c["position"], [0, 0, 5])
+    assert c["fov"] == np.float32(0.4) and c["near"] == np.float32(0.1) and c["far"] == 1000.0
+    _, c2 = brt.CameraExtract.extract_component(cam, brt.Transform((13, 2, 3), (0, 0, 0), (0, 1, 0)), proj)
+    d, u = c2[0]["direction"].astype(np.float64), c2[0]["up"].astype(np.float64)
+    assert abs(np.linalg.norm(d) - 1) < 1e-6 and abs(np.linalg.norm(u) - 1) < 1e-6 and abs(d @ u) < 1e-6
+    assert np.allclose(d, -np.array([13, 2, 3]) / np.linalg.norm([13, 2, 3]), atol=1e-6)
+    # orthographic -> None (extract.rs:148); the node then skips the pass
+    assert brt.CameraExtract.extract_component(cam, brt.Transform(), brt.OrthographicProjection()) is None
+
+
+def test_window_extract():
+    w = brt.WindowExtract.extract_component(1080, 0.5)[0]
+    assert w["height"] == 1080 and w["random_seed"] == 0.5
+
+
+def _check_bvh_contract(models, bvh):
+    n = len(models)
+    assert len(bvh) == 2 * n - 1
+    seen_models = np.zeros(n, int)
+    seen_nodes = np.zeros(len(bvh), int)
+    stack = [0]
+    pos, rad = models["position"], models["radius"]
+    while stack:
+        i = stack.pop()
+        seen_nodes[i] += 1
+        nd = bvh[i]
+        if nd["model_count"] > 0:
+            assert nd["model_count"] == 1
+            m = int(nd["index"])
+            seen_models[m] += 1
+            # Model::aabb pads by 0.1 (extract.rs:220-227)
+            pad = rad[m] + np.float32(0.1)
+            assert np.array_equal(nd["bounds_min"], pos[m] - pad) and np.array_equal(nd["bounds_max"], pos[m] + pad)
+        else:
+            a, b = int(nd["index"]), int(nd["index"]) + 1
+            assert b < len(bvh)
+            for c in (a, b):
+                assert np.all(bvh[c]["bounds_min"] >= nd["bounds_min"]) and np.all(bvh[c]["bounds_max"] <= nd["bounds_max"])
+            stack += [a, b]
+    assert np.all(seen_models == 1) and np.all(seen_nodes == 1)
+
+
+@pytest.mark.parametrize("kind,count", [(brt.SCENE_COVER, None), (brt.SCENE_RTIOW_FINAL, None), (brt.SCENE_STRESS_GRID, 10004)])
+def test_scene_generators_and_ploc_contract(kind, count):
+    b = brt.generate_scene(kind, 1)
+    n = len(b.models)
+    if count is not None:
+        assert n == count
+    else:
+        assert 400 < n <= (23 * 22 + 4 if kind == brt.SCENE_COVER else 22 * 22 + 4)
+    assert np.array_equal(b.models["material_id"], np.arange(n))            # extract.rs:301-310
+    assert tuple(b.models[0]["position"]) == (0.0, -1000.0, 0.0) and b.models[0]["radius"] == 1000.0   # main.rs:96-100
+    assert np.all(b.models[1:-3]["radius"] == np.float32(0.2)) and np.all(b.models[-3:]["radius"] == 1.0)
+    assert [tuple(p) for p in b.models[-3:]["position"]] == [(0, 1, 0), (-4, 1, 0), (4, 1, 0)]           # main.rs:184-239
+    _check_bvh_contract(b.models, b.bvh)
+    depth = brt.validate_scene(b.models, b.materials, b.bvh)
+    assert depth < 31, "PLOC tree should stay well below the shader's 32-entry stack"
+    # deterministic in the seed, different across seeds
+    b2 = brt.generate_scene(kind, 1)
+    assert np.array_equal(b.models.view(np.uint8), b2.models.view(np.uint8)) and np.array_equal(b.bvh.view(np.uint8), b2.bvh.view(np.uint8))
+    b3 = brt.generate_scene(kind, 2)
+    assert not np.array_equal(b.models["position"][1:50], b3.models["position"][1:50])
+
+
+def test_cover_scene_material_lottery():
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    small = b.materials[1:-3]
+    metal = small["metallic"] == 1.0
+    glass = small["specular_transmission"] == 1.0
+    diffuse = ~metal & ~glass
+    n = len(small)
+    assert 0.7 < diffuse.sum() / n < 0.9 and 0.08 < metal.sum() / n < 0.22 and 0.01 < glass.sum() / n < 0.1   # main.rs:116,137,159
+    assert np.all(small["roughness"][diffuse] == 0.5) and np.all(small["roughness"][glass] == 0.5)        # defaults kept
+    assert np.all(small["ior"] == 1.5) and np.all(small["base_color"][glass] == 1.0)
+    # big metal: srgb (0.7,0.6,0.5), roughness 0 (main.rs:222-227)
+    assert np.allclose(b.materials[-1]["base_color"], [0.44798842, 0.31854677, 0.21404114], rtol=1e-6) and b.materials[-1]["roughness"] == 0.0
+    # skip rule main.rs:115
+    d = np.linalg.norm(b.models[1:-3]["position"] - np.array([4, 0.2, 0], np.float32), axis=1)
+    assert np.all(d > 0.9)
+
+
+def test_prepare_buffers_mirrors_extract_stage():
+    data = [((0.0, -1000.0, 0.0), brt.RaytracedSphere(1000.0), brt.StandardMaterial(base_color=(0.5, 0.5, 0.5))),
+            ((1.0, 0.2, 0.0), brt.RaytracedSphere(0.2), brt.StandardMaterial(metallic=1.0, perceptual_roughness=0.1)),
+            ((-1.0, 0.2, 0.5), brt.RaytracedSphere(0.2), brt.StandardMaterial(specular_transmission=1.0))]
+    b = brt.prepare_buffers(data)
+    assert len(b.models) == 3 and len(b.materials) == 3 and len(b.bvh) == 5
+    assert list(b.models["material_id"]) == [0, 1, 2] and b.bvh[0]["model_count"] == 0
+    _check_bvh_contract(b.models, b.bvh)
+    one = brt.prepare_buffers(data[:1])
+    assert len(one.bvh) == 1 and one.bvh[0]["model_count"] == 1 and one.bvh[0]["index"] == 0
+    assert len(brt.prepare_buffers([]).bvh) == 0
+
+
+def test_validate_rejects_malformed_input():
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    assert brt.validate_scene(b.models, b.materials, single_leaf_bvh(b.models)) == 0
+    assert brt.validate_scene(b.models, b.materials, median_split_bvh(b.models, 3)) >= 7
+    assert brt.validate_scene(b.models[:40], b.materials, chain_bvh(b.models[:40])) == 39
+
+    def rejected(models, materials, bvh, code):
+        with pytest.raises(brt.BrtError) as e:
+            brt.validate_scene(models, materials, bvh)
+        assert e.value.code == code, e.value
+
+    bad = b.bvh.copy(); bad[0]["index"] = len(bad) - 1          # child index+1 out of range
+    rejected(b.models, b.materials, bad, -4)
+    bad = b.bvh.copy(); bad[int(b.bvh[0]["index"])]["index"] = 0; bad[int(b.bvh[0]["index"])]["model_count"] = 0   # cycle to the root
+    rejected(b.models, b.materials, bad, -4)
+    leaf = int(np.flatnonzero(b.bvh["model_count"] > 0)[0])
+    bad = b.bvh.copy(); bad[leaf]["index"] = len(b.models)       # leaf range out of range
+    rejected(b.models, b.materials, bad, -4)
+    bad = b.bvh.copy(); bad[leaf]["model_count"] = 0xFFFFFFFF    # u32 overflow of index + count
+    rejected(b.models, b.materials, bad, -4)
+    badm = b.models.copy(); badm[7]["material_id"] = len(b.materials)
+    rejected(badm, b.materials, b.bvh, -5)
+    rejected(b.models[:0], b.materials, b.bvh, -6)               # empty scene: the reference skips the pass
+    rejected(b.models, b.materials, b.bvh[:0], -4)
+
+
+def test_tile_rows_and_strip_mapping():
+    from bevyray_amd.parallel import frame_rows_of_part
+    assert brt.tile_rows(1080, 1) == 1080 and brt.tile_rows(1080, 8) == 136 and brt.tile_rows(225, 2) == 120
+    assert brt.tile_rows(2160, 8) == 272 and brt.tile_rows(7, 3) == 8
+    for h, n in [(1080, 8), (225, 2), (36, 3), (7, 3), (64, 5)]:
+        seen = np.zeros(h, int)
+        for p in range(n):
+            rows = frame_rows_of_part(h, p, n)
+            assert len(rows) == brt.tile_rows(h, n)
+            valid = rows[rows >= 0]
+            seen[valid] += 1
+            assert np.all((valid // 8) % n == p)
+        assert np.all(seen == 1)
+
+
+def test_create_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(brt.BrtError) as e:
+        brt.RaytracePlugin([0])
+    assert e.value.code == -2 and "no CPU path" in e.value.text

@@ -1,0 +1,328 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle -- needs an MI355X.
+
+Bar: BIT-EXACT frames (compared as u32) and exactly equal ray counters.  The arithmetic is
+f32 with one numeric policy on both sides (no FMA contraction, correctly rounded sqrt/divide,
+minNum/maxNum), so nothing is left to a tolerance; north_star's "stated per-channel float
+tolerance" is therefore 0 here (TOL below), and any mismatch is a bug.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import bevyray_amd as brt
+from helpers import (GOLDEN, chain_bvh, fixture_buffers, make_buffers, median_split_bvh, single_leaf_bvh, sky_color,
+                     uniforms)
+
+pytestmark = pytest.mark.gpu
+
+TOL = 0.0   # per-channel absolute tolerance on the RGBA f32 output
+COUNTER_KEYS = ("rays", "node_pops", "interior_visits", "sphere_tests", "hits")
+DBG_MINMAX, DBG_SQRT_DIV, DBG_RNG, DBG_SLAB, DBG_SPHERE, DBG_SEED = range(6)
+
+
+def assert_frames_equal(got, want):
+    same = got.view(np.uint32) == want.view(np.uint32)
+    both_nan = np.isnan(got) & np.isnan(want)
+    bad = ~(same | both_nan)
+    if bad.any():
+        idx = np.argwhere(bad)[:5]
+        diff = np.nanmax(np.abs(got.astype(np.float64) - want.astype(np.float64)))
+        raise AssertionError(f"{bad.sum()} of {bad.size} values differ (max abs {diff:.3g}); first at {idx.tolist()}")
+    assert diff_max(got, want) <= TOL
+
+
+def diff_max(a, b):
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    d[np.isnan(a) & np.isnan(b)] = 0.0
+    return float(np.max(d)) if d.size else 0.0
+
+
+def render_both(plugin, oracle, b, lvl, cam, win, w, h, flags=brt.FLAG_COUNTERS, raster=None, depth=None):
+    got = plugin.node.run(lvl, cam, win, w, h, buffers=b, raster_rgba=raster, raster_depth=depth, flags=flags)
+    want, cnt = oracle.render(b, lvl, cam, win, w, h, raster_rgba=raster, raster_depth=depth)
+    assert_frames_equal(got, want)
+    stats = plugin.node.last_stats
+    assert stats["rays"] == cnt["rays"]
+    if flags & brt.FLAG_COUNTERS:
+        assert {k: stats[k] for k in COUNTER_KEYS} == cnt
+    return got, stats
+
+
+# ---- single functions -------------------------------------------
+
+def _inputs(cols):
+    a = np.zeros((len(cols[0]), 16), np.float32)
+    for i, c in enumerate(cols):
+        a[:, i] = c
+    return a
+
+
+def test_min_max_sqrt_divide_bitwise(plugin, oracle):
+    rng = np.random.default_rng(1)
+    n = 200000
+    a = rng.standard_normal(n).astype(np.float32) * np.float32(10.0) ** rng.integers(-20, 20, n).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32) * np.float32(10.0) ** rng.integers(-20, 20, n).astype(np.float32)
+    special = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 1.0, -1.0, 3.4028235e38, 1e-45, -1e-45, 1.1754944e-38], np.float32)
+    sa, sb = np.meshgrid(special, special)
+    a = np.concatenate([a, sa.ravel()]); b = np.concatenate([b, sb.ravel()])
+    out = plugin.debug_eval(DBG_MINMAX, _inputs([a, b]))
+    want_min = np.array([oracle.lib.oracle_min(float(x), float(y)) for x, y in zip(a[-121:], b[-121:])], np.float32)
+    want_max = np.array([oracle.lib.oracle_max(float(x), float(y)) for x, y in zip(a[-121:], b[-121:])], np.float32)
+    assert_frames_equal(out[-121:, 0], want_min)
+    assert_frames_equal(out[-121:, 1], want_max)
+    assert_frames_equal(out[:n, 0], np.minimum(a[:n], b[:n]))
+    assert_frames_equal(out[:n, 1], np.maximum(a[:n], b[:n]))
+    # sqrt / divide: correctly rounded, denormals kept (numpy on x86 SSE is IEEE-exact)
+    out = plugin.debug_eval(DBG_SQRT_DIV, _inputs([np.abs(a), b]))
+    with np.errstate(all="ignore"):
+        assert_frames_equal(out[:, 0], np.sqrt(np.abs(a)))
+        assert_frames_equal(out[:, 1], np.abs(a) / b)
+
+
+def test_rng_seed_and_unit_ball_bitwise(plugin, oracle):
+    kat = json.load(open(os.path.join(GOLDEN, "rng_kat.json")))
+    starts = np.array([c["start"] for c in kat["chains"]], np.uint32)
+    out = plugin.debug_eval(DBG_RNG, _inputs([starts.view(np.float32)]))
+    for i, c in enumerate(kat["chains"]):
+        assert out[i, 0] == np.float32(c["floats"][0]) and out[i, 1].view(np.uint32) == c["states"][0]
+        ball, end = oracle.unit_ball(c["states"][0])
+        assert np.array_equal(out[i, 2:5], ball) and out[i, 5].view(np.uint32) == end
+    s = kat["seeds"]
+    inp = _inputs([np.array([x[k] for x in s], np.float32) for k in ("random_seed", "px", "py", "w", "h")])
+    out = plugin.debug_eval(DBG_SEED, inp)
+    assert [int(x) for x in out[:, 0].view(np.uint32)] == [x["seed"] for x in s]
+    # the rejection sampler over many states
+    rng = np.random.default_rng(3)
+    states = rng.integers(0, 2**32, 5000, dtype=np.uint64).astype(np.uint32)
+    out = plugin.debug_eval(DBG_RNG, _inputs([states.view(np.float32)]))
+    for i in range(0, 5000, 37):
+        f, s1 = oracle.rng_floats(int(states[i]), 1)
+        ball, s2 = oracle.unit_ball(s1)
+        assert out[i, 0] == f[0] and np.array_equal(out[i, 2:5], ball) and out[i, 5].view(np.uint32) == s2
+
+
+def test_slab_and_sphere_tests_bitwise(plugin, oracle):
+    import ctypes as C
+    rng = np.random.default_rng(4)
+    n = 4000
+    o = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    d = rng.standard_normal((n, 3)).astype(np.float32)
+    d[::7, 0] = 0.0; d[::11, 1] = -0.0; d[::13] *= np.float32(1e-3)
+    lo = rng.uniform(-4, 2, (n, 3)).astype(np.float32)
+    hi = lo + rng.uniform(0, 3, (n, 3)).astype(np.float32)
+    o[::17, 0] = lo[::17, 0]; o[::19, 1] = hi[::19, 1]          # origin on a slab plane, incl. with d == 0
+    closest = np.where(rng.random(n) < 0.3, np.float32(3.40282347e+38), rng.uniform(0, 5, n)).astype(np.float32)
+    inp = np.zeros((n, 16), np.float32)
+    inp[:, 0:3], inp[:, 3:6], inp[:, 6:9], inp[:, 9:12], inp[:, 12] = o, d, lo, hi, closest
+    out = plugin.debug_eval(DBG_SLAB, inp)
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+    INF = np.float32(3.40282347e+38)
+    for i in range(n):
+        dst = np.float32(oracle.lib.oracle_ray_bounding_dst(f3(o[i]), f3(d[i]), f3(lo[i]), f3(hi[i])))
+        assert out[i, 0] == (1.0 if (dst != INF and dst < closest[i]) else 0.0), i
+    c = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    r = rng.uniform(0.05, 2.0, n).astype(np.float32)
+    inp = np.zeros((n, 16), np.float32)
+    inp[:, 0:3], inp[:, 3:6], inp[:, 6:9], inp[:, 9] = o, d, c, r
+    out = plugin.debug_eval(DBG_SPHERE, inp)
+    for i in range(n):
+        t = np.float32(oracle.lib.oracle_hit_sphere(f3(o[i]), f3(d[i]), f3(c[i]), float(r[i])))
+        want = t if (t != np.float32(-1.0) and t > np.float32(0.001)) else INF
+        assert out[i, 0].view(np.uint32) == np.float32(want).view(np.uint32), i
+
+
+# ---- frames --------------------------------------------------------------------------------------------
+
+def test_golden_cover_fixture(plugin, oracle):
+    b, lvl, cam, win, frame, counters = fixture_buffers()
+    got = plugin.node.run(lvl, cam, win, 64, 36, buffers=b, flags=brt.FLAG_COUNTERS)
+    assert_frames_equal(got, frame)
+    assert [plugin.node.last_stats[k] for k in COUNTER_KEYS] == counters
+
+
+@pytest.mark.parametrize("seed", [0.0, 0.25, 0.5, 0.999])
+def test_config1_cover_400x225_1spp_4bounces(plugin, oracle, seed):
+    # BASELINE.json configs[0]: the reference's own CPU-runnable case
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    lvl, cam, win = brt.cover_camera(400, 225, 1, 4, brt.Raytracing.Pure, seed)
+    _, stats = render_both(plugin, oracle, b, lvl, cam, win, 400, 225)
+    assert stats["scene_in_lds"] == 1 and stats["paths"] == 400 * 225
+
+
+@pytest.mark.parametrize("kind,w,h,spp,bounces", [
+    (brt.SCENE_COVER, 192, 108, 8, 8),          # configs[1] shape, reduced size
+    (brt.SCENE_RTIOW_FINAL, 160, 90, 4, 50),    # configs[2] shape: 50 bounces
+    (brt.SCENE_STRESS_GRID, 160, 90, 4, 8),     # configs[4]: 10k spheres, scene NOT LDS resident
+    (brt.SCENE_COVER, 61, 35, 3, 2),            # ragged: neither dimension a multiple of 8
+    (brt.SCENE_COVER, 1, 1, 5, 3),
+])
+def test_scenes_match_oracle(plugin, oracle, kind, w, h, spp, bounces):
+    b = brt.generate_scene(kind, 1)
+    lvl, cam, win = brt.cover_camera(w, h, spp, bounces)
+    _, stats = render_both(plugin, oracle, b, lvl, cam, win, w, h)
+    assert stats["scene_in_lds"] == (0 if kind == brt.SCENE_STRESS_GRID else 1)
+    # timing build (no counters) gives the same pixels and ray count
+    render_both(plugin, oracle, b, lvl, cam, win, w, h, flags=0)
+
+
+def test_bringup_kernel_matches_oracle(plugin, oracle):
+    b = brt.generate_scene(brt.SCENE_COVER, 3)
+    lvl, cam, win = brt.cover_camera(96, 54, 4, 6, brt.Raytracing.Pure, 0.25)
+    render_both(plugin, oracle, b, lvl, cam, win, 96, 54, flags=brt.FLAG_COUNTERS | brt.FLAG_KERNEL_SIMPLE)
+
+
+def test_hand_made_bvh_topologies(plugin, oracle):
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    lvl, cam, win = brt.cover_camera(64, 36, 2, 4)
+    ref, _ = render_both(plugin, oracle, b, lvl, cam, win, 64, 36)
+    for bvh in (single_leaf_bvh(b.models), median_split_bvh(b.models, 3), median_split_bvh(b.models, 1)):
+        bb = brt.Buffers(b.models, b.materials, bvh)
+        got, _ = render_both(plugin, oracle, bb, lvl, cam, win, 64, 36)
+        assert_frames_equal(got, ref)          # pixels do not depend on the topology
+    # callee-built BVH (bvh = None -> native PLOC inside brt_upload_scene)
+    got = plugin.node.run(lvl, cam, win, 64, 36, buffers=brt.Buffers(b.models, b.materials, None))
+    assert_frames_equal(got, ref)
+
+
+def test_stack_overflow_rule(plugin, oracle):
+    # raytrace.wgsl:320: a 40-deep caterpillar overflows the 32-entry stack and drops subtrees
+    data = [((0.0, 0.0, -5.0 - i), 0.5, brt.StandardMaterial(base_color=(0.8, 0.3, 0.3))) for i in range(40)]
+    for n in (40, 33, 32, 31, 30, 28):
+        deep = make_buffers(data[:n], chain_bvh)
+        lvl, cam, win = uniforms(32, 32, spp=2, bounces=3, pos=(0, 0, 0), target=(0, 0, -1), fov=0.3, seed=0.5)
+        got, _ = render_both(plugin, oracle, deep, lvl, cam, win, 32, 32)
+        flat = make_buffers(data[:n], single_leaf_bvh)
+        want_flat, _ = oracle.render(flat, lvl, cam, win, 32, 32)
+        if n <= 31:
+            assert_frames_equal(got, want_flat)
+        else:
+            assert not np.array_equal(got, want_flat)   # the overflow is visible
+
+
+def test_analytic_cases(plugin, oracle):
+    b = make_buffers([((0, 0, 50), 0.5, brt.StandardMaterial())], single_leaf_bvh)
+    lvl, cam, win = uniforms(16, 9, spp=2, bounces=3, pos=(0, 0, 0), target=(0, 0, -1), fov=0.8, seed=0.0)
+    got = plugin.node.run(lvl, cam, win, 16, 9, buffers=b)
+    assert np.array_equal(got[..., :3], sky_color(oracle, cam, win, 16, 9, 2)) and np.all(got[..., 3] == 1.0)
+    # zero samples -> NaN colour, alpha 1 (raytrace.wgsl:169)
+    lvl, cam, win = uniforms(8, 8, spp=0, bounces=2, pos=(0, 0, 0), target=(0, 0, -1), fov=0.5, seed=0.5)
+    got, stats = render_both(plugin, oracle, b, lvl, cam, win, 8, 8)
+    assert np.all(np.isnan(got[..., :3])) and stats["rays"] == 0
+    # zero bounces on a diffuse hit -> black
+    wall = make_buffers([((0, 0, -3), 100.0, brt.StandardMaterial(perceptual_roughness=0.0))], single_leaf_bvh)
+    lvl, cam, win = uniforms(8, 8, spp=4, bounces=0, pos=(0, 0, 200), target=(0, 0, -3), fov=0.2, seed=0.5)
+    got, _ = render_both(plugin, oracle, wall, lvl, cam, win, 8, 8)
+    assert np.all(got[..., :3] == 0.0)
+    # materials: all-metal, all-glass (ior below and above 1), rough metal
+    for mat in (brt.StandardMaterial(metallic=1.0, perceptual_roughness=0.0), brt.StandardMaterial(metallic=1.0, perceptual_roughness=0.9),
+                brt.StandardMaterial(specular_transmission=1.0, ior=1.5), brt.StandardMaterial(specular_transmission=1.0, ior=0.6),
+                brt.StandardMaterial(metallic=0.5, specular_transmission=0.5, base_color=(0.9, 0.5, 0.2))):
+        data = [((0, -100.5, -1), 100.0, brt.StandardMaterial(base_color=(0.5, 0.5, 0.5))), ((0, 0, -1), 0.5, mat),
+                ((-1.0, 0, -1), 0.5, mat), ((1.0, 0, -1.2), 0.5, brt.StandardMaterial(base_color=(0.2, 0.3, 0.8)))]
+        bb = make_buffers(data)
+        lvl, cam, win = uniforms(48, 27, spp=6, bounces=10, pos=(0, 0.3, 1.5), target=(0, 0, -1), fov=0.9, seed=0.37)
+        render_both(plugin, oracle, bb, lvl, cam, win, 48, 27)
+
+
+def test_levels_with_raster_inputs(plugin, oracle):
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    w, h = 40, 24
+    rng = np.random.default_rng(5)
+    raster = rng.random((h, w, 4), dtype=np.float32)
+    depth = rng.random((h, w), dtype=np.float32) * np.float32(0.02)
+    depth[0, :] = 0.0
+    for level in brt.Raytracing:
+        lvl, cam, win = brt.cover_camera(w, h, 2, 3, level, 0.5)
+        got = plugin.node.run(lvl, cam, win, w, h, buffers=b, raster_rgba=raster, raster_depth=depth)
+        want, _ = oracle.render(b, lvl, cam, win, w, h, raster_rgba=raster, raster_depth=depth)
+        assert_frames_equal(got, want)
+        got = plugin.node.run(lvl, cam, win, w, h)     # no raster inputs: cleared to 0
+        want, _ = oracle.render(b, lvl, cam, win, w, h)
+        assert_frames_equal(got, want)
+
+
+def test_window_height_differs_from_target_height(plugin, oracle):
+    # raytrace.wgsl:141-142: the jitter uses window.height, not the render target's size
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    lvl, cam, win = uniforms(64, 40, spp=3, bounces=3, pos=(13, 2, 3), target=(0, 0, 0), fov=0.4, seed=0.5, window_height=720)
+    render_both(plugin, oracle, b, lvl, cam, win, 64, 40)
+
+
+# ---- errors: the node skips the pass (pipeline.rs:82-151) ---------------------------------------------
+
+def test_error_behaviour(plugin):
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    lvl, cam, win = brt.cover_camera(32, 18, 1, 1)
+    assert plugin.node.run(None, None, None, 32, 18) is None
+    assert plugin.node.run(lvl, cam, win, 32, 18, buffers=brt.Buffers(b.models[:0], b.materials, b.bvh)) is None   # empty -> skip
+    bad = b.bvh.copy(); bad[0]["index"] = len(bad)
+    with pytest.raises(brt.BrtError) as e:
+        plugin.node.run(lvl, cam, win, 32, 18, buffers=brt.Buffers(b.models, b.materials, bad))
+    assert e.value.code == -4
+    with pytest.raises(brt.BrtError) as e:      # failed upload leaves no scene behind
+        plugin.node.run(lvl, cam, win, 32, 18)
+    assert e.value.code == -7
+    ortho = cam.copy(); ortho["projection"] = 1
+    plugin.node.write_buffers(b)
+    with pytest.raises(brt.BrtError) as e:
+        plugin.node.run(lvl, ortho, win, 32, 18)
+    assert e.value.code == -8
+    with pytest.raises(brt.BrtError):
+        plugin.node.run(lvl, cam, win, 0, 18)
+
+
+# ---- strips / devices ---------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n_parts", [2, 3, 8])
+def test_parts_assemble_to_the_full_frame(plugin, oracle, n_parts):
+    import torch
+    from bevyray_amd.parallel import frame_rows_of_part
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    w, h = 72, 45
+    lvl, cam, win = brt.cover_camera(w, h, 2, 4)
+    full = plugin.node.run(lvl, cam, win, w, h, buffers=b)
+    rows = brt.tile_rows(h, n_parts)
+    tiles = torch.zeros((n_parts, rows, w, 4), dtype=torch.float32, device="cuda")
+    total_rays = 0
+    for p in range(n_parts):
+        st = plugin.node.render_part_device(lvl, cam, win, w, h, p, n_parts, tiles[p].data_ptr())
+        total_rays += st["rays"]
+        t = tiles[p].cpu().numpy()
+        fr = frame_rows_of_part(h, p, n_parts)
+        assert_frames_equal(t[fr >= 0], full[fr[fr >= 0]])
+    assert total_rays == plugin.node.last_stats["rays"]
+    frame = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    plugin.node.deinterleave_device(tiles.data_ptr(), n_parts, w, h, frame.data_ptr())
+    torch.cuda.synchronize()
+    assert_frames_equal(frame.cpu().numpy(), full)
+
+
+def test_multi_device_context_on_one_gpu(oracle):
+    # brt_create([0, 0, 0]): three sub-contexts on the same GPU exercise the strip split + copy-out
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    lvl, cam, win = brt.cover_camera(80, 50, 2, 4)
+    with brt.RaytracePlugin([0, 0, 0]) as p3:
+        got = p3.node.run(lvl, cam, win, 80, 50, buffers=b, flags=brt.FLAG_COUNTERS)
+        want, cnt = oracle.render(b, lvl, cam, win, 80, 50)
+        assert_frames_equal(got, want)
+        assert {k: p3.node.last_stats[k] for k in COUNTER_KEYS} == cnt
+
+
+# ---- BASELINE.json full size: size-independent properties + sampled rows --------------------------------------
+
+def test_config2_full_size_properties(plugin, oracle):
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    w, h, spp, bounces = 1920, 1080, 64, 8
+    lvl, cam, win = brt.cover_camera(w, h, spp, bounces)
+    f1 = plugin.node.run(lvl, cam, win, w, h, buffers=b)
+    s1 = dict(plugin.node.last_stats)
+    f2 = plugin.node.run(lvl, cam, win, w, h)
+    assert np.array_equal(f1.view(np.uint32), f2.view(np.uint32)) and plugin.node.last_stats["rays"] == s1["rays"]   # idempotent
+    assert s1["paths"] == w * h * spp and w * h * spp <= s1["rays"] <= w * h * spp * (bounces + 1)
+    assert np.all(f1[..., 3] == 1.0) and np.all(np.isfinite(f1)) and f1[..., :3].min() >= 0.0 and f1[..., :3].max() <= 1.0
+    # 12 rows spread over the frame against the oracle, bit for bit
+    for r0 in (0, 405, 700, 1076):
+        want, _ = oracle.render(b, lvl, cam, win, w, h, rows=(r0, r0 + 3))
+        assert_frames_equal(f1[r0:r0 + 3], want[r0:r0 + 3])
