@@ -77,12 +77,28 @@ _PROTOTYPES = {
 EXPORTS = tuple(_PROTOTYPES)
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7, the same
+    SONAME this library links against from /opt/rocm).  Two HIP runtimes in one process cannot
+    both own the GPU ("No HIP GPUs are available"), and the dynamic loader shares by SONAME only
+    with whatever was loaded FIRST.  So when torch is installed it is imported before
+    libbevyray_amd.so is opened; both then run on torch's copy.  Processes without torch (the
+    Rust/C++ hosts) simply get /opt/rocm's runtime.  BRT_NO_TORCH=1 skips this."""
+    import importlib.util
+    import sys
+    if os.environ.get("BRT_NO_TORCH") == "1" or "torch" in sys.modules:
+        return
+    if importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
+
+
 def load() -> C.CDLL:
     """Load (building first if needed) the shared library and declare every prototype."""
     global _lib
     if _lib is not None:
         return _lib
     build()
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly

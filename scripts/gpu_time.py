@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Quick timing of the trace kernel on one GPU (development aid; bench.py is the contract)."""
+import argparse
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bevyray_amd as brt
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scene", type=int, default=0)
+ap.add_argument("--w", type=int, default=1920)
+ap.add_argument("--h", type=int, default=1080)
+ap.add_argument("--spp", type=int, default=64)
+ap.add_argument("--bounces", type=int, default=8)
+ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--flags", type=int, default=0)
+a = ap.parse_args()
+b = brt.generate_scene(a.scene, 1)
+lvl, cam, win = brt.cover_camera(a.w, a.h, a.spp, a.bounces)
+with brt.RaytracePlugin([0]) as p:
+    p.node.write_buffers(b)
+    for i in range(a.reps):
+        f = p.node.run(lvl, cam, win, a.w, a.h, flags=a.flags)
+        s = p.node.last_stats
+        print(f"rep {i}: kernel {s['kernel_ms']:.2f} ms  rays {s['rays']}  {s['rays']/s['kernel_ms']/1e3:.1f} Mrays/s  "
+              f"lds {s['lds_bytes']} in_lds {s['scene_in_lds']} grid {s['n_workgroups']}x{s['threads_per_workgroup']} total {s['total_ms']:.1f} ms", flush=True)
+    p.node.run(lvl, cam, win, a.w, a.h, flags=1)
+    print({k: v for k, v in p.node.last_stats.items()})
