@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s on the README cover scene at 1920x1080, 64 spp, 8 bounces
+(BASELINE.json metric, configs[1]).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one full frame: every rank traces its interleaved row strips with the persistent HIP
+kernel (scene already resident in HBM), the tiles meet on rank 0 in ONE gather over RCCL, and
+rank 0 de-interleaves.  The frame is fixed while N grows, so scaling is "strong".
+Rank 0 prints one JSON line.  `value` = rays of all ranks / max-over-ranks wall time of the K
+timed steps.  `roofline.achieved` = algorithmic bytes of one launch (SURVEY.md 8(d) formula,
+from exact device counters collected OUTSIDE the timed region) / the trace kernel's mean
+launch duration, measured with HIP events on the kernel's own stream inside the timed steps.
+`cpu_baseline` = the C oracle (a port, not the reference: the reference cannot be built here)
+on this host's cores over a bounded, evenly spread row sample of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+WORKLOAD = dict(width=1920, height=1080, spp=64, bounces=8, scene_seed=1, random_seed=0.5)
+
+
+def bytes_alg(stats, width, rows):
+    """what an uncached machine would move for this launch."""
+    return (stats["rays"] * 96 + stats["node_pops"] * 48 + stats["interior_visits"] * 96 +
+            stats["sphere_tests"] * 32 + stats["hits"] * 32 + width * rows * 16)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time target of the CPU baseline sample")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import numpy as np
+    import bevyray_amd as brt
+    from bevyray_amd.parallel import frame_rows_of_part, gather_frame
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    W, H, spp, bounces = WORKLOAD["width"], WORKLOAD["height"], WORKLOAD["spp"], WORKLOAD["bounces"]
+    buffers = brt.generate_scene(brt.SCENE_COVER, WORKLOAD["scene_seed"])
+    lvl, cam, win = brt.cover_camera(W, H, spp, bounces, brt.Raytracing.Pure, WORKLOAD["random_seed"])
+
+    plugin = brt.RaytracePlugin([local_rank])
+    node = plugin.node
+    node.write_buffers(buffers)             # scene resident in HBM before anything is timed
+    rows = brt.tile_rows(H, world)
+    tile = torch.zeros((rows, W, 4), dtype=torch.float32, device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(flags=0):
+        st = node.render_part_device(lvl, cam, win, W, H, rank, world, tile.data_ptr(), flags=flags)  # synchronous
+        frame = gather_frame(tile, H, rank, world, node=node)
+        return st, frame
+
+    # exact counters for the algorithmic-bytes figure (deterministic; outside the timed region)
+    counted, frame = step(brt.FLAG_COUNTERS)
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    rays = 0
+    for _ in range(args.steps):
+        st, frame = step()
+        kernel_ms.append(st["kernel_ms"])
+        rays += st["rays"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    r = torch.tensor([float(rays)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+    elapsed, total_rays = float(t.item()), float(r.item())
+
+    if rank == 0:
+        my_rows = int((frame_rows_of_part(H, 0, world) >= 0).sum())
+        alg = bytes_alg(counted, W, my_rows)
+        mean_kernel_ms = float(np.mean(kernel_ms))
+        achieved = alg / (mean_kernel_ms * 1e-3) / 1e9
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path))
+                if pmc.get("n_gpus") == world and pmc.get("workload") == "cover_1920x1080_64spp_8b":
+                    traffic = pmc.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s at 1920x1080, 64 spp, 8 bounces", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "README cover scene 1920x1080, 64 spp, 8 bounces (BASELINE.json configs[1])",
+                       "spheres": int(len(buffers.models)), "bvh_nodes": int(len(buffers.bvh)), "scene_seed": WORKLOAD["scene_seed"],
+                       "random_seed": WORKLOAD["random_seed"], "level": "Pure",
+                       "parallelism": f"interleaved 8-row strips over {world} GPU(s), one RCCL gather per frame"},
+            "rays_per_frame": total_rays / args.steps, "paths_per_frame": W * H * spp,
+            "mpaths_per_s": W * H * spp * args.steps / elapsed / 1e6,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_trace_persistent", "kernel_ms": mean_kernel_ms, "algorithmic_bytes_per_launch": alg,
+                         "note": "scene is LDS resident: the kernel is VALU/LDS-latency bound, HBM traffic is the "
+                                 "scene load per workgroup + one 16-B store per pixel"},
+            "kernel": {"lds_bytes": counted["lds_bytes"], "scene_in_lds": counted["scene_in_lds"],
+                       "workgroups": counted["n_workgroups"], "threads": counted["threads_per_workgroup"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(buffers, lvl, cam, win, W, H, frame, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    plugin.close()
+
+
+def cpu_baseline(buffers, lvl, cam, win, W, H, gpu_frame, target_seconds):
+    """The C oracle on this host's cores over every `row_step`-th row of the same frame; also
+    checks those rows of the GPU frame bit for bit (the oracle as checker, never as product)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_loader
+    oracle = oracle_loader.load()
+    cores = os.cpu_count() or 1
+    probe_rows = list(range(3, H, max(1, H // 8)))[:8]
+    t0 = time.perf_counter()
+    _, cnt = oracle.render(buffers, lvl, cam, win, W, H, rows=(3, H), row_step=max(1, H // 8), threads=cores)
+    probe = max(time.perf_counter() - t0, 1e-3)
+    per_row = probe / max(1, len(probe_rows))
+    n_rows = int(max(8, min(H, target_seconds / per_row)))
+    row_step = max(1, H // n_rows)
+    t0 = time.perf_counter()
+    frame, cnt = oracle.render(buffers, lvl, cam, win, W, H, rows=(0, H), row_step=row_step, threads=cores)
+    dt = time.perf_counter() - t0
+    sampled = np.arange(0, H, row_step)
+    g = gpu_frame.cpu().numpy()
+    exact = bool(np.array_equal(g[sampled].view(np.uint32), frame[sampled].view(np.uint32)))
+    return {"value": cnt["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"every {row_step}th row of the same 1920x1080x64spp frame ({len(sampled)} rows, {cnt['rays']} rays, "
+                      f"{dt:.1f} s wall on {cores} threads); scalar C restatement of the WGSL loop (no Rust toolchain here)",
+            "gpu_rows_bit_exact": exact}
+
+
+if __name__ == "__main__":
+    main()

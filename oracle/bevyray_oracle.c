@@ -445,7 +445,7 @@ float oracle_tan_half_fov(float fov) { return (float)tan((double)(fov * 0.5f)); 
 
 typedef struct {
     const Scene* s;
-    uint32_t W, H, row_begin, row_end;
+    uint32_t W, H, row_begin, row_end, row_step;
     const float* raster_rgba; const float* raster_depth;
     float* out_rgba;
     uint32_t* next_row;     /* shared work counter */
@@ -457,7 +457,8 @@ static void* worker(void* arg) {
     Job* j = (Job*)arg;
     for (;;) {
         pthread_mutex_lock(j->mu);
-        uint32_t row = (*j->next_row)++;
+        uint32_t row = *j->next_row;
+        *j->next_row = row + j->row_step;
         pthread_mutex_unlock(j->mu);
         if (row >= j->row_end) break;
         for (uint32_t px = 0; px < j->W; px++)
@@ -467,12 +468,12 @@ static void* worker(void* arg) {
     return NULL;
 }
 
-int oracle_render(const void* models, uint32_t n_models, const void* materials, uint32_t n_materials,
-                  const void* bvh_nodes, uint32_t n_nodes, const void* camera80, const void* window16,
-                  uint32_t level, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end,
-                  const float* raster_rgba, const float* raster_depth, float* out_rgba,
-                  uint64_t* counters5, int n_threads) {
-    if (!camera80 || !window16 || !out_rgba) return -1;
+int oracle_render_strided(const void* models, uint32_t n_models, const void* materials, uint32_t n_materials,
+                          const void* bvh_nodes, uint32_t n_nodes, const void* camera80, const void* window16,
+                          uint32_t level, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end,
+                          uint32_t row_step, const float* raster_rgba, const float* raster_depth, float* out_rgba,
+                          uint64_t* counters5, int n_threads) {
+    if (!camera80 || !window16 || !out_rgba || row_step == 0) return -1;
     if (n_nodes == 0 || !bvh_nodes) return -2;
     if (row_end > height) row_end = height;
     Scene s;
@@ -492,7 +493,7 @@ int oracle_render(const void* models, uint32_t n_models, const void* materials, 
     pthread_t* th = (pthread_t*)calloc((size_t)n_threads, sizeof(pthread_t));
     for (int i = 0; i < n_threads; i++) {
         jobs[i].s = &s; jobs[i].W = width; jobs[i].H = height;
-        jobs[i].row_begin = row_begin; jobs[i].row_end = row_end;
+        jobs[i].row_begin = row_begin; jobs[i].row_end = row_end; jobs[i].row_step = row_step;
         jobs[i].raster_rgba = raster_rgba; jobs[i].raster_depth = raster_depth;
         jobs[i].out_rgba = out_rgba; jobs[i].next_row = &next_row; jobs[i].mu = &mu;
     }
@@ -511,6 +512,16 @@ int oracle_render(const void* models, uint32_t n_models, const void* materials, 
     }
     free(jobs); free(th);
     return 0;
+}
+
+int oracle_render(const void* models, uint32_t n_models, const void* materials, uint32_t n_materials,
+                  const void* bvh_nodes, uint32_t n_nodes, const void* camera80, const void* window16,
+                  uint32_t level, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end,
+                  const float* raster_rgba, const float* raster_depth, float* out_rgba,
+                  uint64_t* counters5, int n_threads) {
+    return oracle_render_strided(models, n_models, materials, n_materials, bvh_nodes, n_nodes, camera80, window16, level,
+                                 width, height, row_begin, row_end, 1u, raster_rgba, raster_depth, out_rgba, counters5,
+                                 n_threads);
 }
 
 /* Small probes so tests can pin individual functions against the numpy mirror. */

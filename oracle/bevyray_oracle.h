@@ -19,6 +19,13 @@ int oracle_render(const void* models, uint32_t n_models, const void* materials, 
                   const float* raster_rgba, const float* raster_depth, float* out_rgba,
                   uint64_t* counters5, int n_threads);
 
+/* Same, but only rows row_begin, row_begin+row_step, ... < row_end (an evenly spread sample). */
+int oracle_render_strided(const void* models, uint32_t n_models, const void* materials, uint32_t n_materials,
+                          const void* bvh_nodes, uint32_t n_nodes, const void* camera80, const void* window16,
+                          uint32_t level, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end,
+                          uint32_t row_step, const float* raster_rgba, const float* raster_depth, float* out_rgba,
+                          uint64_t* counters5, int n_threads);
+
 float oracle_tan_half_fov(float fov);
 uint32_t oracle_rng_next(uint32_t state);
 float oracle_rng_float(uint32_t* state);

@@ -27,6 +27,9 @@ class Oracle:
         VP, U32, F = C.c_void_p, C.c_uint32, C.c_float
         lib.oracle_render.restype = C.c_int
         lib.oracle_render.argtypes = [VP, U32, VP, U32, VP, U32, VP, VP, U32, U32, U32, U32, U32, VP, VP, VP, VP, C.c_int]
+        lib.oracle_render_strided.restype = C.c_int
+        lib.oracle_render_strided.argtypes = [VP, U32, VP, U32, VP, U32, VP, VP, U32, U32, U32, U32, U32, U32, VP, VP, VP, VP,
+                                              C.c_int]
         lib.oracle_tan_half_fov.restype = F
         lib.oracle_tan_half_fov.argtypes = [F]
         lib.oracle_rng_next.restype = U32
@@ -50,8 +53,8 @@ class Oracle:
                                        C.POINTER(C.c_int)]
 
     def render(self, buffers, level, camera, window, width, height, raster_rgba=None, raster_depth=None,
-               rows=None, threads=None):
-        """Full frame (or rows [r0,r1)) -> (frame (H,W,4) f32, counters dict)."""
+               rows=None, threads=None, row_step=1):
+        """Full frame (or rows r0, r0+row_step, ... < r1) -> (frame (H,W,4) f32, counters dict)."""
         models = np.ascontiguousarray(buffers.models)
         materials = np.ascontiguousarray(buffers.materials)
         bvh = np.ascontiguousarray(buffers.bvh)
@@ -62,9 +65,9 @@ class Oracle:
         rd = None if raster_depth is None else np.ascontiguousarray(raster_depth, np.float32)
         if threads is None:
             threads = os.cpu_count() or 1
-        rc = self.lib.oracle_render(models.ctypes.data, len(models), materials.ctypes.data, len(materials),
+        rc = self.lib.oracle_render_strided(models.ctypes.data, len(models), materials.ctypes.data, len(materials),
                                     bvh.ctypes.data, len(bvh), camera.ctypes.data, window.ctypes.data,
-                                    int(level["level"][0]), width, height, r0, r1,
+                                    int(level["level"][0]), width, height, r0, r1, row_step,
                                     None if rr is None else rr.ctypes.data, None if rd is None else rd.ctypes.data,
                                     out.ctypes.data, cnt, threads)
         if rc != 0:
