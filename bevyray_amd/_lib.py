@@ -67,6 +67,7 @@ _PROTOTYPES = {
     "brt_tile_rows": (_U32, [_U32, _U32]),
     "brt_deinterleave_device": (_I32, [_VP, _VP, _U32, _U32, _U32, _VP, _VP]),
     "brt_debug_eval": (_I32, [_VP, _U32, _VP, _VP, _U32]),
+    "brt_debug_profile": (_I32, [_VP, C.POINTER(C.c_uint64)]),
     "brt_build_bvh": (_I32, [_VP, _U32, _VP, _U32, C.POINTER(_U32)]),
     "brt_validate_scene": (_I32, [_VP, _U32, _VP, _U32, _VP, _U32, C.POINTER(_U32)]),
     "brt_scene_generate": (_I32, [_U32, C.c_uint64, _VP, _VP, _U32, C.POINTER(_U32)]),

@@ -29,7 +29,7 @@ struct DeviceCtx {
     char* d_scene = nullptr;
     size_t scene_cap = 0;
     DeviceSceneView view{};
-    // small control block: 5 x u64 counters @0, queue counter @48
+    // control block: 32 x u64 counters @0 (5 stats + section profile @8..23), queue counter @256
     char* d_ctrl = nullptr;
     // frame-sized buffers owned by the context (brt_render)
     float* d_tile = nullptr;
@@ -139,25 +139,34 @@ int32_t make_frame_params(brt_ctx* ctx, const void* camera80, const void* window
 
 struct LaunchPlan {
     bool lds_scene;
-    uint32_t block, grid;
+    uint32_t block, grid, wg_per_cu;
     size_t lds_bytes;
 };
 
+// Choose the kernel variant and grid.  The scene (pair records, spheres, material ids) goes to
+// LDS when it fits; the 32-byte materials stay in global memory (read once per hit; measured:
+// no difference).  Measured on the cover scene: the kernel is instruction-issue
+// bound, so occupancy beyond 4 waves/SIMD buys little; 3 x 512 threads (6 waves/SIMD) is the
+// best by a few percent.  BRT_FORCE_GLOBAL_SCENE / BRT_BLOCK_THREADS / BRT_WG_PER_CU override.
 LaunchPlan plan_launch(const DeviceCtx& dc, const FrameParams& fp) {
     LaunchPlan lp{};
     const bool force_global = env_u32("BRT_FORCE_GLOBAL_SCENE", 0) != 0;
     const uint32_t block_env = env_u32("BRT_BLOCK_THREADS", 0);
-    const uint32_t blocks[3] = {1024u, 512u, 256u};
+    const uint32_t wg_env = env_u32("BRT_WG_PER_CU", 0);
+    const uint32_t max_waves_cu = 32;
     lp.lds_scene = false;
-    if (!force_global) {
-        for (uint32_t b : blocks) {
-            if (block_env && b != block_env) continue;
-            const size_t need = trace_lds_bytes(dc.view, true, b);
-            if (need <= dc.max_lds) {
+    if (!force_global && dc.view.desc16) {
+        struct Cand { uint32_t block, per_cu; };
+        const Cand cands[] = {{512, 3}, {1024, 2}, {1024, 1}, {512, 2}, {512, 1}, {256, 1}};
+        for (const Cand& c : cands) {
+            if (block_env && c.block != block_env) continue;
+            if (wg_env && c.per_cu != wg_env) continue;
+            const size_t need = trace_lds_bytes(dc.view, true, c.block);
+            if (need * c.per_cu <= dc.max_lds && c.per_cu * (c.block / 64) <= max_waves_cu) {
                 lp.lds_scene = true;
-                lp.block = b;
+                lp.block = c.block;
+                lp.wg_per_cu = c.per_cu;
                 lp.lds_bytes = need;
-                lp.grid = (uint32_t)dc.num_cus;  // one resident workgroup per CU
                 break;
             }
         }
@@ -166,12 +175,13 @@ LaunchPlan plan_launch(const DeviceCtx& dc, const FrameParams& fp) {
         lp.block = block_env ? block_env : 256u;
         lp.lds_bytes = trace_lds_bytes(dc.view, false, lp.block);
         uint32_t per_cu = (uint32_t)(dc.max_lds / (lp.lds_bytes ? lp.lds_bytes : 1));
-        const uint32_t by_waves = 16u / (lp.block / 64u);  // 16 waves per CU
+        const uint32_t by_waves = max_waves_cu / (lp.block / 64u);
         if (per_cu > by_waves) per_cu = by_waves;
         if (per_cu < 1) per_cu = 1;
-        per_cu = env_u32("BRT_WG_PER_CU", per_cu);
-        lp.grid = (uint32_t)dc.num_cus * per_cu;
+        if (wg_env) per_cu = wg_env;
+        lp.wg_per_cu = per_cu;
     }
+    lp.grid = (uint32_t)dc.num_cus * lp.wg_per_cu;
     const uint32_t useful = (fp.queue_size + lp.block - 1u) / lp.block;
     if (lp.grid > useful) lp.grid = useful;
     if (lp.grid < 1) lp.grid = 1;
@@ -182,7 +192,7 @@ LaunchPlan plan_launch(const DeviceCtx& dc, const FrameParams& fp) {
 int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const float* d_raster_rgba,
                     const float* d_raster_depth, float* d_out_tile, hipStream_t stream, uint32_t flags, bool timed,
                     LaunchPlan* plan_out) {
-    HIP_TRY(ctx, hipMemsetAsync(dc.d_ctrl, 0, 64, stream));
+    HIP_TRY(ctx, hipMemsetAsync(dc.d_ctrl, 0, 512, stream));
     if (timed) HIP_TRY(ctx, hipEventRecord(dc.ev0, stream));
     LaunchPlan lp{};
     if (fp.level == 0u) {
@@ -191,7 +201,7 @@ int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const fl
         TraceLaunch tl{};
         tl.scene = dc.view;
         tl.frame = fp;
-        tl.queue_counter = reinterpret_cast<uint32_t*>(dc.d_ctrl + 48);
+        tl.queue_counter = reinterpret_cast<uint32_t*>(dc.d_ctrl + 256);
         tl.out_tile = d_out_tile;
         tl.raster_rgba = d_raster_rgba;
         tl.raster_depth = d_raster_depth;
@@ -290,7 +300,7 @@ int32_t brt_create(const int32_t* device_ids, int32_t n_devices, brt_ctx** out_c
             HIP_TRY(ctx, hipStreamCreateWithFlags(&dc.stream, hipStreamNonBlocking));
             HIP_TRY(ctx, hipEventCreate(&dc.ev0));
             HIP_TRY(ctx, hipEventCreate(&dc.ev1));
-            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dc.d_ctrl), 64));
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dc.d_ctrl), 512));
             return BRT_OK;
         };
         rc = body();
@@ -361,6 +371,8 @@ int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, co
         v.n_leaf_table = (uint32_t)(e.leaf_table.size() / 2);
         v.root_desc = e.root_desc;
         v.stack_entries = e.stack_entries;
+        v.desc16 = e.desc16 ? 1u : 0u;
+        v.simple_tree = e.simple_tree ? 1u : 0u;
         dc.view = v;
     }
     for (auto& dc : ctx->devs) {
@@ -510,6 +522,14 @@ int32_t brt_deinterleave_device(brt_ctx* ctx, const float* d_tiles, uint32_t n_p
     hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : dc.stream;
     HIP_TRY(ctx, launch_deinterleave(d_tiles, d_frame, width, height, n_parts, brt_tile_rows(height, n_parts), stream));
     if (!hip_stream) HIP_TRY(ctx, hipStreamSynchronize(stream));
+    return BRT_OK;
+}
+
+int32_t brt_debug_profile(brt_ctx* ctx, uint64_t* out32) {
+    if (!ctx || !out32) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
+    DeviceCtx& dc = ctx->devs[0];
+    HIP_TRY(ctx, hipSetDevice(dc.device));
+    HIP_TRY(ctx, hipMemcpy(out32, dc.d_ctrl, 256, hipMemcpyDeviceToHost));
     return BRT_OK;
 }
 

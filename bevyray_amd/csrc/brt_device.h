@@ -79,24 +79,24 @@ BRT_DEV bool slab_push(f3 o, f3 inv, f3 bmin, f3 bmax, float closest) {
     const float t_near = max_f(max_f(min_f(tminx, tmaxx), min_f(tminy, tmaxy)), min_f(tminz, tmaxz));
     const float t_far = min_f(min_f(max_f(tminx, tmaxx), max_f(tminy, tmaxy)), max_f(tminz, tmaxz));
     const bool hit = (t_far >= t_near) && (t_far > 0.0f);
-    const float dst = hit ? (t_near > 0.0f ? t_near : 0.0f) : kInf;
-    return (dst != kInf) && (dst < closest);
+    // dst = hit ? (t_near > 0 ? t_near : 0) : INF;  pushed iff dst != INF && dst < closest.
+    // closest <= INF always, so `dst < closest` already implies `dst != INF`; and for a hit
+    // t_near is not NaN, so select(0, t_near, t_near > 0) == max(t_near, 0) in the compare.
+    return hit && (max_f(t_near, 0.0f) < closest);
 }
 
 // raytrace.wgsl:371-383 + the accept test of :353-354.  `a` = dot(d,d) hoisted per ray,
-// s.w = radius*radius.  (t != -1.0 is implied by t > 0.001.)
+// s.w = radius*radius.  Branch-free: discriminant < 0 gives sqrt -> NaN -> t NaN -> rejected
+// by `t > 0.001`, as the shader's -1.0 is (and t != -1.0 is implied by t > 0.001).
 BRT_DEV void sphere_test(f3 o, f3 d, float a, float4 s, uint32_t idx, float& closest, uint32_t& closest_idx) {
     const f3 oc = mk3(s.x - o.x, s.y - o.y, s.z - o.z);
     const float h = dot3(d, oc);
     const float c = dot3(oc, oc) - s.w;
     const float disc = h * h - a * c;
-    if (!(disc < 0.0f)) {
-        const float t = (h - __builtin_sqrtf(disc)) / a;
-        if (t > 0.001f && t < closest) {
-            closest = t;
-            closest_idx = idx;
-        }
-    }
+    const float t = (h - __builtin_sqrtf(disc)) / a;
+    const bool accept = (t > 0.001f) && (t < closest);
+    closest = accept ? t : closest;
+    closest_idx = accept ? idx : closest_idx;
 }
 
 // Scene accessors.  The persistent kernel instantiates with LDS pointers, the bring-up
@@ -114,51 +114,85 @@ struct ScenePtrs {
 
 struct HitCounters {
     uint32_t node_pops, interior, sphere_tests, hits;
+    // COUNTERS builds only: per code section, how often the wave executed it and with how many
+    // lanes (lane-utilisation profile; read by brt_debug_profile)
+    uint32_t sec_exec[8], sec_lanes[8];
 };
+enum { SEC_INTERIOR = 0, SEC_LEAF, SEC_CAMERA, SEC_SCATTER, SEC_SKY, SEC_END_SAMPLE, SEC_REFILL, SEC_ROUND };
+
+// Counts one execution of a code section and its active lanes.  May be called under divergent
+// control flow: the ballot only sees the lanes that reached the call; the first of them books it.
+template <bool COUNTERS>
+BRT_DEV void prof_section(HitCounters& hc, int sec, bool pred) {
+    if (COUNTERS) {
+        const uint64_t m = __ballot(pred);
+        if (pred && __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0u) {
+            hc.sec_exec[sec]++;
+            hc.sec_lanes[sec] += (uint32_t)__popcll(m);
+        }
+    }
+}
 
 // raytrace.wgsl:313-362: closest hit of one ray.  `stk` points at this lane's column of a
-// [entries][64] u32 array (LDS) or at a private array with stride 1.
+// [entries + 1][STRIDE] array (LDS: u16 entries when descriptors are 16-bit; bring-up kernel:
+// a private array, STRIDE 1); entry `dummy_entry` (the extra one) absorbs the stores of lanes
+// that push nothing.
 // Reference bookkeeping: stack_index == (entries in stk) + (cur valid ? 1 : 0); the loop
-// condition stack_index > 0 && stack_index < 32 (raytrace.wgsl:320) is `valid && n < 31`.
-template <int STRIDE, bool COUNTERS, typename StackT>
-BRT_DEV void raycast(const ScenePtrs& sc, uint32_t root_desc, StackT* stk, f3 o, f3 d, float& t_out,
-                     uint32_t& idx_out, HitCounters& hc) {
+// condition stack_index > 0 && stack_index < 32 (raytrace.wgsl:320) is `cur != DONE && n < 31`.
+//
+// The kernel is bound by TOTAL instruction issue (VALU + scalar + branches), and a
+// divergent if/else nest costs scalar exec-mask bookkeeping on every level.  So both bodies
+// are straight-line: the child selection, push and pop of raytrace.wgsl:331-341 become
+// selects, the push is an unconditional LDS store (to the dummy entry when nothing is
+// pushed), the pop an unconditional LDS load.  hit_sphere's `discriminant < 0 -> -1`
+// (raytrace.wgsl:378-380) needs no branch either: sqrt of a negative is NaN and a NaN t
+// fails `t > 0.001`, exactly like -1 does.
+// SIMPLE_TREE (decided at upload): every leaf holds one sphere and the tree is shallower than
+// 31 levels, so neither the leaf table nor the stack-overflow rule can come into play and
+// both checks are compiled out.
+template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, typename StackT>
+BRT_DEV void raycast(const ScenePtrs& sc, uint32_t root_desc, StackT* stk, uint32_t dummy_entry, f3 o, f3 d,
+                     float& t_out, uint32_t& idx_out, HitCounters& hc) {
+    using DS = Desc<D16>;
     const float a = dot3(d, d);
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     float closest = kInf;
     uint32_t closest_idx = 0xffffffffu;
     uint32_t cur = root_desc;
-    int n = 0;
-    bool valid = true;
-    while (valid && n < 31) {
-        if (COUNTERS) hc.node_pops++;
-        if (cur & DESC_LEAF) {
-            uint32_t first = cur & DESC_INDEX_MASK, count = 1;
-            if (!(cur & 0x40000000u)) {
-                const uint2 lt = sc.leaf_table[first];
-                first = lt.x;
-                count = lt.y;
-            }
-            for (uint32_t i = first; i < first + count; i++) {
+    uint32_t n = 0;
+    while (cur != DS::DONE && (SIMPLE_TREE || n < 31u)) {
+        if (cur & DS::LEAF) {
+            if (COUNTERS) hc.node_pops++;
+            if (STRIDE == 64) prof_section<COUNTERS>(hc, SEC_LEAF, true);
+            const uint32_t first = cur & DS::INDEX_MASK;
+            if (SIMPLE_TREE || (cur & DS::LEAF1)) {      // one sphere (what PLOC produces)
                 if (COUNTERS) hc.sphere_tests++;
-                sphere_test(o, d, a, sc.spheres[i], i, closest, closest_idx);
+                sphere_test(o, d, a, sc.spheres[first], first, closest, closest_idx);
+            } else {                                     // general leaf: {first, count} from the leaf table
+                const uint2 lt = sc.leaf_table[first];
+                for (uint32_t i = lt.x; i < lt.x + lt.y; i++) {
+                    if (COUNTERS) hc.sphere_tests++;
+                    sphere_test(o, d, a, sc.spheres[i], i, closest, closest_idx);
+                }
             }
-            if (n > 0) { n--; cur = stk[n * STRIDE]; } else valid = false;
+            const bool has = n > 0u;
+            n = has ? n - 1u : 0u;
+            const uint32_t popped = stk[n * STRIDE];
+            cur = has ? popped : DS::DONE;
         } else {
-            if (COUNTERS) hc.interior++;
+            if (COUNTERS) { hc.node_pops++; hc.interior++; }
+            if (STRIDE == 64) prof_section<COUNTERS>(hc, SEC_INTERIOR, true);
             const float4 A = sc.q0[cur], B = sc.q1[cur], C = sc.q2[cur];
             const uint2 D = sc.qd[cur];
             const bool p1 = slab_push(o, inv, mk3(A.x, A.y, A.z), mk3(A.w, B.x, B.y), closest);
             const bool p2 = slab_push(o, inv, mk3(B.z, B.w, C.x), mk3(C.y, C.z, C.w), closest);
-            // reference pushes `index` then `index+1`; the later push is popped first
-            if (p2) {
-                if (p1) { stk[n * STRIDE] = D.x; n++; }
-                cur = D.y;
-            } else if (p1) {
-                cur = D.x;
-            } else {
-                if (n > 0) { n--; cur = stk[n * STRIDE]; } else valid = false;
-            }
+            // reference: push `index` (D.x) then `index+1` (D.y); the later push is popped first
+            const bool both = p1 && p2, none = !p1 && !p2;
+            stk[(both ? n : dummy_entry) * STRIDE] = (StackT)D.x;
+            const bool can_pop = none && n > 0u;
+            const uint32_t popped = stk[(n > 0u ? n - 1u : 0u) * STRIDE];   // != the slot just written
+            cur = p2 ? D.y : (p1 ? D.x : (can_pop ? popped : DS::DONE));
+            n = both ? n + 1u : (can_pop ? n - 1u : n);
         }
     }
     t_out = closest;
@@ -186,6 +220,12 @@ BRT_DEV float schlick(float cosine, float ri) {
 // raytrace.wgsl:231-299 applied to the hit (t, idx) of ray (o,d); the HitInfo fields are
 // rebuilt here from (t, idx) exactly as raytrace.wgsl:355-358 builds them.
 // Returns absorbed; writes the scattered ray and the attenuation.
+//
+// Written for a divergent wave: the three material branches of the shader would each carry
+// their own copy of the rejection sampler and of normalize().  Here the lottery first fixes
+// the kind, then ONE rejection loop serves every lane that still needs a ball (metal 1,
+// diffuse 2, glass 0) and ONE normalize serves metal (reflected direction) and glass (incoming
+// direction).  Per lane the RNG draws and the arithmetic are the shader's, in its order.
 BRT_DEV bool scatter(const ScenePtrs& sc, f3& o, f3& d, float t, uint32_t idx, uint32_t& rng, f3& attenuation) {
     const float4 s = sc.spheres[idx];
     const f3 pos = mk3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);          // ray_at, :130-132
@@ -193,34 +233,49 @@ BRT_DEV bool scatter(const ScenePtrs& sc, f3& o, f3& d, float t, uint32_t idx, u
     const uint32_t mid = sc.sphere_material[idx];
     const float4 m0 = sc.materials[2 * mid];      // base_color.rgb, metallic
     const float4 m1 = sc.materials[2 * mid + 1];  // roughness, reflectance, ior, specular_transmission
-    bool absorbed;
-    if (rng_float(rng) < m0.w) {                                              // metal, :234-245
-        const f3 fuzz = m1.x * rng_unit_ball(rng);
-        const f3 refl = normalize3(reflect3(d, nrm)) + fuzz;
-        d = refl;
-        attenuation = mk3(m0.x, m0.y, m0.z);
-        absorbed = dot3(d, nrm) < 0.0f;
-    } else if (rng_float(rng) < m1.w) {                                       // glass, :249-280
-        const bool front_face = dot3(d, nrm) < 0.0f;                          // :358
-        const float ri = front_face ? (1.0f / m1.z) : m1.z;
-        const f3 u = normalize3(d);
-        const float cos_theta = min_f(dot3(neg3(u), nrm), 1.0f);
-        const float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
-        const bool cannot_refract = ri * sin_theta > 1.0f;
-        const float refl = schlick(cos_theta, ri);
-        const float draw = rng_float(rng);                                    // always drawn
-        d = (cannot_refract || refl > draw) ? reflect3(u, nrm) : refract3(u, nrm, ri);
-        attenuation = mk3(1.0f, 1.0f, 1.0f);
-        absorbed = false;
-    } else {                                                                  // diffuse, :281-297
-        const f3 b1 = rng_unit_ball(rng);
-        const f3 b2 = rng_unit_ball(rng);
-        f3 sd = (nrm + b1) + m1.x * b2;
+    const bool metal = rng_float(rng) < m0.w;                                  // :234
+    const bool glass = !metal && (rng_float(rng) < m1.w);                      // :249 (drawn only when not metal)
+    const bool diffuse = !metal && !glass;
+
+    // balls: metal fuzz = roughness * ball (:238); diffuse normal + ball + roughness * ball (:285)
+    uint32_t need = metal ? 1u : (diffuse ? 2u : 0u);
+    f3 acc = mk3(0.0f, 0.0f, 0.0f);
+    while (need != 0u) {                                                      // random.wgsl:19-24
+        const float x = rng_float(rng);
+        const float y = rng_float(rng);
+        const float z = rng_float(rng);
+        const f3 p = mk3(2.0f * x - 1.0f, 2.0f * y - 1.0f, 2.0f * z - 1.0f);
+        if (dot3(p, p) <= 1.0f) {
+            if (diffuse && need == 2u) acc = nrm + p;
+            else if (diffuse) acc = acc + m1.x * p;
+            else acc = m1.x * p;
+            need--;
+        }
+    }
+
+    bool absorbed = false;
+    attenuation = mk3(m0.x, m0.y, m0.z);
+    if (diffuse) {                                                            // :281-297
         const float eps = 1e-8f;
-        if (__builtin_fabsf(sd.x) < eps && __builtin_fabsf(sd.y) < eps && __builtin_fabsf(sd.z) < eps) sd = nrm;
-        d = sd;
-        attenuation = mk3(m0.x, m0.y, m0.z);
-        absorbed = dot3(d, nrm) < 0.0f;
+        if (__builtin_fabsf(acc.x) < eps && __builtin_fabsf(acc.y) < eps && __builtin_fabsf(acc.z) < eps) acc = nrm;
+        absorbed = dot3(acc, nrm) < 0.0f;
+        d = acc;
+    } else {
+        const bool front_face = dot3(d, nrm) < 0.0f;                          // :358 (incoming direction)
+        const f3 u = normalize3(metal ? reflect3(d, nrm) : d);                // :238 / :261
+        if (metal) {                                                          // :234-245
+            d = u + acc;
+            absorbed = dot3(d, nrm) < 0.0f;
+        } else {                                                              // glass, :249-280
+            const float ri = front_face ? (1.0f / m1.z) : m1.z;
+            const float cos_theta = min_f(dot3(neg3(u), nrm), 1.0f);
+            const float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+            const bool cannot_refract = ri * sin_theta > 1.0f;
+            const float refl = schlick(cos_theta, ri);
+            const float draw = rng_float(rng);                                // always drawn
+            d = (cannot_refract || refl > draw) ? reflect3(u, nrm) : refract3(u, nrm, ri);
+            attenuation = mk3(1.0f, 1.0f, 1.0f);
+        }
     }
     o = pos;
     return absorbed;

@@ -31,7 +31,7 @@ int32_t validate_and_encode(const Model* models, uint32_t n_models, const Materi
     if (n_models == 0) { *err = "scene has no spheres (the reference skips the pass)"; return BRT_ERR_EMPTY_SCENE; }
     if (!models || !materials || n_materials == 0) { *err = "null models/materials"; return BRT_ERR_INVALID_ARGUMENT; }
     if (!nodes || n_nodes == 0) { *err = "null/empty BVH"; return BRT_ERR_INVALID_BVH; }
-    if (n_models > DESC_INDEX_MASK || n_nodes > DESC_INDEX_MASK) { *err = "scene too large for 30-bit descriptors"; return BRT_ERR_UNSUPPORTED; }
+    if (n_models > DESC32_MAX_INDEX || n_nodes > DESC32_MAX_INDEX) { *err = "scene too large for 30-bit descriptors"; return BRT_ERR_UNSUPPORTED; }
     for (uint32_t i = 0; i < n_models; i++) {
         if (models[i].material_id >= n_materials) {
             *err = "model " + std::to_string(i) + ": material_id " + std::to_string(models[i].material_id) +
@@ -95,14 +95,18 @@ int32_t validate_and_encode(const Model* models, uint32_t n_models, const Materi
     e.q2.resize(4 * (size_t)e.n_pairs);
     e.qd.resize(2 * (size_t)e.n_pairs);
 
+    // 16-bit descriptors when every index fits 14 bits (general leaves <= nodes)
+    e.desc16 = (n_models <= DESC16_MAX_INDEX) && (n_nodes <= DESC16_MAX_INDEX);
+    const uint32_t LEAF = e.desc16 ? Desc<true>::LEAF : Desc<false>::LEAF;
+    const uint32_t LEAF1 = e.desc16 ? Desc<true>::LEAF1 : Desc<false>::LEAF1;
     auto desc_of = [&](uint32_t n) -> uint32_t {
         const BVHNode& nd = nodes[n];
         if (nd.model_count == 0) return pair_id[n];
-        if (nd.model_count == 1) return DESC_LEAF1 | nd.index;
+        if (nd.model_count == 1) return LEAF | LEAF1 | nd.index;
         uint32_t id = (uint32_t)(e.leaf_table.size() / 2);
         e.leaf_table.push_back(nd.index);
         e.leaf_table.push_back(nd.model_count);
-        return DESC_LEAF | id;
+        return LEAF | id;
     };
 
     e.root_desc = desc_of(0);
@@ -138,6 +142,7 @@ int32_t validate_and_encode(const Model* models, uint32_t n_models, const Materi
     // most two pushes, so the deepest write index is max_leaf_depth (entries needed: +1).
     e.stack_entries = std::min<uint32_t>(32u, max_leaf_depth + 1u);
     if (e.stack_entries < 2) e.stack_entries = 2;
+    e.simple_tree = e.leaf_table.empty() && (max_leaf_depth + 1u < 31u);
     return BRT_OK;
 }
 

@@ -24,6 +24,8 @@ struct EncodedScene {
     uint32_t root_desc = 0;
     uint32_t max_leaf_depth = 0;
     uint32_t stack_entries = 2;
+    bool desc16 = false;                 // descriptors in the 16-bit form (brt_layout.h)
+    bool simple_tree = false;            // single-sphere leaves only, depth below the stack-overflow rule
 };
 
 int32_t validate_and_encode(const Model* models, uint32_t n_models, const Material* materials, uint32_t n_materials,

@@ -21,6 +21,8 @@
 // k_debug_eval        evaluates single device functions for per-function parity tests.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "brt_device.h"
 #include "brt_kernels.h"
 
@@ -121,46 +123,48 @@ BRT_DEV bool shade_segment(const ScenePtrs& sc, const FrameParams& fp, f3& o, f3
 
 // ---- persistent kernel -----------------------------------------------------------------------
 
-template <bool LDS_SCENE, bool COUNTERS>
+// LDS_SCENE: pair records, spheres and material ids live in LDS (descriptors are then always
+// 16-bit); the 32-byte materials stay in global memory (one read per hit).  D16: 16-bit
+// descriptors and u16 stack entries.  SIMPLE: see raycast (brt_device.h).
+template <bool LDS_SCENE, bool D16, bool SIMPLE, bool COUNTERS>
 __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView sv, FrameParams fp,
                                                                 uint32_t* __restrict__ queue_counter,
                                                                 float* __restrict__ out_tile,
                                                                 const float* __restrict__ raster_rgba,
                                                                 const float* __restrict__ raster_depth,
                                                                 unsigned long long* __restrict__ counters) {
+    static_assert(!LDS_SCENE || D16, "an LDS-resident scene always uses 16-bit descriptors");
+    using StackT = typename std::conditional<D16, uint16_t, uint32_t>::type;
     extern __shared__ uint4 smem[];
     ScenePtrs sc;
-    uint32_t* stacks;
+    StackT* stacks;
+    sc.materials = reinterpret_cast<const float4*>(sv.materials);
     if (LDS_SCENE) {
-        // carve: q0 | q1 | q2 | spheres | materials | qd | leaf_table | sphere_material | stacks
+        // carve: q0 | q1 | q2 | spheres | qd | leaf_table | sphere_material | stacks
         float4* p = reinterpret_cast<float4*>(smem);
         float4* l_q0 = p; p += sv.n_pairs;
         float4* l_q1 = p; p += sv.n_pairs;
         float4* l_q2 = p; p += sv.n_pairs;
         float4* l_sp = p; p += sv.n_models;
-        float4* l_mt = p; p += 2 * sv.n_materials;
         uint2* p2 = reinterpret_cast<uint2*>(p);
         uint2* l_qd = p2; p2 += sv.n_pairs;
         uint2* l_lt = p2; p2 += sv.n_leaf_table;
         uint32_t* p1 = reinterpret_cast<uint32_t*>(p2);
         uint32_t* l_sm = p1; p1 += sv.n_models;
-        p1 += (4u - (sv.n_models & 3u)) & 3u;   // keep the stacks 16-byte aligned
-        stacks = p1;
+        stacks = reinterpret_cast<StackT*>(p1);
         const float4* g_q0 = reinterpret_cast<const float4*>(sv.q0);
         const float4* g_q1 = reinterpret_cast<const float4*>(sv.q1);
         const float4* g_q2 = reinterpret_cast<const float4*>(sv.q2);
         const float4* g_sp = reinterpret_cast<const float4*>(sv.spheres);
-        const float4* g_mt = reinterpret_cast<const float4*>(sv.materials);
         const uint2* g_qd = reinterpret_cast<const uint2*>(sv.qd);
         const uint2* g_lt = reinterpret_cast<const uint2*>(sv.leaf_table);
         for (uint32_t i = threadIdx.x; i < sv.n_pairs; i += blockDim.x) {
             l_q0[i] = g_q0[i]; l_q1[i] = g_q1[i]; l_q2[i] = g_q2[i]; l_qd[i] = g_qd[i];
         }
         for (uint32_t i = threadIdx.x; i < sv.n_models; i += blockDim.x) { l_sp[i] = g_sp[i]; l_sm[i] = sv.sphere_material[i]; }
-        for (uint32_t i = threadIdx.x; i < 2 * sv.n_materials; i += blockDim.x) l_mt[i] = g_mt[i];
         for (uint32_t i = threadIdx.x; i < sv.n_leaf_table; i += blockDim.x) l_lt[i] = g_lt[i];
         sc.q0 = l_q0; sc.q1 = l_q1; sc.q2 = l_q2; sc.qd = l_qd;
-        sc.spheres = l_sp; sc.sphere_material = l_sm; sc.materials = l_mt; sc.leaf_table = l_lt;
+        sc.spheres = l_sp; sc.sphere_material = l_sm; sc.leaf_table = l_lt;
         __syncthreads();
     } else {
         sc.q0 = reinterpret_cast<const float4*>(sv.q0);
@@ -169,13 +173,12 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         sc.qd = reinterpret_cast<const uint2*>(sv.qd);
         sc.spheres = reinterpret_cast<const float4*>(sv.spheres);
         sc.sphere_material = sv.sphere_material;
-        sc.materials = reinterpret_cast<const float4*>(sv.materials);
         sc.leaf_table = reinterpret_cast<const uint2*>(sv.leaf_table);
-        stacks = reinterpret_cast<uint32_t*>(smem);
+        stacks = reinterpret_cast<StackT*>(smem);
     }
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
-    uint32_t* stk = stacks + wave * (sv.stack_entries * 64u) + lane;
+    StackT* stk = stacks + wave * ((sv.stack_entries + 1u) * 64u) + lane;   // + 1: dummy entry
 
     PixelState ps;
     ps.sample = 0; ps.rng = 0; ps.out_index = 0; ps.frame_index = 0;
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     float first_depth = kInf;
     bool active = false, exhausted = false;
     uint32_t n_rays = 0;
-    HitCounters hc = {0u, 0u, 0u, 0u};
+    HitCounters hc = {};
 
     for (;;) {
         // ---- refill empty lanes from the pixel queue (wave-aggregated) ----
@@ -212,17 +215,21 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         }
         if (__ballot(active) == 0) break;
 
+        prof_section<COUNTERS>(hc, SEC_ROUND, active);
+        prof_section<COUNTERS>(hc, SEC_CAMERA, active && bounce == 0);
+        if (active && bounce == 0) {
+            // new sample: raytrace.wgsl:162 + :175-186
+            d = camera_ray_dir(fp, ps.ndc0x, ps.ndc0y, ps.rng);
+            o = mk3(fp.cam_pos[0], fp.cam_pos[1], fp.cam_pos[2]);
+            tput = mk3(1.0f, 1.0f, 1.0f);
+            first_depth = kInf;
+        }
+        float t = kInf;
+        uint32_t idx = 0xffffffffu;
+        if (active) raycast<64, COUNTERS, D16, SIMPLE>(sc, sv.root_desc, stk, sv.stack_entries, o, d, t, idx, hc);
+        prof_section<COUNTERS>(hc, SEC_SCATTER, active && t != kInf);
+        prof_section<COUNTERS>(hc, SEC_SKY, active && t == kInf);
         if (active) {
-            if (bounce == 0) {
-                // new sample: raytrace.wgsl:162 + :175-186
-                d = camera_ray_dir(fp, ps.ndc0x, ps.ndc0y, ps.rng);
-                o = mk3(fp.cam_pos[0], fp.cam_pos[1], fp.cam_pos[2]);
-                tput = mk3(1.0f, 1.0f, 1.0f);
-                first_depth = kInf;
-            }
-            float t;
-            uint32_t idx;
-            raycast<64, COUNTERS>(sc, sv.root_desc, stk, o, d, t, idx, hc);
             n_rays++;
             f3 color;
             if (shade_segment(sc, fp, o, d, tput, bounce, first_depth, t, idx, ps.rng, color, hc.hits)) {
@@ -250,12 +257,18 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         }
     }
     const uint32_t h = wave_sum(hc.hits);
-    if (COUNTERS && lane == 0) atomicAdd(&counters[4], (unsigned long long)h);
+    if (COUNTERS && lane == 0) {
+        atomicAdd(&counters[4], (unsigned long long)h);
+        for (int k = 0; k < 8; k++) {
+            atomicAdd(&counters[8 + 2 * k], (unsigned long long)hc.sec_exec[k]);
+            atomicAdd(&counters[9 + 2 * k], (unsigned long long)hc.sec_lanes[k]);
+        }
+    }
 }
 
 // ---- bring-up kernel ---------------------------------------------------------------------------
 
-template <bool COUNTERS>
+template <bool D16, bool COUNTERS>
 __global__ __launch_bounds__(256) void k_trace_simple(DeviceSceneView sv, FrameParams fp, float* __restrict__ out_tile,
                                                       const float* __restrict__ raster_rgba,
                                                       const float* __restrict__ raster_depth,
@@ -271,13 +284,13 @@ __global__ __launch_bounds__(256) void k_trace_simple(DeviceSceneView sv, FrameP
     sc.materials = reinterpret_cast<const float4*>(sv.materials);
     sc.leaf_table = reinterpret_cast<const uint2*>(sv.leaf_table);
     uint32_t n_rays = 0;
-    HitCounters hc = {0u, 0u, 0u, 0u};
+    HitCounters hc = {};
     if (q < fp.queue_size) {
         const PixelCoord c = slot_to_pixel(fp, q);
         if (c.inside) {
             PixelState ps;
             pixel_begin(fp, c, ps);
-            uint32_t stack[32];
+            uint32_t stack[33];   // 32 entries + the dummy slot
             for (uint32_t s = 0; s < fp.sample_count; s++) {          // raytrace.wgsl:161
                 f3 d = camera_ray_dir(fp, ps.ndc0x, ps.ndc0y, ps.rng);
                 f3 o = mk3(fp.cam_pos[0], fp.cam_pos[1], fp.cam_pos[2]);
@@ -288,7 +301,7 @@ __global__ __launch_bounds__(256) void k_trace_simple(DeviceSceneView sv, FrameP
                 for (;;) {
                     float t;
                     uint32_t idx;
-                    raycast<1, COUNTERS>(sc, sv.root_desc, stack, o, d, t, idx, hc);
+                    raycast<1, COUNTERS, D16, false>(sc, sv.root_desc, stack, 32u, o, d, t, idx, hc);
                     n_rays++;
                     if (shade_segment(sc, fp, o, d, tput, bounce, first_depth, t, idx, ps.rng, color, hc.hits)) break;
                 }
@@ -385,17 +398,16 @@ __global__ void k_debug_eval(uint32_t op, const float* __restrict__ in, float* _
 size_t trace_lds_bytes(const DeviceSceneView& sv, bool lds_scene, uint32_t block) {
     size_t bytes = 0;
     if (lds_scene) {
-        bytes += (size_t)sv.n_pairs * 48 + (size_t)sv.n_models * 16 + (size_t)sv.n_materials * 32;
-        bytes += (size_t)sv.n_pairs * 8 + (size_t)sv.n_leaf_table * 8;
-        bytes += (((size_t)sv.n_models + 3) & ~(size_t)3) * 4;
+        bytes += (size_t)sv.n_pairs * 48 + (size_t)sv.n_models * 16;
+        bytes += (size_t)sv.n_pairs * 8 + (size_t)sv.n_leaf_table * 8 + (size_t)sv.n_models * 4;
     }
-    bytes += (size_t)(block / 64) * sv.stack_entries * 64 * 4;
-    return bytes;
+    bytes += (size_t)(block / 64) * (sv.stack_entries + 1) * 64 * (sv.desc16 ? 2 : 4);   // + 1: dummy entry
+    return (bytes + 15) & ~(size_t)15;
 }
 
-template <bool L, bool C>
+template <bool L, bool D, bool S, bool C>
 static hipError_t launch_persistent_t(const TraceLaunch& tl) {
-    auto kern = k_trace_persistent<L, C>;
+    auto kern = k_trace_persistent<L, D, S, C>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)tl.lds_bytes);
     if (e != hipSuccess) return e;
@@ -404,21 +416,33 @@ static hipError_t launch_persistent_t(const TraceLaunch& tl) {
     return hipGetLastError();
 }
 
+template <bool L, bool D>
+static hipError_t launch_persistent_ld(const TraceLaunch& tl) {
+    if (tl.scene.simple_tree)
+        return tl.counters_on ? launch_persistent_t<L, D, true, true>(tl) : launch_persistent_t<L, D, true, false>(tl);
+    return tl.counters_on ? launch_persistent_t<L, D, false, true>(tl) : launch_persistent_t<L, D, false, false>(tl);
+}
+
 hipError_t launch_trace_persistent(const TraceLaunch& tl) {
-    if (tl.lds_scene) return tl.counters_on ? launch_persistent_t<true, true>(tl) : launch_persistent_t<true, false>(tl);
-    return tl.counters_on ? launch_persistent_t<false, true>(tl) : launch_persistent_t<false, false>(tl);
+    if (tl.lds_scene) {
+        if (!tl.scene.desc16) return hipErrorInvalidValue;
+        return launch_persistent_ld<true, true>(tl);
+    }
+    return tl.scene.desc16 ? launch_persistent_ld<false, true>(tl) : launch_persistent_ld<false, false>(tl);
+}
+
+template <bool D, bool C>
+static hipError_t launch_simple_t(const TraceLaunch& tl, uint32_t grid) {
+    hipLaunchKernelGGL((k_trace_simple<D, C>), dim3(grid), dim3(256), 0, tl.stream, tl.scene, tl.frame, tl.out_tile,
+                       tl.raster_rgba, tl.raster_depth, tl.counters);
+    return hipGetLastError();
 }
 
 hipError_t launch_trace_simple(const TraceLaunch& tl) {
     const uint32_t grid = (tl.frame.queue_size + 255u) / 256u;
     if (grid == 0) return hipSuccess;
-    if (tl.counters_on)
-        hipLaunchKernelGGL(k_trace_simple<true>, dim3(grid), dim3(256), 0, tl.stream, tl.scene, tl.frame, tl.out_tile,
-                           tl.raster_rgba, tl.raster_depth, tl.counters);
-    else
-        hipLaunchKernelGGL(k_trace_simple<false>, dim3(grid), dim3(256), 0, tl.stream, tl.scene, tl.frame, tl.out_tile,
-                           tl.raster_rgba, tl.raster_depth, tl.counters);
-    return hipGetLastError();
+    if (tl.scene.desc16) return tl.counters_on ? launch_simple_t<true, true>(tl, grid) : launch_simple_t<true, false>(tl, grid);
+    return tl.counters_on ? launch_simple_t<false, true>(tl, grid) : launch_simple_t<false, false>(tl, grid);
 }
 
 hipError_t launch_passthrough(const FrameParams& fp, float* out_tile, const float* raster_rgba, hipStream_t stream) {

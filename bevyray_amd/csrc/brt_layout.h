@@ -73,13 +73,22 @@ static_assert(sizeof(Window) == 16 && offsetof(Window, height) == 4, "Window");
 // each interior node becomes a "pair record" with both children's boxes and descriptors.
 // The push/pop ORDER is the reference's, so results (ties, stack-overflow rule) are the same.
 //
-// Descriptor:
+// Descriptor (32-bit form; scenes too large for LDS):
 //   bit31 = 0                 interior: bits[30:0] = pair-record index
 //   bit31 = 1, bit30 = 1      leaf with exactly one sphere: bits[29:0] = model index
 //   bit31 = 1, bit30 = 0      general leaf: bits[29:0] = index into the leaf table {first, count}
-constexpr uint32_t DESC_LEAF = 0x80000000u;
-constexpr uint32_t DESC_LEAF1 = 0xC0000000u;
-constexpr uint32_t DESC_INDEX_MASK = 0x3FFFFFFFu;
+// 16-bit form (every index < 16384, always the case for an LDS-resident scene): the same three
+// cases with the flags in bits 15/14 and a 14-bit index, so that a traversal-stack entry is a
+// u16 and 32 waves' stacks fit beside the scene in a CU's LDS.
+template <bool D16>
+struct Desc {
+    static constexpr uint32_t LEAF = D16 ? 0x8000u : 0x80000000u;
+    static constexpr uint32_t LEAF1 = D16 ? 0x4000u : 0x40000000u;   // set together with LEAF
+    static constexpr uint32_t INDEX_MASK = D16 ? 0x3FFFu : 0x3FFFFFFFu;
+    static constexpr uint32_t DONE = D16 ? 0xFFFFu : 0xFFFFFFFFu;    // "walk finished" marker, never a real descriptor
+};
+constexpr uint32_t DESC32_MAX_INDEX = 0x3FFFFFFEu;   // largest encodable index (all-ones is DONE)
+constexpr uint32_t DESC16_MAX_INDEX = 0x3FFEu;
 
 // Pair records are stored as four parallel arrays of 16-byte (12 for the last) granules so
 // that 64 lanes reading 64 different records spread over all LDS banks (a 64-byte
@@ -104,6 +113,8 @@ struct DeviceSceneView {
     uint32_t n_pairs, n_models, n_materials, n_leaf_table;
     uint32_t root_desc;
     uint32_t stack_entries;  // min(32, max leaf depth + 1)
+    uint32_t desc16;         // 1: descriptors are in the 16-bit form
+    uint32_t simple_tree;    // 1: every leaf holds one sphere and max leaf depth + 1 < 31
 };
 
 // Frame-uniform values, evaluated once on the host with the reference's expressions

@@ -260,6 +260,13 @@ class RaytracePlugin:
         except Exception:
             pass
 
+    def debug_profile(self) -> dict:
+        """Lane-utilisation profile of the last FLAG_COUNTERS launch: section -> (executions, lanes)."""
+        raw = (C.c_uint64 * 32)()
+        _lib.check(self._lib.brt_debug_profile(self._ctx, raw), self._ctx)
+        names = ["interior", "leaf", "camera", "scatter", "sky", "sec5", "sec6", "round"]
+        return {n: (int(raw[8 + 2 * k]), int(raw[9 + 2 * k])) for k, n in enumerate(names)}
+
     def debug_eval(self, op: int, inputs: np.ndarray) -> np.ndarray:
         inputs = np.ascontiguousarray(inputs, np.float32)
         assert inputs.ndim == 2 and inputs.shape[1] == 16

@@ -161,6 +161,12 @@ enum {
 };
 int32_t brt_debug_eval(brt_ctx* ctx, uint32_t op, const float* in16, float* out8, uint32_t n);
 
+/* Diagnostic: raw device counters of the last launch on the context's first device: out32[0..4]
+ * = the brt_stats counters; after a BRT_FLAG_COUNTERS launch out32[8+2k], out32[9+2k] = how
+ * often the waves executed code section k and the sum of active lanes over those executions
+ * (k: 0 interior step, 1 leaf step, 2 camera ray, 3 scatter, 4 sky, 5 -, 6 -, 7 ray round). */
+int32_t brt_debug_profile(brt_ctx* ctx, uint64_t* out32);
+
 /* ---- host-only helpers (no GPU needed) --------------------------------------------- */
 
 /* Replaces: obvhs::ploc::build_ploc::<24>(aabbs, identity, SortPrecision::U64, 0) and the

@@ -27,3 +27,7 @@ with brt.RaytracePlugin([0]) as p:
               f"lds {s['lds_bytes']} in_lds {s['scene_in_lds']} grid {s['n_workgroups']}x{s['threads_per_workgroup']} total {s['total_ms']:.1f} ms", flush=True)
     p.node.run(lvl, cam, win, a.w, a.h, flags=1)
     print({k: v for k, v in p.node.last_stats.items()})
+    prof = p.debug_profile()
+    for k, (ex, ln) in prof.items():
+        if ex:
+            print(f"   section {k:9s} executions {ex:12d}  lanes {ln:14d}  avg lanes/exec {ln/ex:6.2f}")
