@@ -133,6 +133,10 @@ int32_t make_frame_params(brt_ctx* ctx, const void* camera80, const void* window
     const uint32_t strips = (height + BRT_STRIP_ROWS - 1u) / BRT_STRIP_ROWS;
     fp.local_strips = (strips + n_parts - 1u) / n_parts;
     fp.queue_size = fp.local_strips * fp.tiles_x * 64u;
+    fp.bottom_up = env_u32("BRT_BOTTOM_UP", 0);
+    fp.refill_min = env_u32("BRT_REFILL_MIN", 1);
+    if (fp.refill_min < 1u) fp.refill_min = 1u;
+    if (fp.refill_min > 64u) fp.refill_min = 64u;
     *out = fp;
     return BRT_OK;
 }
@@ -145,9 +149,10 @@ struct LaunchPlan {
 
 // Choose the kernel variant and grid.  The scene (pair records, spheres, material ids) goes to
 // LDS when it fits; the 32-byte materials stay in global memory (read once per hit; measured:
-// no difference).  Measured on the cover scene: the kernel is instruction-issue
-// bound, so occupancy beyond 4 waves/SIMD buys little; 3 x 512 threads (6 waves/SIMD) is the
-// best by a few percent.  BRT_FORCE_GLOBAL_SCENE / BRT_BLOCK_THREADS / BRT_WG_PER_CU override.
+// no difference).  Measured on the cover scene: the kernel is bound by VALU pipe
+// time, not by latency -- 4, 6 and 8 waves/SIMD run within 4 % of each other -- so the plan is
+// simply one 1024-thread workgroup per CU.  BRT_FORCE_GLOBAL_SCENE / BRT_BLOCK_THREADS /
+// BRT_WG_PER_CU override (tuning aids).
 LaunchPlan plan_launch(const DeviceCtx& dc, const FrameParams& fp) {
     LaunchPlan lp{};
     const bool force_global = env_u32("BRT_FORCE_GLOBAL_SCENE", 0) != 0;
@@ -157,7 +162,7 @@ LaunchPlan plan_launch(const DeviceCtx& dc, const FrameParams& fp) {
     lp.lds_scene = false;
     if (!force_global && dc.view.desc16) {
         struct Cand { uint32_t block, per_cu; };
-        const Cand cands[] = {{512, 3}, {1024, 2}, {1024, 1}, {512, 2}, {512, 1}, {256, 1}};
+        const Cand cands[] = {{1024, 1}, {512, 2}, {512, 3}, {1024, 2}, {512, 1}, {256, 1}};
         for (const Cand& c : cands) {
             if (block_env && c.block != block_env) continue;
             if (wg_env && c.per_cu != wg_env) continue;

@@ -38,7 +38,9 @@ struct PixelCoord {
 };
 BRT_DEV PixelCoord slot_to_pixel(const FrameParams& fp, uint32_t q) {
     const uint32_t tile = q >> 6, t = q & 63u;
-    const uint32_t strip = tile / fp.tiles_x, tx = tile - strip * fp.tiles_x;
+    const uint32_t sq = tile / fp.tiles_x, tx = tile - sq * fp.tiles_x;
+    // queue order: bottom strips first when fp.bottom_up (longest-pixels-first heuristic)
+    const uint32_t strip = fp.bottom_up ? (fp.local_strips - 1u - sq) : sq;
     PixelCoord c;
     c.px = tx * 8u + (t & 7u);
     const uint32_t r = t >> 3;
@@ -196,6 +198,10 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             const bool need = !active && !exhausted;
             const uint64_t m = __ballot(need);
             if (m == 0) break;
+            // keep a wave's pixels of one cost class: take new ones only in batches of refill_min
+            // (a round costs the max over its lanes, so a cheap pixel dropped among expensive ones
+            // pays their price for each of its samples); always refill when nothing else runs
+            if ((uint32_t)__popcll(m) < fp.refill_min && __ballot(active) != 0ull) break;
             uint32_t base = 0;
             if (need && mbcnt64(m) == 0) base = atomicAdd(queue_counter, (uint32_t)__popcll(m));
             base = __shfl(base, (int)(__ffsll((long long)m) - 1), 64);

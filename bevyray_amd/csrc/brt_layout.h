@@ -134,6 +134,12 @@ struct FrameParams {
     uint32_t tiles_x;                // ceil(width / 8)
     uint32_t local_strips;           // strips owned by this part (padded count)
     uint32_t queue_size;             // local_strips * tiles_x * 64
+    // Pixels are independent but each is ONE sequential chain of sample_count paths (the
+    // reference threads one RNG state through them), so the frame ends when the slowest pixels
+    // end: hand out the (usually) expensive ones first.  With the usual "up = +Y" camera the
+    // lower rows see ground and objects, the upper rows sky (one ray per sample).
+    uint32_t bottom_up;
+    uint32_t refill_min;             // lanes that must be free before a wave takes new pixels (1..64)
 };
 
 }  // namespace brt
