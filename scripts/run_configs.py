@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Runs the BASELINE.json configs on one MI355X and prints one JSON line per config:
+kernel time, Mrays/s, exact counters, algorithmic bytes, and a bit-exact check of a few sampled
+rows against the CPU oracle at FULL size.  Config 4 (8 GPUs) is run as part 0 of 8 on this GPU."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import bevyray_amd as brt
+import oracle_loader
+
+def bytes_alg(s, w, rows):
+    return s["rays"]*96 + s["node_pops"]*48 + s["interior_visits"]*96 + s["sphere_tests"]*32 + s["hits"]*32 + w*rows*16
+
+CONFIGS = [
+    ("1: cover 400x225 1spp 4b", brt.SCENE_COVER, 400, 225, 1, 4, 1),
+    ("2: cover 1920x1080 64spp 8b", brt.SCENE_COVER, 1920, 1080, 64, 8, 1),
+    ("3: RTIOW final 1920x1080 256spp 50b", brt.SCENE_RTIOW_FINAL, 1920, 1080, 256, 50, 1),
+    ("4: RTIOW final 3840x2160 1024spp 8b, part 0 of 8", brt.SCENE_RTIOW_FINAL, 3840, 2160, 1024, 8, 8),
+    ("5: 10k-sphere grid 1920x1080 64spp 8b", brt.SCENE_STRESS_GRID, 1920, 1080, 64, 8, 1),
+]
+only = sys.argv[1:]
+oracle = oracle_loader.load()
+with brt.RaytracePlugin([0]) as p:
+    for name, kind, w, h, spp, bounces, n_parts in CONFIGS:
+        if only and name.split(":")[0] not in only:
+            continue
+        b = brt.generate_scene(kind, 1)
+        lvl, cam, win = brt.cover_camera(w, h, spp, bounces)
+        p.node.write_buffers(b)
+        rows = brt.tile_rows(h, n_parts)
+        tile = torch.zeros((rows, w, 4), dtype=torch.float32, device="cuda")
+        st = p.node.render_part_device(lvl, cam, win, w, h, 0, n_parts, tile.data_ptr())           # warm
+        st = min((p.node.render_part_device(lvl, cam, win, w, h, 0, n_parts, tile.data_ptr()) for _ in range(2)), key=lambda s: s["kernel_ms"])
+        cs = p.node.render_part_device(lvl, cam, win, w, h, 0, n_parts, tile.data_ptr(), flags=brt.FLAG_COUNTERS)
+        t = tile.cpu().numpy()
+        # sampled rows vs the oracle, full size, bit for bit
+        from bevyray_amd.parallel import frame_rows_of_part
+        fr = frame_rows_of_part(h, 0, n_parts)
+        picks = [int(x) for x in np.linspace(0, len(fr) - 1, 4) if fr[int(x)] >= 0]
+        t0 = time.time(); ok = True
+        for k in picks:
+            y = int(fr[k])
+            want, _ = oracle.render(b, lvl, cam, win, w, h, rows=(y, y + 1))
+            ok &= bool(np.array_equal(t[k].view(np.uint32), want[y].view(np.uint32)))
+        my_rows = int((fr >= 0).sum())
+        alg = bytes_alg(cs, w, my_rows)
+        print(json.dumps({"config": name, "spheres": int(len(b.models)), "kernel_ms": round(st["kernel_ms"], 3),
+                          "mrays_s": round(st["rays"] / st["kernel_ms"] / 1e3, 1), "rays": st["rays"], "paths": st["paths"],
+                          "rays_per_path": round(st["rays"] / max(1, st["paths"]), 3),
+                          "node_pops_per_ray": round(cs["node_pops"] / max(1, cs["rays"]), 2),
+                          "alg_bytes": alg, "alg_GBs": round(alg / st["kernel_ms"] / 1e6, 1), "scene_in_lds": st["scene_in_lds"],
+                          "grid": f"{st['n_workgroups']}x{st['threads_per_workgroup']}", "lds_bytes": st["lds_bytes"],
+                          "rows_checked_bit_exact": ok, "rows_checked": len(picks), "oracle_s": round(time.time() - t0, 1)}), flush=True)
