@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libbevyray_amd.so")
 _SOURCES = ["brt_api.cpp", "brt_host.cpp", "brt_kernels.hip", "brt_host.h", "brt_kernels.h", "brt_layout.h",
-            "brt_device.h", "Makefile"]
+            "brt_device.h", "brt_ploc.h", "brt_bvh.hip", "Makefile"]
 
 _lock = threading.Lock()
 _lib = None
@@ -69,6 +69,7 @@ _PROTOTYPES = {
     "brt_debug_eval": (_I32, [_VP, _U32, _VP, _VP, _U32]),
     "brt_debug_profile": (_I32, [_VP, C.POINTER(C.c_uint64)]),
     "brt_build_bvh": (_I32, [_VP, _U32, _VP, _U32, C.POINTER(_U32)]),
+    "brt_build_bvh_device": (_I32, [_VP, _VP, _U32, _VP, _U32, C.POINTER(_U32), C.POINTER(C.c_double)]),
     "brt_validate_scene": (_I32, [_VP, _U32, _VP, _U32, _VP, _U32, C.POINTER(_U32)]),
     "brt_scene_generate": (_I32, [_U32, C.c_uint64, _VP, _VP, _U32, C.POINTER(_U32)]),
     "brt_host_camera_extract": (_I32, [C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _F, _F, _F, _F, _U32, _U32, _VP]),

@@ -40,6 +40,11 @@ struct DeviceCtx {
     size_t raster_depth_cap = 0;
     float* h_stage = nullptr;  // pinned
     size_t stage_cap = 0;
+    // GPU BVH build
+    char* d_bvh_scratch = nullptr;
+    size_t bvh_scratch_cap = 0;
+    char* d_bvh_models = nullptr;
+    size_t bvh_models_cap = 0;
 };
 
 }  // namespace
@@ -261,10 +266,40 @@ void free_device(DeviceCtx& dc) {
     if (dc.d_raster_rgba) (void)hipFree(dc.d_raster_rgba);
     if (dc.d_raster_depth) (void)hipFree(dc.d_raster_depth);
     if (dc.h_stage) (void)hipHostFree(dc.h_stage);
+    if (dc.d_bvh_scratch) (void)hipFree(dc.d_bvh_scratch);
+    if (dc.d_bvh_models) (void)hipFree(dc.d_bvh_models);
     if (dc.ev0) (void)hipEventDestroy(dc.ev0);
     if (dc.ev1) (void)hipEventDestroy(dc.ev1);
     if (dc.stream) (void)hipStreamDestroy(dc.stream);
     dc = DeviceCtx();
+}
+
+constexpr uint32_t kMaxGpuBuildModels = 1u << 20;
+
+// PLOC on the context's first device: models (host) -> nodes (host vector), build time in ms.
+int32_t build_bvh_on_device(brt_ctx* ctx, const Model* models, uint32_t n, std::vector<BVHNode>* out, double* build_ms) {
+    out->clear();
+    if (n == 0) return BRT_OK;
+    if (n > kMaxGpuBuildModels) return ctx_fail(ctx, BRT_ERR_UNSUPPORTED, "GPU BVH build supports up to 2^20 spheres");
+    DeviceCtx& dc = ctx->devs[0];
+    HIP_TRY(ctx, hipSetDevice(dc.device));
+    int32_t rc = ensure(ctx, &dc.d_bvh_scratch, &dc.bvh_scratch_cap, ploc_scratch_bytes(n, nullptr));
+    if (rc != BRT_OK) return rc;
+    rc = ensure(ctx, &dc.d_bvh_models, &dc.bvh_models_cap, (size_t)n * sizeof(Model));
+    if (rc != BRT_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(dc.d_bvh_models, models, (size_t)n * sizeof(Model), hipMemcpyHostToDevice, dc.stream));
+    BVHNode* d_out = nullptr;
+    uint32_t* d_info = nullptr;
+    HIP_TRY(ctx, hipEventRecord(dc.ev0, dc.stream));
+    HIP_TRY(ctx, launch_build_ploc(reinterpret_cast<const Model*>(dc.d_bvh_models), n, dc.d_bvh_scratch, &d_out, &d_info, dc.stream));
+    HIP_TRY(ctx, hipEventRecord(dc.ev1, dc.stream));
+    out->resize(2 * (size_t)n - 1);
+    HIP_TRY(ctx, hipMemcpyAsync(out->data(), d_out, out->size() * sizeof(BVHNode), hipMemcpyDeviceToHost, dc.stream));
+    HIP_TRY(ctx, hipStreamSynchronize(dc.stream));
+    float ms = 0.0f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, dc.ev0, dc.ev1));
+    if (build_ms) *build_ms = ms;
+    return BRT_OK;
 }
 
 }  // namespace
@@ -334,8 +369,11 @@ int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, co
     std::vector<BVHNode> built;
     const BVHNode* nodes = static_cast<const BVHNode*>(bvh_nodes);
     if (n_models > 0 && models && (!bvh_nodes || n_nodes == 0)) {
-        int32_t rc = build_bvh_ploc(static_cast<const Model*>(models), n_models, &built);
-        if (rc != BRT_OK) return ctx_fail(ctx, rc, g_last_error);
+        // no BVH from the caller: build it here -- on the GPU (same bytes as the CPU builder)
+        int32_t rc = (n_models <= kMaxGpuBuildModels && env_u32("BRT_CPU_BVH", 0) == 0)
+                         ? build_bvh_on_device(ctx, static_cast<const Model*>(models), n_models, &built, nullptr)
+                         : build_bvh_ploc(static_cast<const Model*>(models), n_models, &built);
+        if (rc != BRT_OK) return rc;
         nodes = built.data();
         n_nodes = (uint32_t)built.size();
     }
@@ -527,6 +565,23 @@ int32_t brt_deinterleave_device(brt_ctx* ctx, const float* d_tiles, uint32_t n_p
     hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : dc.stream;
     HIP_TRY(ctx, launch_deinterleave(d_tiles, d_frame, width, height, n_parts, brt_tile_rows(height, n_parts), stream));
     if (!hip_stream) HIP_TRY(ctx, hipStreamSynchronize(stream));
+    return BRT_OK;
+}
+
+int32_t brt_build_bvh_device(brt_ctx* ctx, const void* models, uint32_t n_models, void* out_nodes, uint32_t capacity,
+                             uint32_t* out_n_nodes, double* out_build_ms) {
+    if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (!out_n_nodes) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "out_n_nodes is null");
+    *out_n_nodes = 0;
+    if (n_models == 0) return BRT_OK;
+    if (!models) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "models is null");
+    std::vector<BVHNode> nodes;
+    int32_t rc = build_bvh_on_device(ctx, static_cast<const Model*>(models), n_models, &nodes, out_build_ms);
+    if (rc != BRT_OK) return rc;
+    *out_n_nodes = (uint32_t)nodes.size();
+    if (nodes.size() > capacity || !out_nodes)
+        return ctx_fail(ctx, BRT_ERR_CAPACITY, "BVH needs " + std::to_string(nodes.size()) + " nodes, capacity " + std::to_string(capacity));
+    std::memcpy(out_nodes, nodes.data(), nodes.size() * sizeof(BVHNode));
     return BRT_OK;
 }
 

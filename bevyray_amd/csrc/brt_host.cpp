@@ -6,6 +6,7 @@
 //   * mirror of the extract stage for non-Rust hosts           (reference extract.rs:63-209)
 // None of this traces rays; there is no CPU rendering path in the product.
 #include "brt_host.h"
+#include "brt_ploc.h"
 
 #include <algorithm>
 #include <cmath>
@@ -147,114 +148,52 @@ int32_t validate_and_encode(const Model* models, uint32_t n_models, const Materi
 }
 
 // ---------------------------------------------------------------------------------------
-// PLOC builder (Meister & Bittner 2018), search radius 24, 63-bit Morton codes.
-// Restates the published algorithm; obvhs 0.1.x itself is not available here, so the
-// topology is this builder's own (pixels do not depend on it).
+// PLOC builder, CPU version (the GPU version in brt_bvh.hip produces the same bytes; both use
+// the arithmetic and the numbering rule of brt_ploc.h).
 // ---------------------------------------------------------------------------------------
-
-namespace {
-
-struct Box {
-    float mn[3], mx[3];
-};
-inline Box merge(const Box& a, const Box& b) {
-    Box r;
-    for (int k = 0; k < 3; k++) { r.mn[k] = std::min(a.mn[k], b.mn[k]); r.mx[k] = std::max(a.mx[k], b.mx[k]); }
-    return r;
-}
-inline float half_area(const Box& b) {
-    float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
-    return dx * dy + dy * dz + dz * dx;
-}
-inline uint64_t spread21(uint64_t x) {
-    x &= 0x1fffffull;
-    x = (x | x << 32) & 0x1f00000000ffffull;
-    x = (x | x << 16) & 0x1f0000ff0000ffull;
-    x = (x | x << 8) & 0x100f00f00f00f00full;
-    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
-    x = (x | x << 2) & 0x1249249249249249ull;
-    return x;
-}
-
-struct TmpNode {
-    Box box;
-    int32_t left, right;   // children in tmp array, or -1
-    uint32_t prim;         // for leaves
-};
-
-}  // namespace
 
 int32_t build_bvh_ploc(const Model* models, uint32_t n_models, std::vector<BVHNode>* out) {
     out->clear();
     if (n_models == 0) return BRT_OK;
-    constexpr int SEARCH = 24;  // build_ploc::<24>, extract.rs:316
-
-    std::vector<TmpNode> tmp;
-    tmp.reserve(2 * (size_t)n_models);
-    Box scene;
-    for (int k = 0; k < 3; k++) { scene.mn[k] = std::numeric_limits<float>::infinity(); scene.mx[k] = -scene.mn[k]; }
-    for (uint32_t i = 0; i < n_models; i++) {
-        TmpNode t;
-        const float pad = models[i].radius + 0.1f;  // Model::aabb, extract.rs:220-227
-        for (int k = 0; k < 3; k++) { t.box.mn[k] = models[i].position[k] - pad; t.box.mx[k] = models[i].position[k] + pad; }
-        t.left = t.right = -1;
-        t.prim = i;
-        tmp.push_back(t);
-        scene = merge(scene, t.box);
+    const uint32_t n = n_models;
+    std::vector<PlocBox> box(2 * (size_t)n - 1);
+    std::vector<int32_t> left(2 * (size_t)n - 1, -1), right(2 * (size_t)n - 1, -1);
+    PlocBox scene = ploc_model_box(models[0].position, models[0].radius);
+    for (uint32_t i = 0; i < n; i++) {
+        box[i] = ploc_model_box(models[i].position, models[i].radius);
+        scene = ploc_merge(scene, box[i]);
     }
-    // Morton codes of the AABB centres, 21 bits per axis
-    std::vector<std::pair<uint64_t, uint32_t>> keys(n_models);
-    double ext[3];
-    for (int k = 0; k < 3; k++) ext[k] = std::max(1e-30, (double)scene.mx[k] - (double)scene.mn[k]);
-    for (uint32_t i = 0; i < n_models; i++) {
-        uint64_t q[3];
-        for (int k = 0; k < 3; k++) {
-            double c = 0.5 * ((double)tmp[i].box.mn[k] + (double)tmp[i].box.mx[k]);
-            double u = (c - (double)scene.mn[k]) / ext[k];
-            if (!(u > 0.0)) u = 0.0;
-            if (u > 1.0) u = 1.0;
-            q[k] = (uint64_t)(u * 2097151.0);
-        }
-        keys[i] = {spread21(q[0]) | (spread21(q[1]) << 1) | (spread21(q[2]) << 2), i};
-    }
-    std::stable_sort(keys.begin(), keys.end());
+    std::vector<std::pair<uint64_t, uint32_t>> keys(n);
+    for (uint32_t i = 0; i < n; i++) keys[i] = {ploc_morton(box[i], scene), i};
+    std::sort(keys.begin(), keys.end());   // (code, index): a strict total order
 
-    std::vector<int32_t> cur(n_models), next;
-    for (uint32_t i = 0; i < n_models; i++) cur[i] = (int32_t)keys[i].second;
-    std::vector<int32_t> nn;
+    std::vector<int32_t> cur(n), next, nn;
+    for (uint32_t i = 0; i < n; i++) cur[i] = (int32_t)keys[i].second;
+    uint32_t created = n;
     while (cur.size() > 1) {
-        const int32_t n = (int32_t)cur.size();
-        nn.assign(n, -1);
-        for (int32_t i = 0; i < n; i++) {
-            // Nearest neighbour under the strict total order (area, min(i,j), max(i,j)): the
-            // globally smallest pair is then always mutual, so every round merges something.
-            float best = std::numeric_limits<float>::infinity();
+        const int32_t m = (int32_t)cur.size();
+        nn.assign(m, -1);
+        for (int32_t i = 0; i < m; i++) {
+            float best = 0.0f;
             int32_t bj = -1;
-            const int32_t lo = std::max(0, i - SEARCH), hi = std::min(n - 1, i + SEARCH);
+            const int32_t lo = std::max(0, i - PLOC_SEARCH), hi = std::min(m - 1, i + PLOC_SEARCH);
             for (int32_t j = lo; j <= hi; j++) {
                 if (j == i) continue;
-                float a = half_area(merge(tmp[cur[i]].box, tmp[cur[j]].box));
-                bool better = a < best;
-                if (!better && a == best && bj >= 0) {
-                    const int32_t p0 = std::min(i, j), p1 = std::max(i, j), q0 = std::min(i, bj), q1 = std::max(i, bj);
-                    better = p0 < q0 || (p0 == q0 && p1 < q1);
-                }
-                if (better || bj < 0) { best = a; bj = j; }
+                const float a = ploc_half_area(ploc_merge(box[cur[i]], box[cur[j]]));
+                if (ploc_better(a, i, j, best, bj)) { best = a; bj = j; }
             }
             nn[i] = bj;
         }
         next.clear();
-        for (int32_t i = 0; i < n; i++) {
+        for (int32_t i = 0; i < m; i++) {
             const int32_t j = nn[i];
             if (nn[j] == i) {
                 if (i < j) {
-                    TmpNode t;
-                    t.box = merge(tmp[cur[i]].box, tmp[cur[j]].box);
-                    t.left = cur[i];
-                    t.right = cur[j];
-                    t.prim = 0;
-                    tmp.push_back(t);
-                    next.push_back((int32_t)tmp.size() - 1);
+                    box[created] = ploc_merge(box[cur[i]], box[cur[j]]);
+                    left[created] = cur[i];
+                    right[created] = cur[j];
+                    next.push_back((int32_t)created);
+                    created++;
                 }
             } else {
                 next.push_back(cur[i]);
@@ -263,27 +202,20 @@ int32_t build_bvh_ploc(const Model* models, uint32_t n_models, std::vector<BVHNo
         cur.swap(next);
     }
 
-    // Flatten breadth-first: node 0 = root, the two children of an interior node adjacent.
-    out->resize(tmp.size());
-    std::vector<std::pair<int32_t, uint32_t>> queue;  // (tmp index, output slot)
-    queue.reserve(tmp.size());
-    queue.push_back({cur[0], 0u});
-    uint32_t next_slot = 1;
-    for (size_t head = 0; head < queue.size(); head++) {
-        const TmpNode& t = tmp[queue[head].first];
-        BVHNode& o = (*out)[queue[head].second];
+    // numbering rule of brt_ploc.h: root = the last cluster; children of rank r at 1+2r, 2+2r
+    out->resize(2 * (size_t)n - 1);
+    auto write = [&](uint32_t slot, int32_t t) {
+        BVHNode& o = (*out)[slot];
         std::memset(&o, 0, sizeof o);
-        for (int k = 0; k < 3; k++) { o.bounds_min[k] = t.box.mn[k]; o.bounds_max[k] = t.box.mx[k]; }
-        if (t.left < 0) {
-            o.index = t.prim;      // indexes the model buffer directly (extract.rs:318,329)
-            o.model_count = 1;
-        } else {
-            o.index = next_slot;
-            o.model_count = 0;
-            queue.push_back({t.left, next_slot});
-            queue.push_back({t.right, next_slot + 1});
-            next_slot += 2;
-        }
+        for (int k = 0; k < 3; k++) { o.bounds_min[k] = box[t].mn[k]; o.bounds_max[k] = box[t].mx[k]; }
+        if (left[t] < 0) { o.index = (uint32_t)t; o.model_count = 1; }          // leaf: model id (extract.rs:318,329)
+        else { o.index = 1u + 2u * ((2u * n - 2u) - (uint32_t)t); o.model_count = 0; }
+    };
+    write(0, (int32_t)(2 * n - 2));
+    for (uint32_t t = n; t < 2 * n - 1; t++) {
+        const uint32_t r = (2 * n - 2) - t;
+        write(1 + 2 * r, left[t]);
+        write(2 + 2 * r, right[t]);
     }
     return BRT_OK;
 }

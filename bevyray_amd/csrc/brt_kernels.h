@@ -36,4 +36,11 @@ hipError_t launch_deinterleave(const float* tiles, float* frame, uint32_t width,
                                uint32_t tile_rows, hipStream_t stream);
 hipError_t launch_debug_eval(uint32_t op, const float* in, float* out, uint32_t n, hipStream_t stream);
 
+// GPU PLOC builder (brt_bvh.hip): scratch size for n models, and the launch; *d_out / *d_info
+// point into the scratch (nodes in the reference's 48-byte format; info[0] = node count,
+// info[1] = PLOC rounds)
+size_t ploc_scratch_bytes(uint32_t n, uint32_t* n_pow2_out);
+hipError_t launch_build_ploc(const Model* d_models, uint32_t n, char* d_scratch, BVHNode** d_out, uint32_t** d_info,
+                             hipStream_t stream);
+
 }  // namespace brt

@@ -177,6 +177,12 @@ int32_t brt_debug_profile(brt_ctx* ctx, uint64_t* out32);
 int32_t brt_build_bvh(const void* models, uint32_t n_models,
                       void* out_nodes, uint32_t capacity, uint32_t* out_n_nodes);
 
+/* The same build on the GPU (PLOC in one workgroup, bevyray_amd/csrc/brt_bvh.hip): takes the
+ * host model vector, returns byte-identical nodes to brt_build_bvh plus the kernel time.
+ * brt_upload_scene uses it when the caller passes no BVH.  Needs a context (a GPU). */
+int32_t brt_build_bvh_device(brt_ctx* ctx, const void* models, uint32_t n_models,
+                             void* out_nodes, uint32_t capacity, uint32_t* out_n_nodes, double* out_build_ms);
+
 /* Checks what brt_upload_scene checks, without a context. */
 int32_t brt_validate_scene(const void* models, uint32_t n_models,
                            const void* materials, uint32_t n_materials,

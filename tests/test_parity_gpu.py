@@ -324,3 +324,32 @@ def test_config2_full_size_properties(plugin, oracle):
     for r0 in (0, 405, 700, 1076):
         want, _ = oracle.render(b, lvl, cam, win, w, h, rows=(r0, r0 + 3))
         assert_frames_equal(f1[r0:r0 + 3], want[r0:r0 + 3])
+
+
+# ---- GPU BVH build --------------------------------------------------------------------
+
+def test_gpu_ploc_build_is_byte_identical_to_cpu_build(plugin, oracle):
+    rng = np.random.default_rng(11)
+    scenes = [brt.generate_scene(brt.SCENE_COVER, s).models for s in (1, 2, 3)]
+    scenes += [brt.generate_scene(brt.SCENE_RTIOW_FINAL, 1).models, brt.generate_scene(brt.SCENE_STRESS_GRID, 1).models]
+    for n in (1, 2, 3, 5, 24, 25, 26, 49, 50, 51, 1023, 1024, 1025):
+        m = np.zeros(n, brt.MODEL_DTYPE)
+        m["position"] = rng.uniform(-20, 20, (n, 3)).astype(np.float32)
+        m["radius"] = rng.uniform(0.05, 2.0, n).astype(np.float32)
+        scenes.append(m)
+    dup = np.zeros(300, brt.MODEL_DTYPE); dup["position"] = (1.0, 2.0, 3.0); dup["radius"] = 0.5    # all Morton codes and areas tie
+    line = np.zeros(200, brt.MODEL_DTYPE); line["position"][:, 0] = np.arange(200, dtype=np.float32); line["radius"] = 0.25
+    scenes += [dup, line]
+    for models in scenes:
+        cpu = brt.build_bvh(models)
+        gpu, ms = plugin.build_bvh(models)
+        assert len(cpu) == len(gpu) == 2 * len(models) - 1
+        assert np.array_equal(cpu.view(np.uint8), gpu.view(np.uint8)), f"n={len(models)}"
+        assert ms >= 0.0
+    # and the callee-built path renders the same pixels as the caller-built one
+    b = brt.generate_scene(brt.SCENE_STRESS_GRID, 1)
+    lvl, cam, win = brt.cover_camera(96, 54, 2, 4)
+    f1 = plugin.node.run(lvl, cam, win, 96, 54, buffers=b, flags=brt.FLAG_COUNTERS)
+    s1 = dict(plugin.node.last_stats)
+    f2 = plugin.node.run(lvl, cam, win, 96, 54, buffers=brt.Buffers(b.models, b.materials, None), flags=brt.FLAG_COUNTERS)
+    assert_frames_equal(f1, f2) and all(plugin.node.last_stats[k] == s1[k] for k in COUNTER_KEYS)
