@@ -136,8 +136,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_trace_persistent", "kernel_ms": mean_kernel_ms, "algorithmic_bytes_per_launch": alg,
-                         "note": "scene is LDS resident: the kernel is VALU/LDS-latency bound, HBM traffic is the "
-                                 "scene load per workgroup + one 16-B store per pixel"},
+                         "note": "scene is LDS resident and ray state lives in registers: HBM traffic is the scene load "
+                                 "per workgroup + one 16-B store per pixel, the kernel is bound by VALU/scalar issue "
+                                 "under divergence (DESIGN.md section 5), so achieved algorithmic bytes exceed the HBM peak"},
             "kernel": {"lds_bytes": counted["lds_bytes"], "scene_in_lds": counted["scene_in_lds"],
                        "workgroups": counted["n_workgroups"], "threads": counted["threads_per_workgroup"]},
         }
@@ -157,7 +158,7 @@ def cpu_baseline(buffers, lvl, cam, win, W, H, gpu_frame, target_seconds):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_loader
     oracle = oracle_loader.load()
-    cores = os.cpu_count() or 1
+    cores = oracle_loader.usable_cores()
     probe_rows = list(range(3, H, max(1, H // 8)))[:8]
     t0 = time.perf_counter()
     _, cnt = oracle.render(buffers, lvl, cam, win, W, H, rows=(3, H), row_step=max(1, H // 8), threads=cores)
@@ -173,7 +174,8 @@ def cpu_baseline(buffers, lvl, cam, win, W, H, gpu_frame, target_seconds):
     exact = bool(np.array_equal(g[sampled].view(np.uint32), frame[sampled].view(np.uint32)))
     return {"value": cnt["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": f"every {row_step}th row of the same 1920x1080x64spp frame ({len(sampled)} rows, {cnt['rays']} rays, "
-                      f"{dt:.1f} s wall on {cores} threads); scalar C restatement of the WGSL loop (no Rust toolchain here)",
+                      f"{dt:.1f} s wall on {cores} threads = the CPUs granted to this process; {os.cpu_count()} logical CPUs on the host); "
+                      f"scalar C restatement of the WGSL loop (no Rust toolchain here)",
             "gpu_rows_bit_exact": exact}
 
 

@@ -443,25 +443,28 @@ static void fragment(const Scene* s, uint32_t px, uint32_t py, uint32_t W, uint3
 
 float oracle_tan_half_fov(float fov) { return (float)tan((double)(fov * 0.5f)); }
 
+/* Work items are 64-pixel spans of a row, taken from a shared atomic counter, so that a few
+ * hundred threads stay busy to the end (rows differ a lot in cost: sky vs ground). */
+#define SPAN 64u
 typedef struct {
     const Scene* s;
-    uint32_t W, H, row_begin, row_end, row_step;
+    uint32_t W, H, row_begin, row_step, n_rows, spans_per_row;
     const float* raster_rgba; const float* raster_depth;
     float* out_rgba;
-    uint32_t* next_row;     /* shared work counter */
-    pthread_mutex_t* mu;
+    uint32_t* next_item;    /* shared work counter */
     Counters cnt;
 } Job;
 
 static void* worker(void* arg) {
     Job* j = (Job*)arg;
+    const uint32_t total = j->n_rows * j->spans_per_row;
     for (;;) {
-        pthread_mutex_lock(j->mu);
-        uint32_t row = *j->next_row;
-        *j->next_row = row + j->row_step;
-        pthread_mutex_unlock(j->mu);
-        if (row >= j->row_end) break;
-        for (uint32_t px = 0; px < j->W; px++)
+        uint32_t item = __atomic_fetch_add(j->next_item, 1u, __ATOMIC_RELAXED);
+        if (item >= total) break;
+        uint32_t row = j->row_begin + (item / j->spans_per_row) * j->row_step;
+        uint32_t x0 = (item % j->spans_per_row) * SPAN;
+        uint32_t x1 = x0 + SPAN < j->W ? x0 + SPAN : j->W;
+        for (uint32_t px = x0; px < x1; px++)
             fragment(j->s, px, row, j->W, j->H, j->raster_rgba, j->raster_depth,
                      j->out_rgba + 4 * ((size_t)row * j->W + px), &j->cnt);
     }
@@ -486,16 +489,17 @@ int oracle_render_strided(const void* models, uint32_t n_models, const void* mat
     s.tan_half_fov = oracle_tan_half_fov(s.camera.fov);
 
     if (n_threads < 1) n_threads = 1;
-    if (n_threads > 256) n_threads = 256;
-    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
-    uint32_t next_row = row_begin;
+    if (n_threads > 1024) n_threads = 1024;
+    uint32_t next_item = 0;
+    uint32_t n_rows = row_end > row_begin ? (row_end - row_begin + row_step - 1) / row_step : 0;
     Job* jobs = (Job*)calloc((size_t)n_threads, sizeof(Job));
     pthread_t* th = (pthread_t*)calloc((size_t)n_threads, sizeof(pthread_t));
     for (int i = 0; i < n_threads; i++) {
         jobs[i].s = &s; jobs[i].W = width; jobs[i].H = height;
-        jobs[i].row_begin = row_begin; jobs[i].row_end = row_end; jobs[i].row_step = row_step;
+        jobs[i].row_begin = row_begin; jobs[i].row_step = row_step; jobs[i].n_rows = n_rows;
+        jobs[i].spans_per_row = (width + SPAN - 1) / SPAN;
         jobs[i].raster_rgba = raster_rgba; jobs[i].raster_depth = raster_depth;
-        jobs[i].out_rgba = out_rgba; jobs[i].next_row = &next_row; jobs[i].mu = &mu;
+        jobs[i].out_rgba = out_rgba; jobs[i].next_item = &next_item;
     }
     if (n_threads == 1) worker(&jobs[0]);
     else {

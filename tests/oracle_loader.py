@@ -12,6 +12,30 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB = os.path.join(ORACLE_DIR, "libbevyray_oracle.so")
 
 
+def usable_cores():
+    """CPU cores this process may actually use: the affinity mask, capped by the cgroup CPU quota
+    (the GPU boxes report 256 logical CPUs but grant e.g. 16 via cpu.max; more threads than
+    that only get throttled)."""
+    import math
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, math.ceil(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, math.ceil(q / period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+
 def build(force=False):
     src = os.path.join(ORACLE_DIR, "bevyray_oracle.c")
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
@@ -64,7 +88,7 @@ class Oracle:
         rr = None if raster_rgba is None else np.ascontiguousarray(raster_rgba, np.float32)
         rd = None if raster_depth is None else np.ascontiguousarray(raster_depth, np.float32)
         if threads is None:
-            threads = os.cpu_count() or 1
+            threads = usable_cores()
         rc = self.lib.oracle_render_strided(models.ctypes.data, len(models), materials.ctypes.data, len(materials),
                                     bvh.ctypes.data, len(bvh), camera.ctypes.data, window.ctypes.data,
                                     int(level["level"][0]), width, height, r0, r1, row_step,

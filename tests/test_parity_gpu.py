@@ -353,3 +353,34 @@ def test_gpu_ploc_build_is_byte_identical_to_cpu_build(plugin, oracle):
     s1 = dict(plugin.node.last_stats)
     f2 = plugin.node.run(lvl, cam, win, 96, 54, buffers=brt.Buffers(b.models, b.materials, None), flags=brt.FLAG_COUNTERS)
     assert_frames_equal(f1, f2) and all(plugin.node.last_stats[k] == s1[k] for k in COUNTER_KEYS)
+
+
+# ---- launch-shape and scheduling knobs must never change a pixel -------------------------------------------------
+
+@pytest.mark.parametrize("env", [
+    {"BRT_BLOCK_THREADS": "512", "BRT_WG_PER_CU": "2"}, {"BRT_BLOCK_THREADS": "256", "BRT_WG_PER_CU": "1"},
+    {"BRT_FORCE_GLOBAL_SCENE": "1"}, {"BRT_REFILL_MIN": "64"}, {"BRT_REFILL_MIN": "17", "BRT_BOTTOM_UP": "1"},
+    {"BRT_CPU_BVH": "1"},
+])
+def test_tuning_knobs_do_not_change_results(plugin, oracle, env):
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    lvl, cam, win = brt.cover_camera(120, 68, 3, 6, brt.Raytracing.Pure, 0.25)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        bb = brt.Buffers(b.models, b.materials, None) if "BRT_CPU_BVH" in env else b
+        got = plugin.node.run(lvl, cam, win, 120, 68, buffers=bb, flags=brt.FLAG_COUNTERS)
+        stats = dict(plugin.node.last_stats)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    want, cnt = oracle.render(b, lvl, cam, win, 120, 68)
+    assert_frames_equal(got, want)
+    assert {k: stats[k] for k in COUNTER_KEYS} == cnt
+    if "BRT_FORCE_GLOBAL_SCENE" in env:
+        assert stats["scene_in_lds"] == 0
+    if "BRT_BLOCK_THREADS" in env:
+        assert stats["threads_per_workgroup"] == int(env["BRT_BLOCK_THREADS"])
