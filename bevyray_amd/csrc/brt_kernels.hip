@@ -262,12 +262,15 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             atomicAdd(&counters[3], (unsigned long long)c);
         }
     }
-    const uint32_t h = wave_sum(hc.hits);
-    if (COUNTERS && lane == 0) {
-        atomicAdd(&counters[4], (unsigned long long)h);
-        for (int k = 0; k < 8; k++) {
-            atomicAdd(&counters[8 + 2 * k], (unsigned long long)hc.sec_exec[k]);
-            atomicAdd(&counters[9 + 2 * k], (unsigned long long)hc.sec_lanes[k]);
+    if (COUNTERS) {
+        const uint32_t h = wave_sum(hc.hits);
+        if (lane == 0) atomicAdd(&counters[4], (unsigned long long)h);
+        for (int k = 0; k < 8; k++) {   // each execution was booked by ONE lane of the wave: sum over lanes
+            const uint32_t e = wave_sum(hc.sec_exec[k]), l = wave_sum(hc.sec_lanes[k]);
+            if (lane == 0) {
+                atomicAdd(&counters[8 + 2 * k], (unsigned long long)e);
+                atomicAdd(&counters[9 + 2 * k], (unsigned long long)l);
+            }
         }
     }
 }

@@ -18,6 +18,10 @@ with brt.RaytracePlugin([0]) as p:
             for _ in range(3):
                 st = p.node.render_part_device(lvl, cam, win, W, H, part, n, tile.data_ptr())
                 best = st if best is None or st["kernel_ms"] < best["kernel_ms"] else best
+        cs = p.node.render_part_device(lvl, cam, win, W, H, 0, n, tile.data_ptr(), flags=brt.FLAG_COUNTERS)
+        prof = p.debug_profile()
+        rl = prof["round"]; it = prof["interior"]
+        print(f"      rounds {rl[0]:9d} avg live lanes {rl[1]/max(1,rl[0]):5.1f}; interior execs {it[0]:10d} avg lanes {it[1]/max(1,it[0]):5.1f}")
         full = 27.5
         print(f"n_parts {n:2d}: kernel {best['kernel_ms']:7.3f} ms  rays {best['rays']:10d}  {best['rays']/best['kernel_ms']/1e3:8.1f} Mrays/s  "
               f"grid {best['n_workgroups']}x{best['threads_per_workgroup']}  ideal {full/n:6.3f} ms", flush=True)

@@ -384,3 +384,44 @@ def test_tuning_knobs_do_not_change_results(plugin, oracle, env):
         assert stats["scene_in_lds"] == 0
     if "BRT_BLOCK_THREADS" in env:
         assert stats["threads_per_workgroup"] == int(env["BRT_BLOCK_THREADS"])
+
+
+# ---- randomized scenes: materials, sizes, cameras, topologies -------------------------------------------------------
+
+def _random_case(rng):
+    n = int(rng.integers(1, 60))
+    data = []
+    for _ in range(n):
+        kind = rng.random()
+        mat = brt.StandardMaterial(base_color=tuple(float(x) for x in rng.random(3)),
+                                   metallic=float(rng.choice([0.0, 1.0, rng.random()])),
+                                   perceptual_roughness=float(rng.choice([0.0, 0.5, rng.random()])),
+                                   ior=float(rng.uniform(0.5, 2.5)),
+                                   specular_transmission=float(rng.choice([0.0, 1.0, rng.random()])))
+        r = float(rng.uniform(0.05, 1.5)) if kind < 0.9 else float(rng.uniform(20, 200))
+        pos = tuple(float(x) for x in rng.uniform(-4, 4, 3)) if kind < 0.9 else (float(rng.uniform(-3, 3)), -r - 1.0, float(rng.uniform(-3, 3)))
+        data.append((pos, r, mat))
+    topo = rng.integers(0, 4)
+    bvh_fn = [None, single_leaf_bvh, lambda m: median_split_bvh(m, int(rng.integers(1, 5))), chain_bvh][topo]
+    if bvh_fn is chain_bvh and n < 2:
+        bvh_fn = single_leaf_bvh
+    b = make_buffers(data, bvh_fn)
+    w, h = int(rng.integers(1, 70)), int(rng.integers(1, 50))
+    pos = tuple(float(x) for x in rng.uniform(-8, 8, 3))
+    lvl, cam, win = uniforms(w, h, spp=int(rng.integers(1, 6)), bounces=int(rng.integers(0, 12)), pos=pos,
+                             target=tuple(float(x) for x in rng.uniform(-1, 1, 3)), fov=float(rng.uniform(0.2, 1.5)),
+                             seed=float(np.float32(rng.random())), level=brt.Raytracing(int(rng.integers(1, 4))),
+                             window_height=int(rng.integers(1, 1200)))
+    return b, lvl, cam, win, w, h
+
+
+def test_randomized_scenes_bit_exact(plugin, oracle):
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        b, lvl, cam, win, w, h = _random_case(rng)
+        raster = rng.random((h, w, 4), dtype=np.float32) if case % 3 == 0 else None
+        depth = (rng.random((h, w), dtype=np.float32) * np.float32(0.05)) if case % 3 == 0 else None
+        try:
+            render_both(plugin, oracle, b, lvl, cam, win, w, h, raster=raster, depth=depth)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: {len(b.models)} spheres, {len(b.bvh)} nodes, {w}x{h}: {e}")
