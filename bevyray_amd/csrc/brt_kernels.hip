@@ -21,6 +21,7 @@
 // k_debug_eval        evaluates single device functions for per-function parity tests.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "brt_device.h"
@@ -232,6 +233,20 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         }
         float t = kInf;
         uint32_t idx = 0xffffffffu;
+        if (COUNTERS) {   // diagnostic ray dump for the trace microbenchmark (brt_debug_trace_bench)
+            float* dump = reinterpret_cast<float*>(counters[24]);
+            if (dump != nullptr) {
+                const uint64_t m = __ballot(active);
+                unsigned long long base = 0;
+                if (active && mbcnt64(m) == 0) base = atomicAdd(&counters[26], (unsigned long long)__popcll(m));
+                base = __shfl(base, (int)(__ffsll((long long)m) - 1), 64);
+                const unsigned long long slot = base + mbcnt64(m);
+                if (active && slot < counters[25]) {
+                    float* r = dump + slot * 8;
+                    r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z; r[6] = 0.0f; r[7] = 0.0f;
+                }
+            }
+        }
         if (active) raycast<64, COUNTERS, D16, SIMPLE>(sc, sv.root_desc, stk, sv.stack_entries, o, d, t, idx, hc);
         prof_section<COUNTERS>(hc, SEC_SCATTER, active && t != kInf);
         prof_section<COUNTERS>(hc, SEC_SKY, active && t == kInf);
@@ -273,6 +288,127 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             }
         }
     }
+}
+
+// ---- trace-only microbenchmark (diagnostic) ----------------------------------------------------------
+// Walks a buffer of recorded rays (8 floats each: o, d, 2 pad), writes (t, idx) per ray.  Models the
+// trace phase of a workgroup-local ray pool: the scene AND a chunk of BENCH_CHUNK rays are staged in
+// LDS; a lane that finishes its ray takes the next one from the chunk (LDS atomic, wave-aggregated)
+// as soon as refill_min lanes of its wave are idle.  refill_min = 64 is the behaviour of
+// k_trace_persistent's rounds (64 rays per wave walked to completion).
+__global__ __launch_bounds__(BRT_BLOCK) void k_bench_trace(DeviceSceneView sv, const float4* __restrict__ rays, uint32_t n_rays,
+                                                          uint32_t refill_min, uint32_t BENCH_CHUNK, float2* __restrict__ out,
+                                                          unsigned long long* __restrict__ prof) {
+    using DS = Desc<true>;
+    extern __shared__ uint4 smem[];
+    ScenePtrs sc;
+    float4* p = reinterpret_cast<float4*>(smem);
+    float4* l_q0 = p; p += sv.n_pairs;
+    float4* l_q1 = p; p += sv.n_pairs;
+    float4* l_q2 = p; p += sv.n_pairs;
+    float4* l_sp = p; p += sv.n_models;
+    float4* l_ra = p; p += BENCH_CHUNK;          // ray chunk: {o.xyz, d.x}
+    uint2* p2 = reinterpret_cast<uint2*>(p);
+    uint2* l_rb = p2; p2 += BENCH_CHUNK;         //            {d.y, d.z}
+    uint2* l_qd = p2; p2 += sv.n_pairs;
+    uint32_t* p1 = reinterpret_cast<uint32_t*>(p2);
+    uint32_t* l_head = p1; p1 += 4;
+    uint16_t* stacks = reinterpret_cast<uint16_t*>(p1);
+    for (uint32_t i = threadIdx.x; i < sv.n_pairs; i += blockDim.x) {
+        l_q0[i] = reinterpret_cast<const float4*>(sv.q0)[i]; l_q1[i] = reinterpret_cast<const float4*>(sv.q1)[i];
+        l_q2[i] = reinterpret_cast<const float4*>(sv.q2)[i]; l_qd[i] = reinterpret_cast<const uint2*>(sv.qd)[i];
+    }
+    for (uint32_t i = threadIdx.x; i < sv.n_models; i += blockDim.x) l_sp[i] = reinterpret_cast<const float4*>(sv.spheres)[i];
+    sc.q0 = l_q0; sc.q1 = l_q1; sc.q2 = l_q2; sc.qd = l_qd; sc.spheres = l_sp;
+    sc.sphere_material = sv.sphere_material; sc.materials = nullptr; sc.leaf_table = nullptr;
+    const uint32_t lane = lane_id();
+    uint16_t* stk = stacks + (threadIdx.x >> 6) * ((sv.stack_entries + 1u) * 64u) + lane;
+    const uint32_t dummy = sv.stack_entries;
+    uint32_t iters = 0, lanes = 0;
+
+    for (uint32_t chunk = blockIdx.x * BENCH_CHUNK; chunk < n_rays; chunk += gridDim.x * BENCH_CHUNK) {
+        const uint32_t cnt = (n_rays - chunk < BENCH_CHUNK) ? n_rays - chunk : BENCH_CHUNK;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const float4 a = rays[2 * (chunk + i)], b = rays[2 * (chunk + i) + 1];
+            l_ra[i] = a;
+            l_rb[i] = make_uint2(__float_as_uint(b.x), __float_as_uint(b.y));
+        }
+        if (threadIdx.x == 0) l_head[0] = 0u;
+        __syncthreads();
+
+        f3 o = mk3(0, 0, 0), inv = mk3(1, 1, 1), d = mk3(0, 0, 1);
+        float a = 1.0f, closest = kInf;
+        uint32_t closest_idx = 0xffffffffu, cur = DS::DONE, n = 0, ray_id = 0xffffffffu;
+        bool exhausted = false;
+        for (;;) {
+            // ---- checkpoint: flush finished lanes, refill idle ones from the LDS chunk ----
+            const bool idle = (cur == DS::DONE);
+            const uint64_t mi = __ballot(idle);
+            const uint32_t ci = (uint32_t)__popcll(mi);
+            if (ci == 64u || (ci >= refill_min && !exhausted)) {
+                if (idle && ray_id != 0xffffffffu) { out[chunk + ray_id] = make_float2(closest, __uint_as_float(closest_idx)); ray_id = 0xffffffffu; }
+                if (!exhausted) {
+                    uint32_t base = 0;
+                    if (idle && mbcnt64(mi) == 0) base = atomicAdd(&l_head[0], ci);
+                    base = __shfl(base, (int)(__ffsll((long long)mi) - 1), 64);
+                    if (base + ci >= cnt) exhausted = true;
+                    const uint32_t r = base + mbcnt64(mi);
+                    if (idle && r < cnt) {
+                        const float4 ra = l_ra[r];
+                        const uint2 rb = l_rb[r];
+                        o = mk3(ra.x, ra.y, ra.z); d = mk3(ra.w, __uint_as_float(rb.x), __uint_as_float(rb.y));
+                        a = dot3(d, d);
+                        inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        closest = kInf; closest_idx = 0xffffffffu; cur = sv.root_desc; n = 0; ray_id = r;
+                    }
+                }
+                if (__ballot(cur != DS::DONE) == 0ull) break;
+            }
+            // ---- one walk step for every walking lane (the bodies of raycast) ----
+            iters++;
+            lanes += (uint32_t)__popcll(__ballot(cur != DS::DONE));
+            if (cur != DS::DONE) {
+                if (cur & DS::LEAF) {
+                    const uint32_t first = cur & DS::INDEX_MASK;
+                    sphere_test(o, d, a, sc.spheres[first], first, closest, closest_idx);
+                    const bool has = n > 0u;
+                    n = has ? n - 1u : 0u;
+                    const uint32_t popped = stk[n * 64];
+                    cur = has ? popped : DS::DONE;
+                } else {
+                    const float4 A = sc.q0[cur], B = sc.q1[cur], C = sc.q2[cur];
+                    const uint2 D = sc.qd[cur];
+                    const bool p1 = slab_push(o, inv, mk3(A.x, A.y, A.z), mk3(A.w, B.x, B.y), closest);
+                    const bool p2b = slab_push(o, inv, mk3(B.z, B.w, C.x), mk3(C.y, C.z, C.w), closest);
+                    const bool both = p1 && p2b, none = !p1 && !p2b;
+                    stk[(both ? n : dummy) * 64] = (uint16_t)D.x;
+                    const bool can_pop = none && n > 0u;
+                    const uint32_t popped = stk[(n > 0u ? n - 1u : 0u) * 64];
+                    cur = p2b ? D.y : (p1 ? D.x : (can_pop ? popped : DS::DONE));
+                    n = both ? n + 1u : (can_pop ? n - 1u : n);
+                }
+            }
+        }
+    }
+    if (lane == 0) { atomicAdd(&prof[0], (unsigned long long)iters); atomicAdd(&prof[1], (unsigned long long)lanes); }
+}
+
+hipError_t launch_bench_trace(int mode, const DeviceSceneView& sv, const float* rays, uint32_t n_rays, uint32_t refill_min,
+                              uint32_t* queue_counter, float* out, unsigned long long* prof, uint32_t grid, hipStream_t stream) {
+    (void)queue_counter;
+    if (!sv.desc16 || !sv.simple_tree) return hipErrorInvalidValue;   // microbenchmark: 16-bit descriptors, simple trees
+    const char* eb = getenv("BRT_BENCH_BLOCK");
+    const char* ec = getenv("BRT_BENCH_CHUNK");
+    const uint32_t block = eb ? (uint32_t)atoi(eb) : (uint32_t)BRT_BLOCK;
+    const uint32_t chunk = ec ? (uint32_t)atoi(ec) : 2048u;
+    const size_t lds = (size_t)sv.n_pairs * 56 + (size_t)sv.n_models * 16 + (size_t)chunk * 24 + 16 +
+                       (size_t)(block / 64) * (sv.stack_entries + 1) * 64 * 2;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bench_trace), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_bench_trace, dim3(grid), dim3(block), lds, stream, sv, reinterpret_cast<const float4*>(rays), n_rays,
+                       mode == 0 ? 64u : refill_min, chunk, reinterpret_cast<float2*>(out), prof);
+    return hipGetLastError();
 }
 
 // ---- bring-up kernel ---------------------------------------------------------------------------
