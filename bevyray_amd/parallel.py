@@ -44,11 +44,11 @@ def gather_frame(tile, height: int, rank: int, world: int, node=None, group=None
     if world == 1:
         tiles = tile.unsqueeze(0)
     else:
-        gather_list = [torch.empty_like(tile) for _ in range(world)] if rank == 0 else None
-        dist.gather(tile, gather_list, dst=0, group=group)
+        # receive straight into one [world, rows, W, 4] buffer (the layout the de-interleave kernel reads)
+        tiles = torch.empty((world,) + tuple(tile.shape), dtype=tile.dtype, device=tile.device) if rank == 0 else None
+        dist.gather(tile, list(tiles.unbind(0)) if rank == 0 else None, dst=0, group=group)
         if rank != 0:
             return None
-        tiles = torch.stack(gather_list, 0)
     if tiles.is_cuda:
         if node is None:
             raise RuntimeError("gather_frame on CUDA tensors needs the RayTracingNode (de-interleave kernel)")
