@@ -19,7 +19,9 @@
  * instead: (1) integer known-answer vectors for the RNG and the seed formula,
  * produced by an independent numpy restatement (tests/golden/make_golden.py);
  * (2) analytic single-ray cases derived from the WGSL (tests/test_oracle.py);
- * (3) brute-force (single-leaf BVH) == BVH traversal on this same code.
+ * (3) whole tiny frames from a second, independent restatement of the shader in
+ * numpy f32 scalars (tests/golden/numpy_restatement.py), reproduced bit for bit;
+ * (4) brute-force (single-leaf BVH) == BVH traversal on this same code.
  *
  * Numeric policy (the WGSL leaves these implementation
  * defined, the oracle and the HIP kernels make the same choice):

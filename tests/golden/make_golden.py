@@ -7,7 +7,11 @@
    independently of the C oracle and of the HIP kernels.  The reference has no tests or golden
    vectors of its own, and it cannot be executed in this environment, so
    these are derived from reading the WGSL.
-2. cover_64x36.npz -- a small regression fixture: scene bytes + uniforms (inputs) and the
+2. tiny_frames.npz -- whole tiny frames rendered by a SECOND independent restatement of the
+   shader (numpy_restatement.py: numpy f32 scalars, written from the WGSL, not from the C
+   oracle): hits, metal / glass / diffuse scatter, multi-sphere leaves, depth blend.  Pins the
+   C oracle (and through it the HIP kernels) on complete paths.
+3. cover_64x36.npz -- a small regression fixture: scene bytes + uniforms (inputs) and the
    frame + counters the C oracle produced for them (expected outputs).  It pins the oracle and
    the kernels against silent drift; it is NOT reference output ("parity unpinned").
 
@@ -23,6 +27,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, HERE)
 
 U32 = np.uint32
 F32 = np.float32
@@ -78,8 +83,41 @@ def main():
         json.dump({"chains": chains, "seeds": seeds}, f, indent=1)
     print("wrote rng_kat.json")
 
-    # regression fixture from the C oracle
+    # tiny frames from the independent numpy restatement
     import bevyray_amd as brt
+    from helpers import make_buffers, median_split_bvh, uniforms
+    import numpy_restatement as npr
+    M = brt.StandardMaterial
+    data = [((0.0, -100.5, -1.0), 100.0, M(base_color=(0.5, 0.5, 0.5))),
+            ((0.0, 0.0, -1.2), 0.5, M(base_color=(0.7, 0.3, 0.3), perceptual_roughness=0.0)),
+            ((-1.05, 0.0, -1.0), 0.5, M(specular_transmission=1.0, ior=1.5)),
+            ((1.05, 0.0, -1.0), 0.5, M(base_color=(0.8, 0.6, 0.2), metallic=1.0, perceptual_roughness=0.3)),
+            ((0.3, -0.3, -0.4), 0.2, M(base_color=(0.2, 0.4, 0.9), metallic=0.5, specular_transmission=0.5, ior=0.8)),
+            ((-0.4, 0.6, -1.6), 0.35, M(base_color=(0.9, 0.9, 0.9), metallic=1.0, perceptual_roughness=0.0))]
+    cases = {}
+    rng = np.random.default_rng(7)
+    for name, bvh_fn, w, h, spp, bounces, level, rseed in [
+            ("ploc_pure", None, 16, 12, 3, 6, brt.Raytracing.Pure, 0.37),
+            ("leaf2_blend", lambda m: median_split_bvh(m, 2), 12, 9, 2, 4, brt.Raytracing.FallbackRaytraced, 0.81),
+            ("leaf3_raster", lambda m: median_split_bvh(m, 3), 10, 8, 2, 3, brt.Raytracing.FallbackRaster, 0.12)]:
+        b = make_buffers(data, bvh_fn)
+        lvl, cam, win = uniforms(w, h, spp=spp, bounces=bounces, pos=(0.2, 0.4, 1.6), target=(0.0, 0.0, -1.0), fov=0.9, seed=rseed,
+                                 level=level, window_height=h * 3)
+        raster = rng.random((h, w, 4), dtype=np.float32) if level != brt.Raytracing.Pure else None
+        depth = (rng.random((h, w), dtype=np.float32) * np.float32(0.2)) if level != brt.Raytracing.Pure else None
+        frame, rays = npr.render(b.models, b.materials, b.bvh, cam[0], win[0], int(level), w, h, raster, depth)
+        for k, v in dict(models=b.models.view(np.uint8), materials=b.materials.view(np.uint8), bvh=b.bvh.view(np.uint8),
+                         level=lvl.view(np.uint8), camera=cam.view(np.uint8), window=win.view(np.uint8), frame=frame,
+                         rays=np.array([rays], np.uint64), size=np.array([w, h], np.uint32)).items():
+            cases[f"{name}.{k}"] = v
+        if raster is not None:
+            cases[f"{name}.raster"] = raster
+            cases[f"{name}.depth"] = depth
+        print("numpy restatement:", name, frame.shape, rays, "rays, mean", frame[..., :3].mean())
+    np.savez_compressed(os.path.join(HERE, "tiny_frames.npz"), **cases)
+    print("wrote tiny_frames.npz")
+
+    # regression fixture from the C oracle
     import oracle_loader
     o = oracle_loader.load()
     b = brt.generate_scene(brt.SCENE_COVER, 1)

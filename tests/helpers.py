@@ -137,3 +137,17 @@ def sky_color(oracle, cam, win, w, h, spp):
                 total = (total + np.sqrt(col.astype(F32), dtype=F32)).astype(F32)
             out[py, px] = total / F32(spp)
     return out
+
+
+def tiny_frame_cases():
+    """Frames rendered by the independent numpy restatement (tests/golden/numpy_restatement.py)."""
+    z = np.load(os.path.join(GOLDEN, "tiny_frames.npz"))
+    names = sorted({k.split(".")[0] for k in z.files})
+    for name in names:
+        g = lambda k: z[f"{name}.{k}"]
+        b = brt.Buffers(g("models").view(brt.MODEL_DTYPE), g("materials").view(brt.MATERIAL_DTYPE), g("bvh").view(brt.BVH_NODE_DTYPE))
+        w, h = (int(x) for x in g("size"))
+        raster = g("raster") if f"{name}.raster" in z.files else None
+        depth = g("depth") if f"{name}.depth" in z.files else None
+        yield (name, b, g("level").view(brt.LEVEL_DTYPE), g("camera").view(brt.CAMERA_DTYPE), g("window").view(brt.WINDOW_DTYPE),
+               w, h, raster, depth, g("frame"), int(g("rays")[0]))

@@ -15,7 +15,7 @@ import pytest
 
 import bevyray_amd as brt
 from helpers import (GOLDEN, chain_bvh, fixture_buffers, make_buffers, median_split_bvh, single_leaf_bvh, sky_color,
-                     uniforms)
+                     tiny_frame_cases, uniforms)
 
 INF = np.float32(3.40282347e+38)
 
@@ -226,6 +226,18 @@ def test_threads_and_row_ranges_do_not_change_pixels(oracle):
     assert np.array_equal(full, par) and cnt == cnt2
     part, _ = oracle.render(b, lvl, cam, win, w, h, rows=(5, 9), threads=2)
     assert np.array_equal(part[5:9], full[5:9]) and np.all(part[:5] == 0) and np.all(part[9:] == 0)
+
+
+# ---- (3b) whole frames from the second, independent restatement (numpy f32) -----------------------------
+
+def test_oracle_matches_numpy_restatement_frames(oracle):
+    n = 0
+    for name, b, lvl, cam, win, w, h, raster, depth, frame, rays in tiny_frame_cases():
+        got, cnt = oracle.render(b, lvl, cam, win, w, h, raster_rgba=raster, raster_depth=depth, threads=2)
+        assert np.array_equal(got.view(np.uint32), frame.view(np.uint32)), name
+        assert cnt["rays"] == rays, name
+        n += 1
+    assert n == 3
 
 
 # ---- (4) regression fixture ----------------------------------------------------------------------------

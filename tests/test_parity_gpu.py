@@ -13,7 +13,7 @@ import pytest
 
 import bevyray_amd as brt
 from helpers import (GOLDEN, chain_bvh, fixture_buffers, make_buffers, median_split_bvh, single_leaf_bvh, sky_color,
-                     uniforms)
+                     tiny_frame_cases, uniforms)
 
 pytestmark = pytest.mark.gpu
 
@@ -138,6 +138,14 @@ def test_golden_cover_fixture(plugin, oracle):
     got = plugin.node.run(lvl, cam, win, 64, 36, buffers=b, flags=brt.FLAG_COUNTERS)
     assert_frames_equal(got, frame)
     assert [plugin.node.last_stats[k] for k in COUNTER_KEYS] == counters
+
+
+def test_numpy_restatement_frames(plugin):
+    # frames rendered by the second, independent restatement of the shader (numpy f32 scalars)
+    for name, b, lvl, cam, win, w, h, raster, depth, frame, rays in tiny_frame_cases():
+        got = plugin.node.run(lvl, cam, win, w, h, buffers=b, raster_rgba=raster, raster_depth=depth)
+        assert_frames_equal(got, frame)
+        assert plugin.node.last_stats["rays"] == rays, name
 
 
 @pytest.mark.parametrize("seed", [0.0, 0.25, 0.5, 0.999])
