@@ -3,22 +3,27 @@
 //
 // k_trace_persistent  the production kernel: persistent threads, one path per lane.
 //     * One 1024-thread workgroup per CU (16 waves, 4 per SIMD) stays resident for the whole
-//       frame.  When the encoded scene fits, the workgroup first copies pair records,
-//       spheres and materials into LDS (cover scene: ~53 KB); the per-lane traversal stack
-//       also lives in LDS as a [entry][lane] array (conflict-free: bank = lane).
+//       frame.  When the encoded scene fits, the workgroup first copies pair records, spheres
+//       and material ids into LDS (cover scene: 38 KB; the 32-byte materials stay in global
+//       memory, one read per hit); the per-lane traversal stacks also live in LDS as
+//       [entry][lane] arrays of u16 descriptors (conflict-free: bank = lane).
 //     * Each lane owns one pixel at a time and walks that pixel's samples and bounces as a
-//       flat state machine, one ray segment per outer iteration, because the reference
-//       threads ONE RNG state through all samples of a pixel (raytrace.wgsl:161-163): the
-//       samples of a pixel are sequentially dependent, the pixels are not.
+//       flat state machine, one ray segment per outer iteration ("round"), because the
+//       reference threads ONE RNG state through all samples of a pixel
+//       (raytrace.wgsl:161-163): the samples of a pixel are sequentially dependent, the
+//       pixels are not.
 //     * Finished lanes are refilled from a global pixel queue: __ballot of the empty lanes,
 //       one wave-aggregated atomicAdd, mbcnt prefix sum to hand out consecutive queue slots.
 //       Queue slots map to 8x8 pixel tiles so that a wave starts on coherent primary rays.
 //     * No ray state ever goes to HBM; the only HBM traffic is the scene load per workgroup
 //       and one 16-byte store per pixel.
+//     * Bound by instruction issue under divergence, not by memory: the
+//       hot bodies are therefore straight-line (selects instead of nested branches).
 // k_trace_simple      bring-up kernel: one thread per pixel, scene in global memory, private
 //                     stack.  Kept as an independent second implementation for debugging.
 // k_deinterleave      root side of the multi-GPU gather.
 // k_debug_eval        evaluates single device functions for per-function parity tests.
+// k_bench_trace       trace-only microbenchmark on recorded rays (diagnostic, scripts/trace_bench.py).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
