@@ -6,6 +6,7 @@
 // HIP device brt_create fails with BRT_ERR_NO_DEVICE -- there is no CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -40,6 +41,18 @@ struct DeviceCtx {
     size_t raster_depth_cap = 0;
     float* h_stage = nullptr;  // pinned
     size_t stage_cap = 0;
+    // longest-first dispatch (see plan_tile_order): this frame's per-tile ray counts and the
+    // order derived from the previous frame of the same view
+    uint32_t* d_tile_cost = nullptr;
+    size_t tile_cost_cap = 0;
+    uint32_t* d_tile_order = nullptr;
+    size_t tile_order_cap = 0;
+    bool order_valid = false;
+    uint32_t order_age = 0;                       // frames since the costs were last measured
+    uint32_t order_key[6] = {0, 0, 0, 0, 0, 0};   // width, height, part, n_parts, scene epoch, n_tiles
+    std::vector<uint32_t> h_cost;
+    std::vector<uint64_t> h_keys;
+    std::vector<uint32_t> h_order;
     // GPU BVH build
     char* d_bvh_scratch = nullptr;
     size_t bvh_scratch_cap = 0;
@@ -53,6 +66,7 @@ struct brt_ctx {
     std::vector<DeviceCtx> devs;
     EncodedScene enc;
     bool has_scene = false;
+    uint32_t scene_epoch = 0;   // bumped by every upload: invalidates the tile-cost history
     std::string last_error;
 };
 
@@ -198,6 +212,77 @@ LaunchPlan plan_launch(const DeviceCtx& dc, const FrameParams& fp) {
     return lp;
 }
 
+// Expensive-tiles-first dispatch.  A pixel is one sequential chain of samples, so a frame ends
+// when its slowest pixels end: a tile that needs many rays must not be handed out late.  The cost
+// of a tile is not known in advance, but a renderer draws nearly the same frame again and again:
+// the kernel measures the rays each tile needed (one atomic per finished pixel, every
+// kLptRefresh-th frame of a view) and the next frames hand out the most expensive tenth of the
+// tiles first, the rest in raster order.  (A FULLY sorted order is slower: every wave then runs
+// the same phase at the same time -- all heavy tiles, later all sky -- which costs 11 % more wave
+// cycles at equal instruction count; raster order mixes phases.  A sorted cheap tail hurts too.)
+// Measured on MI355X, cover scene, one rank's share of the frame: 1/1 27.4 -> 27.1 ms,
+// 1/2 16.2 -> 14.2 ms, 1/4 11.9 -> 10.3 ms.  Pixels never change, only the queue order does.
+// BRT_LPT=0 disables; BRT_LPT_HEAD_PERMILLE sets the head size (default 100).
+constexpr uint32_t kLptRefresh = 16;
+bool lpt_enabled() { return env_u32("BRT_LPT", 1) != 0; }
+
+void order_key_of(const brt_ctx* ctx, const FrameParams& fp, uint32_t key[6]) {
+    key[0] = fp.width; key[1] = fp.height; key[2] = fp.part; key[3] = fp.n_parts;
+    key[4] = ctx->scene_epoch; key[5] = fp.local_strips * fp.tiles_x;
+}
+
+// before the launch: attach the order table if the history matches this view, and -- when the
+// history is missing or kLptRefresh frames old -- the (zeroed) cost buffer to measure again
+int32_t attach_tile_order(brt_ctx* ctx, DeviceCtx& dc, FrameParams& fp, hipStream_t stream, bool may_measure) {
+    fp.tile_order = nullptr;
+    fp.tile_cost = nullptr;
+    if (!lpt_enabled() || fp.level == 0u) return BRT_OK;
+    const uint32_t n_tiles = fp.local_strips * fp.tiles_x;
+    uint32_t key[6];
+    order_key_of(ctx, fp, key);
+    const bool match = dc.order_valid && std::memcmp(key, dc.order_key, sizeof key) == 0;
+    if (match) fp.tile_order = dc.d_tile_order;
+    if (may_measure && (!match || ++dc.order_age >= kLptRefresh)) {
+        int32_t rc = ensure(ctx, &dc.d_tile_cost, &dc.tile_cost_cap, (size_t)n_tiles * 4);
+        if (rc != BRT_OK) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(dc.d_tile_cost, 0, (size_t)n_tiles * 4, stream));
+        fp.tile_cost = dc.d_tile_cost;
+    }
+    return BRT_OK;
+}
+
+// after a measuring frame has completed on `stream`: build the order of the next frames
+int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hipStream_t stream) {
+    if (!fp.tile_cost) return BRT_OK;
+    const uint32_t n_tiles = fp.local_strips * fp.tiles_x;
+    dc.h_cost.resize(n_tiles);
+    HIP_TRY(ctx, hipMemcpyAsync(dc.h_cost.data(), dc.d_tile_cost, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    uint32_t head = (uint32_t)((uint64_t)n_tiles * env_u32("BRT_LPT_HEAD_PERMILLE", 100) / 1000u);
+    if (head > n_tiles) head = n_tiles;
+    dc.h_keys.resize(n_tiles);
+    for (uint32_t i = 0; i < n_tiles; i++) dc.h_keys[i] = ((uint64_t)(~dc.h_cost[i]) << 32) | i;   // cost descending, index ascending
+    std::nth_element(dc.h_keys.begin(), dc.h_keys.begin() + head, dc.h_keys.end());
+    std::sort(dc.h_keys.begin(), dc.h_keys.begin() + head);                    // head: most expensive first
+    dc.h_order.resize(n_tiles);
+    std::vector<uint8_t> in_head(n_tiles, 0);
+    for (uint32_t i = 0; i < head; i++) {
+        dc.h_order[i] = (uint32_t)(dc.h_keys[i] & 0xffffffffu);
+        in_head[dc.h_order[i]] = 1;
+    }
+    uint32_t k = head;
+    for (uint32_t tile = 0; tile < n_tiles; tile++)                            // the rest: raster order
+        if (!in_head[tile]) dc.h_order[k++] = tile;
+    int32_t rc = ensure(ctx, &dc.d_tile_order, &dc.tile_order_cap, (size_t)n_tiles * 4);
+    if (rc != BRT_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(dc.d_tile_order, dc.h_order.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));   // h_order may be reused by the next call
+    order_key_of(ctx, fp, dc.order_key);
+    dc.order_valid = true;
+    dc.order_age = 0;
+    return BRT_OK;
+}
+
 // Launch the trace of one part on one device into d_out_tile.  Asynchronous on `stream`.
 int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const float* d_raster_rgba,
                     const float* d_raster_depth, float* d_out_tile, hipStream_t stream, uint32_t flags, bool timed,
@@ -267,6 +352,8 @@ void free_device(DeviceCtx& dc) {
     if (dc.d_raster_depth) (void)hipFree(dc.d_raster_depth);
     if (dc.h_stage) (void)hipHostFree(dc.h_stage);
     if (dc.d_bvh_scratch) (void)hipFree(dc.d_bvh_scratch);
+    if (dc.d_tile_cost) (void)hipFree(dc.d_tile_cost);
+    if (dc.d_tile_order) (void)hipFree(dc.d_tile_order);
     if (dc.d_bvh_models) (void)hipFree(dc.d_bvh_models);
     if (dc.ev0) (void)hipEventDestroy(dc.ev0);
     if (dc.ev1) (void)hipEventDestroy(dc.ev1);
@@ -423,6 +510,7 @@ int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, co
         HIP_TRY(ctx, hipStreamSynchronize(dc.stream));  // the caller's vectors are no longer referenced
     }
     ctx->has_scene = true;
+    ctx->scene_epoch++;
     return BRT_OK;
 }
 
@@ -447,6 +535,8 @@ int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* w
     HIP_TRY(ctx, hipSetDevice(dc.device));
     const bool own_stream = (hip_stream == nullptr);
     hipStream_t stream = own_stream ? dc.stream : static_cast<hipStream_t>(hip_stream);
+    rc = attach_tile_order(ctx, dc, fp, stream, own_stream);
+    if (rc != BRT_OK) return rc;
     LaunchPlan lp{};
     rc = launch_part(ctx, dc, fp, d_raster_rgba, d_raster_depth, d_out_tile, stream, flags, own_stream, &lp);
     if (rc != BRT_OK) return rc;
@@ -464,6 +554,8 @@ int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* w
         if (rc != BRT_OK) return rc;
         float ms = 0.0f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, dc.ev0, dc.ev1));
+        rc = update_tile_order(ctx, dc, fp, stream);
+        if (rc != BRT_OK) return rc;
         if (stats) {
             stats->rays = tmp.rays; stats->node_pops = tmp.node_pops; stats->interior_visits = tmp.interior_visits;
             stats->sphere_tests = tmp.sphere_tests; stats->hits = tmp.hits;
@@ -519,6 +611,8 @@ int32_t brt_render(brt_ctx* ctx, const void* camera80, const void* window16, uin
             HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&dc.h_stage), tile_bytes, hipHostMallocDefault));
             dc.stage_cap = tile_bytes;
         }
+        rc = attach_tile_order(ctx, dc, fps[p], dc.stream, true);
+        if (rc != BRT_OK) return rc;
         rc = launch_part(ctx, dc, fps[p], d_rgba, d_depth, dc.d_tile, dc.stream, flags, true, &lp);
         if (rc != BRT_OK) return rc;
         HIP_TRY(ctx, hipMemcpyAsync(dc.h_stage, dc.d_tile, tile_bytes, hipMemcpyDeviceToHost, dc.stream));
@@ -532,6 +626,8 @@ int32_t brt_render(brt_ctx* ctx, const void* camera80, const void* window16, uin
         float ms = 0.0f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, dc.ev0, dc.ev1));
         if (ms > kernel_ms) kernel_ms = ms;
+        rc = update_tile_order(ctx, dc, fps[p], dc.stream);
+        if (rc != BRT_OK) return rc;
         const auto g0 = std::chrono::steady_clock::now();
         const uint32_t strips = (height + BRT_STRIP_ROWS - 1u) / BRT_STRIP_ROWS;
         for (uint32_t s = p, k = 0; s < strips; s += n_parts, k++) {

@@ -40,10 +40,12 @@ namespace brt {
 struct PixelCoord {
     uint32_t px, py;        // frame coordinates
     uint32_t local_row;     // row in the dense tile buffer
+    uint32_t tile;          // tile id (strip * tiles_x + tx)
     bool inside;
 };
 BRT_DEV PixelCoord slot_to_pixel(const FrameParams& fp, uint32_t q) {
-    const uint32_t tile = q >> 6, t = q & 63u;
+    const uint32_t t = q & 63u;
+    const uint32_t tile = fp.tile_order ? fp.tile_order[q >> 6] : (q >> 6);   // longest-first order, if known
     const uint32_t sq = tile / fp.tiles_x, tx = tile - sq * fp.tiles_x;
     // queue order: bottom strips first when fp.bottom_up (longest-pixels-first heuristic)
     const uint32_t strip = fp.bottom_up ? (fp.local_strips - 1u - sq) : sq;
@@ -52,6 +54,7 @@ BRT_DEV PixelCoord slot_to_pixel(const FrameParams& fp, uint32_t q) {
     const uint32_t r = t >> 3;
     c.local_row = strip * 8u + r;
     c.py = (strip * fp.n_parts + fp.part) * 8u + r;
+    c.tile = tile;
     c.inside = (c.px < fp.width) && (c.py < fp.height);
     return c;
 }
@@ -76,6 +79,8 @@ struct PixelState {
     uint32_t sample;
     uint32_t out_index;     // pixel index in the tile buffer
     uint32_t frame_index;   // pixel index in the frame (raster inputs)
+    uint32_t tile;          // for the per-tile cost measurement
+    uint32_t rays_begin;    // lane's ray counter when the pixel started
 };
 
 BRT_DEV void pixel_begin(const FrameParams& fp, const PixelCoord& c, PixelState& ps) {
@@ -89,6 +94,7 @@ BRT_DEV void pixel_begin(const FrameParams& fp, const PixelCoord& c, PixelState&
     ps.sample = 0;
     ps.out_index = c.local_row * fp.width + c.px;
     ps.frame_index = c.py * fp.width + c.px;
+    ps.tile = c.tile;
 }
 
 BRT_DEV void pixel_finish(const FrameParams& fp, const PixelState& ps, float* out_tile, const float* raster_rgba,
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     StackT* stk = stacks + wave * ((sv.stack_entries + 1u) * 64u) + lane;   // + 1: dummy entry
 
     PixelState ps;
-    ps.sample = 0; ps.rng = 0; ps.out_index = 0; ps.frame_index = 0;
+    ps.sample = 0; ps.rng = 0; ps.out_index = 0; ps.frame_index = 0; ps.tile = 0; ps.rays_begin = 0;
     ps.ndc0x = ps.ndc0y = 0.0f; ps.sum = mk3(0.0f, 0.0f, 0.0f); ps.dsum = 0.0f;
     f3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f), tput = mk3(1.0f, 1.0f, 1.0f);
     uint32_t bounce = 0;
@@ -219,6 +225,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                     const PixelCoord c = slot_to_pixel(fp, q);
                     if (c.inside) {
                         pixel_begin(fp, c, ps);
+                        ps.rays_begin = n_rays;
                         if (fp.sample_count == 0) pixel_finish(fp, ps, out_tile, raster_rgba, raster_depth);  // 0/0
                         else { active = true; bounce = 0; }
                     }
@@ -265,6 +272,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                 bounce = 0;
                 if (ps.sample == fp.sample_count) {
                     pixel_finish(fp, ps, out_tile, raster_rgba, raster_depth);
+                    if (fp.tile_cost) atomicAdd(&fp.tile_cost[ps.tile], n_rays - ps.rays_begin);
                     active = false;
                 }
             }

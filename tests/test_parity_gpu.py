@@ -472,3 +472,27 @@ def test_async_render_on_a_caller_stream(plugin, oracle):
                                    d_raster_depth=depth.data_ptr())
     want2, _ = oracle.render(b, lvl2, cam2, win2, w, h, raster_rgba=raster.cpu().numpy(), raster_depth=depth.cpu().numpy())
     assert_frames_equal(tile2.cpu().numpy()[:h], want2)
+
+
+def test_expensive_first_dispatch_never_changes_pixels(plugin, oracle):
+    # the tile order of a frame comes from the previous frame's per-tile ray counts (brt_api.cpp
+    # attach_tile_order): first frame raster order, later frames expensive tiles first
+    b = brt.generate_scene(brt.SCENE_COVER, 4)
+    w, h = 200, 120
+    lvl, cam, win = brt.cover_camera(w, h, 3, 6, brt.Raytracing.Pure, 0.61)
+    want, cnt = oracle.render(b, lvl, cam, win, w, h)
+    plugin.node.write_buffers(b)                       # new scene epoch: no history
+    for frame_no in range(4):
+        got = plugin.node.run(lvl, cam, win, w, h, flags=brt.FLAG_COUNTERS)
+        assert_frames_equal(got, want)
+        assert {k: plugin.node.last_stats[k] for k in COUNTER_KEYS} == cnt, frame_no
+    os.environ["BRT_LPT"] = "0"
+    try:
+        assert_frames_equal(plugin.node.run(lvl, cam, win, w, h), want)
+    finally:
+        del os.environ["BRT_LPT"]
+    # another view of the same scene reuses nothing wrongly (different size -> history key mismatch)
+    lvl2, cam2, win2 = brt.cover_camera(96, 54, 2, 4)
+    want2, _ = oracle.render(b, lvl2, cam2, win2, 96, 54)
+    assert_frames_equal(plugin.node.run(lvl2, cam2, win2, 96, 54), want2)
+    assert_frames_equal(plugin.node.run(lvl, cam, win, w, h), want)
