@@ -20,10 +20,6 @@ namespace {
 
 constexpr int BVH_BLOCK = 1024;
 
-struct KeyIdx {
-    uint64_t key;
-    uint32_t idx;
-};
 __device__ __forceinline__ bool key_less(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib) {
     return ka < kb || (ka == kb && ia < ib);
 }

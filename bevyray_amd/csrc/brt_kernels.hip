@@ -324,9 +324,9 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_bench_trace(DeviceSceneView sv, c
     uint2* p2 = reinterpret_cast<uint2*>(p);
     uint2* l_rb = p2; p2 += BENCH_CHUNK;         //            {d.y, d.z}
     uint2* l_qd = p2; p2 += sv.n_pairs;
-    uint32_t* p1 = reinterpret_cast<uint32_t*>(p2);
-    uint32_t* l_head = p1; p1 += 4;
-    uint16_t* stacks = reinterpret_cast<uint16_t*>(p1);
+    uint32_t* pw = reinterpret_cast<uint32_t*>(p2);
+    uint32_t* l_head = pw; pw += 4;
+    uint16_t* stacks = reinterpret_cast<uint16_t*>(pw);
     for (uint32_t i = threadIdx.x; i < sv.n_pairs; i += blockDim.x) {
         l_q0[i] = reinterpret_cast<const float4*>(sv.q0)[i]; l_q1[i] = reinterpret_cast<const float4*>(sv.q1)[i];
         l_q2[i] = reinterpret_cast<const float4*>(sv.q2)[i]; l_qd[i] = reinterpret_cast<const uint2*>(sv.qd)[i];
