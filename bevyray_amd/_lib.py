@@ -62,6 +62,8 @@ _PROTOTYPES = {
     "brt_destroy": (_I32, [_VP]),
     "brt_upload_scene": (_I32, [_VP, _VP, _U32, _VP, _U32, _VP, _U32]),
     "brt_render": (_I32, [_VP, _VP, _VP, _U32, _U32, _U32, _VP, _VP, _VP, _U32, C.POINTER(BrtStats)]),
+    "brt_host_alloc": (_I32, [_VP, C.c_uint64, C.POINTER(_VP)]),
+    "brt_host_free": (_I32, [_VP, _VP]),
     "brt_render_part_device": (_I32, [_VP, _VP, _VP, _U32, _U32, _U32, _U32, _U32, _VP, _VP, _VP, _VP, _U32,
                                       C.POINTER(BrtStats)]),
     "brt_tile_rows": (_U32, [_U32, _U32]),

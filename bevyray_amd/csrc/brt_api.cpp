@@ -67,6 +67,7 @@ struct brt_ctx {
     EncodedScene enc;
     bool has_scene = false;
     uint32_t scene_epoch = 0;   // bumped by every upload: invalidates the tile-cost history
+    std::vector<std::pair<char*, size_t>> pinned;   // brt_host_alloc blocks
     std::string last_error;
 };
 
@@ -210,6 +211,13 @@ LaunchPlan plan_launch(const DeviceCtx& dc, const FrameParams& fp) {
     if (lp.grid > useful) lp.grid = useful;
     if (lp.grid < 1) lp.grid = 1;
     return lp;
+}
+
+bool is_pinned(const brt_ctx* ctx, const void* p, size_t bytes) {
+    const char* c = static_cast<const char*>(p);
+    for (const auto& b : ctx->pinned)
+        if (c >= b.first && c + bytes <= b.first + b.second) return true;
+    return false;
 }
 
 // Expensive-tiles-first dispatch.  A pixel is one sequential chain of samples, so a frame ends
@@ -442,8 +450,31 @@ int32_t brt_create(const int32_t* device_ids, int32_t n_devices, brt_ctx** out_c
     return BRT_OK;
 }
 
+int32_t brt_host_alloc(brt_ctx* ctx, uint64_t bytes, void** out_ptr) {
+    if (!ctx || !out_ptr || bytes == 0) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer / zero size");
+    *out_ptr = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->devs[0].device));
+    void* p = nullptr;
+    HIP_TRY(ctx, hipHostMalloc(&p, (size_t)bytes, hipHostMallocPortable));
+    ctx->pinned.emplace_back(static_cast<char*>(p), (size_t)bytes);
+    *out_ptr = p;
+    return BRT_OK;
+}
+
+int32_t brt_host_free(brt_ctx* ctx, void* ptr) {
+    if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
+    for (size_t i = 0; i < ctx->pinned.size(); i++)
+        if (ctx->pinned[i].first == ptr) {
+            HIP_TRY(ctx, hipHostFree(ptr));
+            ctx->pinned.erase(ctx->pinned.begin() + (long)i);
+            return BRT_OK;
+        }
+    return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "pointer was not allocated by brt_host_alloc");
+}
+
 int32_t brt_destroy(brt_ctx* ctx) {
     if (!ctx) return BRT_OK;
+    for (auto& b : ctx->pinned) (void)hipHostFree(b.first);
     for (auto& d : ctx->devs) free_device(d);
     delete ctx;
     return BRT_OK;
@@ -583,6 +614,7 @@ int32_t brt_render(brt_ctx* ctx, const void* camera80, const void* window16, uin
     const size_t frame_px = (size_t)width * height;
     brt_stats st{};
     LaunchPlan lp{};
+    const bool direct = is_pinned(ctx, out_rgba, frame_px * 16);
 
     // launch every device, then collect: the devices trace their strips concurrently
     for (uint32_t p = 0; p < n_parts; p++) {
@@ -604,7 +636,7 @@ int32_t brt_render(brt_ctx* ctx, const void* camera80, const void* window16, uin
             HIP_TRY(ctx, hipMemcpyAsync(dc.d_raster_depth, raster_depth, frame_px * 4, hipMemcpyHostToDevice, dc.stream));
             d_depth = dc.d_raster_depth;
         }
-        if (dc.stage_cap < tile_bytes) {
+        if (!direct && dc.stage_cap < tile_bytes) {
             if (dc.h_stage) HIP_TRY(ctx, hipHostFree(dc.h_stage));
             dc.h_stage = nullptr;
             dc.stage_cap = 0;
@@ -615,7 +647,22 @@ int32_t brt_render(brt_ctx* ctx, const void* camera80, const void* window16, uin
         if (rc != BRT_OK) return rc;
         rc = launch_part(ctx, dc, fps[p], d_rgba, d_depth, dc.d_tile, dc.stream, flags, true, &lp);
         if (rc != BRT_OK) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(dc.h_stage, dc.d_tile, tile_bytes, hipMemcpyDeviceToHost, dc.stream));
+        if (direct) {
+            // page-locked destination: DMA every strip to its place in the frame, no CPU copy
+            const uint32_t strips = (height + BRT_STRIP_ROWS - 1u) / BRT_STRIP_ROWS;
+            for (uint32_t s = p, k = 0; s < strips; s += n_parts, k++) {
+                const uint32_t r0 = s * BRT_STRIP_ROWS;
+                const uint32_t rows = (r0 + BRT_STRIP_ROWS <= height) ? BRT_STRIP_ROWS : (height - r0);
+                if (n_parts == 1) {   // the tile IS the frame: one copy
+                    HIP_TRY(ctx, hipMemcpyAsync(out_rgba, dc.d_tile, frame_px * 16, hipMemcpyDeviceToHost, dc.stream));
+                    break;
+                }
+                HIP_TRY(ctx, hipMemcpyAsync(out_rgba + (size_t)r0 * width * 4, dc.d_tile + (size_t)k * BRT_STRIP_ROWS * width * 4,
+                                            (size_t)rows * width * 16, hipMemcpyDeviceToHost, dc.stream));
+            }
+        } else {
+            HIP_TRY(ctx, hipMemcpyAsync(dc.h_stage, dc.d_tile, tile_bytes, hipMemcpyDeviceToHost, dc.stream));
+        }
     }
     double kernel_ms = 0.0, gather_ms = 0.0;
     for (uint32_t p = 0; p < n_parts; p++) {
@@ -629,7 +676,7 @@ int32_t brt_render(brt_ctx* ctx, const void* camera80, const void* window16, uin
         rc = update_tile_order(ctx, dc, fps[p], dc.stream);
         if (rc != BRT_OK) return rc;
         const auto g0 = std::chrono::steady_clock::now();
-        const uint32_t strips = (height + BRT_STRIP_ROWS - 1u) / BRT_STRIP_ROWS;
+        const uint32_t strips = direct ? 0u : (height + BRT_STRIP_ROWS - 1u) / BRT_STRIP_ROWS;
         for (uint32_t s = p, k = 0; s < strips; s += n_parts, k++) {
             const uint32_t r0 = s * BRT_STRIP_ROWS;
             const uint32_t rows = (r0 + BRT_STRIP_ROWS <= height) ? BRT_STRIP_ROWS : (height - r0);

@@ -181,6 +181,12 @@ public:
     RaytracePlugin(const RaytracePlugin&) = delete;
     RaytracePlugin& operator=(const RaytracePlugin&) = delete;
     RayTracingNode node() { return RayTracingNode(ctx_); }
+    // page-locked frame memory: brt_render DMAs straight into it (brt_host_alloc)
+    float* alloc_frame(uint32_t width, uint32_t height) {
+        void* p = nullptr;
+        check(brt_host_alloc(ctx_, static_cast<uint64_t>(width) * height * 16, &p), ctx_);
+        return static_cast<float*>(p);
+    }
     brt_ctx* context() { return ctx_; }
 private:
     brt_ctx* ctx_ = nullptr;

@@ -260,6 +260,15 @@ class RaytracePlugin:
         except Exception:
             pass
 
+    def alloc_frame(self, width: int, height: int) -> np.ndarray:
+        """Page-locked (height, width, 4) f32 frame owned by the context (brt_host_alloc): passing it
+        as `out` to RayTracingNode.run lets the library DMA straight into it."""
+        nbytes = width * height * 16
+        ptr = C.c_void_p()
+        _lib.check(self._lib.brt_host_alloc(self._ctx, nbytes, C.byref(ptr)), self._ctx)
+        buf = (C.c_float * (width * height * 4)).from_address(ptr.value)
+        return np.frombuffer(buf, np.float32).reshape(height, width, 4)
+
     def build_bvh(self, models: np.ndarray):
         """GPU PLOC build (brt_build_bvh_device): returns (nodes, kernel ms); same bytes as build_bvh()."""
         models = np.ascontiguousarray(models, MODEL_DTYPE)
@@ -305,7 +314,7 @@ class RayTracingNode:
 
     def run(self, level, camera, window, width: int, height: int, buffers: Optional[Buffers] = None,
             raster_rgba: Optional[np.ndarray] = None, raster_depth: Optional[np.ndarray] = None,
-            flags: int = 0) -> Optional[np.ndarray]:
+            flags: int = 0, out: Optional[np.ndarray] = None) -> Optional[np.ndarray]:
         """Returns the RGBA f32 frame (height, width, 4), or None when the pass is skipped the
         way the reference skips it (missing camera extract, empty buffers)."""
         if camera is None or window is None or level is None:
@@ -318,7 +327,9 @@ class RayTracingNode:
                 if e.code == -6:  # BRT_ERR_EMPTY_SCENE: no binding -> skip (pipeline.rs:141-151)
                     return None
                 raise
-        out = np.empty((height, width, 4), np.float32)
+        if out is None:
+            out = np.empty((height, width, 4), np.float32)
+        assert out.shape == (height, width, 4) and out.dtype == np.float32 and out.flags["C_CONTIGUOUS"]
         stats = BrtStats()
         rr = None if raster_rgba is None else np.ascontiguousarray(raster_rgba, np.float32)
         rd = None if raster_depth is None else np.ascontiguousarray(raster_depth, np.float32)

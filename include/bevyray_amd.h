@@ -126,6 +126,13 @@ int32_t brt_render(brt_ctx* ctx, const void* camera80, const void* window16, uin
                    const float* raster_rgba, const float* raster_depth,
                    float* out_rgba, uint32_t flags, brt_stats* stats_or_null);
 
+/* Optional fast path for brt_render: page-locked host memory owned by the context.  When
+ * out_rgba (and/or raster_rgba / raster_depth) lies inside such an allocation the frame is DMA'd
+ * straight into it (no staging copy on the CPU: ~2 ms less per 1080p frame).  The memory stays
+ * valid until brt_host_free / brt_destroy.  Any other pointer keeps working through staging. */
+int32_t brt_host_alloc(brt_ctx* ctx, uint64_t bytes, void** out_ptr);
+int32_t brt_host_free(brt_ctx* ctx, void* ptr);
+
 /* Same frame, but only the strips of `part` out of `n_parts` (strip s belongs to part
  * s % n_parts), written densely into a DEVICE tile buffer of brt_tile_rows() rows on the
  * context's first device: tile row (k*BRT_STRIP_ROWS + r) is frame row

@@ -496,3 +496,19 @@ def test_expensive_first_dispatch_never_changes_pixels(plugin, oracle):
     want2, _ = oracle.render(b, lvl2, cam2, win2, 96, 54)
     assert_frames_equal(plugin.node.run(lvl2, cam2, win2, 96, 54), want2)
     assert_frames_equal(plugin.node.run(lvl, cam, win, w, h), want)
+
+
+def test_pinned_frame_fast_path(plugin, oracle):
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    w, h = 136, 77
+    lvl, cam, win = brt.cover_camera(w, h, 2, 4)
+    want, _ = oracle.render(b, lvl, cam, win, w, h)
+    frame = plugin.alloc_frame(w, h)
+    frame[:] = -1.0
+    got = plugin.node.run(lvl, cam, win, w, h, buffers=b, out=frame)
+    assert got is frame
+    assert_frames_equal(frame, want)
+    with brt.RaytracePlugin([0, 0]) as p2:          # strips of two sub-contexts DMA'd into one pinned frame
+        f2 = p2.alloc_frame(w, h)
+        p2.node.run(lvl, cam, win, w, h, buffers=b, out=f2)
+        assert_frames_equal(f2, want)
