@@ -68,6 +68,8 @@ struct brt_ctx {
     bool has_scene = false;
     uint32_t scene_epoch = 0;   // bumped by every upload: invalidates the tile-cost history
     std::vector<std::pair<char*, size_t>> pinned;   // brt_host_alloc blocks
+    // bytes of the last successful upload (dirty tracking: an unchanged scene is not re-sent)
+    std::vector<char> last_models, last_materials, last_bvh;
     std::string last_error;
 };
 
@@ -483,6 +485,17 @@ int32_t brt_destroy(brt_ctx* ctx) {
 int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, const void* materials, uint32_t n_materials,
                          const void* bvh_nodes, uint32_t n_nodes) {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
+    // Dirty tracking (the reference re-uploads everything every frame, README.md:17 lists that as
+    // future work): identical bytes as the last successful upload -> nothing to do, and the tile-cost
+    // history stays valid.  BRT_NO_DIRTY_TRACKING=1 disables.
+    const size_t mb = (size_t)n_models * sizeof(Model), tb = (size_t)n_materials * sizeof(Material),
+                 bb = (bvh_nodes ? (size_t)n_nodes : 0) * sizeof(BVHNode);
+    auto same = [](const std::vector<char>& v, const void* p, size_t n) {
+        return v.size() == n && (n == 0 || (p && std::memcmp(v.data(), p, n) == 0));
+    };
+    if (ctx->has_scene && env_u32("BRT_NO_DIRTY_TRACKING", 0) == 0 && same(ctx->last_models, models, mb) &&
+        same(ctx->last_materials, materials, tb) && same(ctx->last_bvh, bvh_nodes, bb))
+        return BRT_OK;
     ctx->has_scene = false;
     std::vector<BVHNode> built;
     const BVHNode* nodes = static_cast<const BVHNode*>(bvh_nodes);
@@ -540,6 +553,10 @@ int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, co
         HIP_TRY(ctx, hipSetDevice(dc.device));
         HIP_TRY(ctx, hipStreamSynchronize(dc.stream));  // the caller's vectors are no longer referenced
     }
+    ctx->last_models.assign(static_cast<const char*>(models), static_cast<const char*>(models) + mb);
+    ctx->last_materials.assign(static_cast<const char*>(materials), static_cast<const char*>(materials) + tb);
+    if (bb) ctx->last_bvh.assign(static_cast<const char*>(bvh_nodes), static_cast<const char*>(bvh_nodes) + bb);
+    else ctx->last_bvh.clear();
     ctx->has_scene = true;
     ctx->scene_epoch++;
     return BRT_OK;

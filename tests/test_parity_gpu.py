@@ -512,3 +512,29 @@ def test_pinned_frame_fast_path(plugin, oracle):
         f2 = p2.alloc_frame(w, h)
         p2.node.run(lvl, cam, win, w, h, buffers=b, out=f2)
         assert_frames_equal(f2, want)
+
+
+def test_unchanged_scene_is_not_reuploaded_and_changes_are(plugin, oracle):
+    import time
+    b = brt.generate_scene(brt.SCENE_STRESS_GRID, 1)
+    nb = brt.Buffers(b.models, b.materials, None)             # callee builds the BVH: the expensive upload
+    plugin.node.write_buffers(brt.generate_scene(brt.SCENE_COVER, 9))
+    t0 = time.perf_counter(); plugin.node.write_buffers(nb); first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(10):
+        plugin.node.write_buffers(nb)
+    again = (time.perf_counter() - t0) / 10
+    assert again < first / 3, (first, again)                  # byte compare only
+    lvl, cam, win = brt.cover_camera(64, 36, 2, 4)
+    f1 = plugin.node.run(lvl, cam, win, 64, 36)
+    moved = b.models.copy(); moved[-1]["position"] = (4.0, 1.5, 0.0)   # one sphere moves: must be noticed
+    f2 = plugin.node.run(lvl, cam, win, 64, 36, buffers=brt.Buffers(moved, b.materials, None))
+    want2, _ = oracle.render(brt.Buffers(moved, b.materials, brt.build_bvh(moved)), lvl, cam, win, 64, 36)
+    assert_frames_equal(f2, want2)
+    assert not np.array_equal(f1, f2)
+    # a failed upload invalidates the scene even if the next upload repeats earlier bytes
+    bad = brt.build_bvh(moved); bad[0]["index"] = len(bad)
+    with pytest.raises(brt.BrtError):
+        plugin.node.write_buffers(brt.Buffers(moved, b.materials, bad))
+    f3 = plugin.node.run(lvl, cam, win, 64, 36, buffers=brt.Buffers(moved, b.materials, None))
+    assert_frames_equal(f3, want2)
