@@ -81,9 +81,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step(flags=0):
+    gather_events = []
+
+    def step(flags=0, timed=False):
         st = node.render_part_device(lvl, cam, win, W, H, rank, world, tile.data_ptr(), flags=flags)  # synchronous
+        if timed:   # gather + de-interleave run on torch's current stream: time them there
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         frame = gather_frame(tile, H, rank, world, node=node)
+        if timed:
+            e1.record()
+            gather_events.append((e0, e1))
         return st, frame
 
     # exact counters for the algorithmic-bytes figure (deterministic; outside the timed region)
@@ -96,7 +104,7 @@ def main():
     kernel_ms = []
     rays = 0
     for _ in range(args.steps):
-        st, frame = step()
+        st, frame = step(timed=True)
         kernel_ms.append(st["kernel_ms"])
         rays += st["rays"]
     barrier()
@@ -109,6 +117,7 @@ def main():
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
     elapsed, total_rays = float(t.item()), float(r.item())
 
+    gather_ms = float(np.mean([a.elapsed_time(b) for a, b in gather_events])) if gather_events else 0.0
     if rank == 0:
         my_rows = int((frame_rows_of_part(H, 0, world) >= 0).sum())
         alg = bytes_alg(counted, W, my_rows)
@@ -133,6 +142,7 @@ def main():
                        "parallelism": f"interleaved 8-row strips over {world} GPU(s), one RCCL gather per frame"},
             "rays_per_frame": total_rays / args.steps, "paths_per_frame": W * H * spp,
             "mpaths_per_s": W * H * spp * args.steps / elapsed / 1e6,
+            "gather_ms": gather_ms,   # rank 0: RCCL gather (N > 1) + de-interleave copy kernel, per frame
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_trace_persistent", "kernel_ms": mean_kernel_ms, "algorithmic_bytes_per_launch": alg,

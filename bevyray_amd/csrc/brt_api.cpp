@@ -392,7 +392,13 @@ int32_t build_bvh_on_device(brt_ctx* ctx, const Model* models, uint32_t n, std::
     HIP_TRY(ctx, hipEventRecord(dc.ev1, dc.stream));
     out->resize(2 * (size_t)n - 1);
     HIP_TRY(ctx, hipMemcpyAsync(out->data(), d_out, out->size() * sizeof(BVHNode), hipMemcpyDeviceToHost, dc.stream));
+    uint32_t info[2] = {0u, 0u};
+    HIP_TRY(ctx, hipMemcpyAsync(info, d_info, sizeof info, hipMemcpyDeviceToHost, dc.stream));
     HIP_TRY(ctx, hipStreamSynchronize(dc.stream));
+    if (info[0] != 2u * n - 1u) {
+        out->clear();
+        return ctx_fail(ctx, BRT_ERR_HIP, "GPU BVH build made no progress after " + std::to_string(info[1]) + " rounds");
+    }
     float ms = 0.0f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, dc.ev0, dc.ev1));
     if (build_ms) *build_ms = ms;

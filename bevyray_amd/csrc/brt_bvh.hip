@@ -113,7 +113,8 @@ __global__ __launch_bounds__(BVH_BLOCK) void k_build_ploc(const Model* __restric
             const int hi = (int)i + PLOC_SEARCH > (int)m - 1 ? (int)m - 1 : (int)i + PLOC_SEARCH;
             for (int j = lo; j <= hi; j++) {
                 if (j == (int)i) continue;
-                const float a = ploc_half_area(ploc_merge(bi, box[cur[j]]));
+                const PlocBox bj_box = box[cur[j]];
+                const float a = j < (int)i ? ploc_pair_cost(bj_box, bi) : ploc_pair_cost(bi, bj_box);
                 if (ploc_better(a, (int)i, j, best, bj)) { best = a; bj = j; }
             }
             nn[i] = bj;
@@ -150,6 +151,11 @@ __global__ __launch_bounds__(BVH_BLOCK) void k_build_ploc(const Model* __restric
         m = total_keep;
         created += total_merge;
         rounds++;
+        if (total_merge == 0u) break;   // block-uniform; cannot happen (brt_ploc.h), but a build must never spin
+    }
+    if (m > 1) {
+        if (t == 0) { info[0] = 0u; info[1] = rounds; }
+        return;
     }
 
     // 5. numbering rule of brt_ploc.h

@@ -178,7 +178,7 @@ int32_t build_bvh_ploc(const Model* models, uint32_t n_models, std::vector<BVHNo
             const int32_t lo = std::max(0, i - PLOC_SEARCH), hi = std::min(m - 1, i + PLOC_SEARCH);
             for (int32_t j = lo; j <= hi; j++) {
                 if (j == i) continue;
-                const float a = ploc_half_area(ploc_merge(box[cur[i]], box[cur[j]]));
+                const float a = ploc_pair_cost(box[cur[std::min(i, j)]], box[cur[std::max(i, j)]]);
                 if (ploc_better(a, i, j, best, bj)) { best = a; bj = j; }
             }
             nn[i] = bj;
@@ -198,6 +198,7 @@ int32_t build_bvh_ploc(const Model* models, uint32_t n_models, std::vector<BVHNo
                 next.push_back(cur[i]);
             }
         }
+        if (next.size() == cur.size()) return BRT_ERR_INVALID_SCENE;   // cannot happen (brt_ploc.h: the cheapest pair is mutual)
         cur.swap(next);
     }
 

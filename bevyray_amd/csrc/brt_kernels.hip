@@ -226,8 +226,13 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                     if (c.inside) {
                         pixel_begin(fp, c, ps);
                         ps.rays_begin = n_rays;
-                        if (fp.sample_count == 0) pixel_finish(fp, ps, out_tile, raster_rgba, raster_depth);  // 0/0
-                        else { active = true; bounce = 0; }
+                        if (fp.sample_count == 0) {
+                            // 0/0 per channel.  The sums are compile-time zeros here; keep them opaque: hipcc 7.2
+                            // otherwise folds the four divisions into one and then drops two channels of the
+                            // level-1/2 result (found by scripts/fuzz_parity.py; tests: sample_count 0).
+                            asm volatile("" : "+v"(ps.sum.x), "+v"(ps.sum.y), "+v"(ps.sum.z), "+v"(ps.dsum));
+                            pixel_finish(fp, ps, out_tile, raster_rgba, raster_depth);
+                        } else { active = true; bounce = 0; }
                     }
                 }
             }

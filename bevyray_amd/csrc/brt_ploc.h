@@ -31,8 +31,10 @@ constexpr int PLOC_SEARCH = 24;   // build_ploc::<24>, extract.rs:316
 struct PlocBox {
     float mn[3], mx[3];
 };
-BRT_HD float ploc_min(float a, float b) { return (b < a) ? b : a; }   // std::min
-BRT_HD float ploc_max(float a, float b) { return (a < b) ? b : a; }   // std::max
+// min/max that ignore a NaN operand (a sphere with a NaN coordinate must not poison the scene box
+// or its ancestors, and the result must not depend on the order of a reduction)
+BRT_HD float ploc_min(float a, float b) { return (b < a || a != a) ? b : a; }
+BRT_HD float ploc_max(float a, float b) { return (a < b || a != a) ? b : a; }
 BRT_HD PlocBox ploc_merge(const PlocBox& a, const PlocBox& b) {
     PlocBox r;
     for (int k = 0; k < 3; k++) { r.mn[k] = ploc_min(a.mn[k], b.mn[k]); r.mx[k] = ploc_max(a.mx[k], b.mx[k]); }
@@ -42,11 +44,23 @@ BRT_HD float ploc_half_area(const PlocBox& b) {
     const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
     return (dx * dy + dy * dz) + dz * dx;
 }
+// Merge cost of two clusters; `first` is the one that comes first in the current cluster order, so
+// cost(i, j) == cost(j, i) bit for bit, and NaN (inf - inf, NaN boxes) counts as +inf: together with
+// ploc_better's tie rule the costs are strictly totally ordered and the cheapest pair of a round is
+// always mutual, i.e. every round merges at least once whatever the input.
+BRT_HD float ploc_pair_cost(const PlocBox& first, const PlocBox& second) {
+    const float h = ploc_half_area(ploc_merge(first, second));
+    return (h == h) ? h : __builtin_inff();
+}
 // Model::aabb, extract.rs:220-227: centre -+ (radius + 0.1)
 BRT_HD PlocBox ploc_model_box(const float* position, float radius) {
     const float pad = radius + 0.1f;
     PlocBox b;
-    for (int k = 0; k < 3; k++) { b.mn[k] = position[k] - pad; b.mx[k] = position[k] + pad; }
+    for (int k = 0; k < 3; k++) {
+        const float lo = position[k] - pad, hi = position[k] + pad;
+        b.mn[k] = (lo == lo) ? lo : __builtin_nanf("");   // one NaN bit pattern on every machine (x86 and gfx950
+        b.mx[k] = (hi == hi) ? hi : __builtin_nanf("");   // differ in the sign/payload they generate)
+    }
     return b;
 }
 BRT_HD uint64_t ploc_spread21(uint64_t x) {

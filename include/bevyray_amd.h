@@ -53,7 +53,7 @@ enum {
     BRT_ERR_NO_DEVICE = -2,        /* no HIP device / HIP runtime failure at create */
     BRT_ERR_HIP = -3,              /* a HIP call failed; text in brt_last_error */
     BRT_ERR_INVALID_BVH = -4,      /* node index out of range, cycle, leaf range out of range */
-    BRT_ERR_INVALID_SCENE = -5,    /* material_id out of range, non-finite sphere */
+    BRT_ERR_INVALID_SCENE = -5,    /* material_id out of range (non-finite spheres are accepted, as in the reference) */
     BRT_ERR_EMPTY_SCENE = -6,      /* zero spheres: the reference skips the pass (pipeline.rs:141-151) */
     BRT_ERR_NO_SCENE = -7,         /* render before upload */
     BRT_ERR_UNSUPPORTED = -8,      /* e.g. orthographic projection (extract.rs:148) */

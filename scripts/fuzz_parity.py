@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Soak test: adversarial random scenes, HIP path (through the C ABI) vs the CPU oracle, bit for bit.
+
+    python scripts/fuzz_parity.py --cases 600 --seed 7 [--log gpurun_out/fuzz.txt]
+
+Beyond tests/test_parity_gpu.py::test_randomized_scenes_bit_exact this injects the values the
+reference never guards against (raytrace.wgsl has no validation): zero / negative / huge / NaN /
+infinite radii and positions, coincident spheres (exact ties, raytrace.wgsl:353 strict `<`),
+materials outside [0,1], ior 0 and inf, cameras inside spheres, degenerate up vectors, window
+height 0 (infinite jitter), NaN / huge / negative random_seed, sample_count 0, bounce counts past the
+stack size, hand-made trees deeper than the 32-entry stack, multi-sphere leaves, and callee-built
+trees (GPU PLOC, checked byte for byte against the CPU builder).  A failing case is dumped to
+gpurun_out/fuzz_fail_<n>.npz.  Needs an MI355X; the oracle is the checker (test infrastructure).
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import bevyray_amd as brt                      # noqa: E402
+import oracle_loader                           # noqa: E402
+from helpers import chain_bvh, make_buffers, median_split_bvh, single_leaf_bvh, uniforms   # noqa: E402
+
+COUNTER_KEYS = ("rays", "node_pops", "interior_visits", "sphere_tests", "hits")
+SPECIAL = [0.0, -0.0, np.nan, np.inf, -np.inf, 3.0e38, -3.0e38, 1e-38, 1e-45, 1.0, -1.0, 1e6, 1e-6]
+
+
+def special(rng):
+    return float(SPECIAL[int(rng.integers(0, len(SPECIAL)))])
+
+
+def random_material(rng, wild):
+    def unit():
+        if wild and rng.random() < 0.15:
+            return special(rng) if rng.random() < 0.5 else float(rng.uniform(-2, 3))
+        return float(rng.choice([0.0, 1.0, rng.random()]))
+    ior = float(rng.uniform(0.3, 3.0))
+    if wild and rng.random() < 0.2:
+        ior = special(rng)
+    return brt.StandardMaterial(base_color=tuple(float(x) for x in rng.random(3)), metallic=unit(),
+                                perceptual_roughness=unit(), ior=ior, specular_transmission=unit())
+
+
+def random_case(rng):
+    wild = rng.random() < 0.5            # half of the cases stay "sane" but structurally varied
+    n = int(rng.choice([1, 2, 3, int(rng.integers(4, 40)), int(rng.integers(40, 400)), int(rng.integers(400, 3000))],
+                       p=[0.05, 0.05, 0.05, 0.45, 0.3, 0.1]))
+    spread = float(rng.choice([0.5, 4.0, 30.0]))
+    data = []
+    for i in range(n):
+        r = float(rng.uniform(0.05, 1.5)) if rng.random() < 0.9 else float(rng.uniform(20, 2000))
+        pos = [float(x) for x in rng.uniform(-spread, spread, 3)]
+        if r > 10:
+            pos[1] = -r - 1.0
+        data.append((tuple(pos), r, random_material(rng, wild)))
+    if n >= 2 and rng.random() < 0.3:    # coincident spheres: exact ties in t
+        for _ in range(int(rng.integers(1, 4))):
+            a, b = rng.integers(0, n, 2)
+            data[int(b)] = (data[int(a)][0], data[int(a)][1], data[int(b)][2])
+
+    topo = int(rng.integers(0, 5))
+    if n > 400 and topo in (1, 3):
+        topo = 0                          # single leaf / chain of 1000s of spheres: too slow for the oracle
+    bvh_fn = [None, single_leaf_bvh, lambda m: median_split_bvh(m, int(rng.integers(1, 9))), chain_bvh,
+              lambda m: chain_bvh(m, far_first=True)][topo]
+    if topo in (3, 4) and n < 2:
+        bvh_fn = single_leaf_bvh
+    b = brt.prepare_buffers([(p, brt.RaytracedSphere(r), m) for p, r, m in data])
+    models = b.models.copy()
+    if wild:
+        for _ in range(int(rng.integers(0, 4))):
+            i = int(rng.integers(0, n))
+            if rng.random() < 0.5:
+                models["radius"][i] = special(rng)
+            else:
+                models["position"][i, int(rng.integers(0, 3))] = special(rng)
+    bvh = None if bvh_fn is None else bvh_fn(models)
+    if bvh is not None and wild and rng.random() < 0.2:      # a poisoned box
+        k = int(rng.integers(0, len(bvh)))
+        bvh["bounds_min" if rng.random() < 0.5 else "bounds_max"][k, int(rng.integers(0, 3))] = special(rng)
+    b = brt.Buffers(models, b.materials, bvh)
+
+    big = n > 400
+    w, h = (int(rng.integers(1, 40)), int(rng.integers(1, 30))) if big else (int(rng.integers(1, 90)), int(rng.integers(1, 60)))
+    spp = int(rng.choice([0, 1, 2, 3, 5, 9, 33], p=[0.03, 0.3, 0.25, 0.2, 0.12, 0.07, 0.03]))
+    bounces = int(rng.choice([0, 1, 3, 8, 20, 70], p=[0.1, 0.15, 0.3, 0.3, 0.1, 0.05]))
+    per_ray = n if topo in (1, 3, 4) else 40          # sphere/box tests per ray, roughly
+    while w * h * max(spp, 1) * (bounces + 1) * per_ray > 2e8 and w * h > 1:   # keep the oracle under about a second
+        w, h = max(1, w // 2), max(1, (h * 2) // 3)
+    pos = tuple(float(x) for x in rng.uniform(-8, 8, 3))
+    if rng.random() < 0.15:               # camera inside (or on) a sphere
+        i = int(rng.integers(0, n))
+        pos = tuple(float(x) for x in np.nan_to_num(models["position"][i], nan=0.0, posinf=9.0, neginf=-9.0))
+    target = tuple(float(x) for x in rng.uniform(-1, 1, 3))
+    up = (0.0, 1.0, 0.0)
+    if wild and rng.random() < 0.1:
+        up = tuple(float(x) for x in rng.uniform(-1, 1, 3))
+    fov = float(rng.uniform(0.2, 1.5))
+    if wild and rng.random() < 0.15:
+        fov = float(rng.choice([1e-4, 3.1, 3.14159274, 0.0, 6.0]))
+    seed = float(np.float32(rng.random()))
+    if wild and rng.random() < 0.2:
+        seed = float(rng.choice([0.0, 1.0, -0.5, 1e9, np.nan, np.inf, 1e-30]))
+    window_height = int(rng.integers(1, 2400))
+    if wild and rng.random() < 0.05:
+        window_height = 0
+    near, far = 0.1, 1000.0
+    if wild and rng.random() < 0.1:
+        near, far = float(rng.choice([0.0, 5.0, 1e4])), float(rng.choice([0.0, 1.0, 1e30]))
+    lvl, cam, win = uniforms(w, h, spp=spp, bounces=bounces, pos=pos, target=target, fov=fov, seed=seed,
+                             level=brt.Raytracing(int(rng.integers(0, 4))), near=near, far=far, up=up,
+                             window_height=window_height)
+    raster = depth = None
+    if rng.random() < 0.4:
+        raster = rng.random((h, w, 4), dtype=np.float32)
+        depth = rng.random((h, w), dtype=np.float32) * np.float32(rng.choice([0.05, 1.0]))
+        if wild and rng.random() < 0.3:
+            depth[rng.random((h, w)) < 0.1] = np.float32(special(rng))
+    return dict(buffers=b, level=lvl, camera=cam, window=win, w=w, h=h, raster=raster, depth=depth, wild=wild, topo=topo)
+
+
+def frames_differ(got, want):
+    got, want = np.asarray(got, np.float32), np.asarray(want, np.float32)
+    same = got.view(np.uint32) == want.view(np.uint32)
+    both_nan = np.isnan(got) & np.isnan(want)
+    return int((~(same | both_nan)).sum())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=300)
+    ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--log", default=None)
+    ap.add_argument("--seconds", type=float, default=1e9, help="stop after this much wall time")
+    args = ap.parse_args()
+
+    oracle = oracle_loader.load()
+    plugin = brt.RaytracePlugin([0])
+    node = plugin.node
+    rng = np.random.default_rng(args.seed)
+    t_start = time.time()
+    fails, done, pixels, rays, ploc_checked, rejected = 0, 0, 0, 0, 0, 0
+    lines = []
+    for case in range(args.cases):
+        if time.time() - t_start > args.seconds:
+            break
+        c = random_case(rng)
+        b = c["buffers"]
+        try:
+            if b.bvh is None:             # callee-built: GPU PLOC must equal the CPU builder byte for byte
+                cpu_nodes = brt.build_bvh(b.models)
+                gpu_nodes, _ = plugin.build_bvh(b.models)
+                ploc_checked += 1
+                ob = brt.Buffers(b.models, b.materials, cpu_nodes)
+                if cpu_nodes.tobytes() != gpu_nodes.tobytes():
+                    raise AssertionError("GPU PLOC tree differs from the CPU builder's")
+            else:
+                ob = b
+            try:
+                got = node.run(c["level"], c["camera"], c["window"], c["w"], c["h"], buffers=b, raster_rgba=c["raster"],
+                               raster_depth=c["depth"], flags=brt.FLAG_COUNTERS)
+            except brt.BrtError as e:   # a poisoned scene may be refused: then the oracle's validator must agree
+                rejected += 1
+                lines.append(f"case {case}: refused by the library ({e})")
+                continue
+            want, cnt = oracle.render(ob, c["level"], c["camera"], c["window"], c["w"], c["h"], raster_rgba=c["raster"],
+                                      raster_depth=c["depth"])
+            bad = frames_differ(got, want)
+            stats = node.last_stats
+            if bad:
+                raise AssertionError(f"{bad} of {got.size} frame values differ")
+            if {k: stats[k] for k in COUNTER_KEYS} != cnt:
+                raise AssertionError(f"counters differ: gpu { {k: stats[k] for k in COUNTER_KEYS} } oracle {cnt}")
+            done += 1
+            pixels += c["w"] * c["h"]
+            rays += cnt["rays"]
+        except AssertionError as e:
+            fails += 1
+            msg = (f"case {case} FAILED: {e} | {len(b.models)} spheres, topo {c['topo']}, wild {c['wild']}, {c['w']}x{c['h']}, "
+                   f"level {int(c['level'][0]['level']) if hasattr(c['level'], 'dtype') else c['level']}")
+            print(msg, flush=True)
+            lines.append(msg)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            np.savez(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_{case}.npz"), models=b.models.view(np.uint8),
+                     materials=b.materials.view(np.uint8), bvh=(ob.bvh if b.bvh is None else b.bvh).view(np.uint8),
+                     level=np.asarray(c["level"]).view(np.uint8), camera=np.asarray(c["camera"]).view(np.uint8),
+                     window=np.asarray(c["window"]).view(np.uint8), size=np.array([c["w"], c["h"]]),
+                     raster=np.zeros(0) if c["raster"] is None else c["raster"], depth=np.zeros(0) if c["depth"] is None else c["depth"])
+    summary = (f"fuzz_parity seed {args.seed}: {done} cases bit-exact (frames + 5 counters), {fails} failed, {rejected} refused; "
+               f"{pixels} pixels, {rays} rays; {ploc_checked} callee-built trees byte-identical CPU vs GPU; "
+               f"{time.time() - t_start:.0f} s")
+    print(summary, flush=True)
+    if args.log:
+        os.makedirs(os.path.dirname(os.path.abspath(args.log)), exist_ok=True)
+        with open(args.log, "a") as f:
+            f.write("\n".join(lines + [summary]) + "\n")
+    plugin.close()
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()

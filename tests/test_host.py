@@ -120,6 +120,31 @@ def test_scene_generators_and_ploc_contract(kind, count):
     assert not np.array_equal(b.models["position"][1:50], b3.models["position"][1:50])
 
 
+def test_ploc_builder_terminates_on_non_finite_spheres():
+    """The reference never validates spheres, so NaN / inf positions and radii reach the builder.
+    Merge costs must stay symmetric and totally ordered (brt_ploc.h) or a round merges nothing and
+    the build spins -- found by scripts/fuzz_parity.py with one NaN coordinate among 12 spheres."""
+    rng = np.random.default_rng(58)
+    for trial in range(200):
+        n = int(rng.integers(2, 80))
+        m = np.zeros(n, brt.MODEL_DTYPE)
+        m["position"] = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+        m["radius"] = rng.uniform(0.05, 1.5, n).astype(np.float32)
+        for _ in range(int(rng.integers(1, 5))):
+            bad = rng.choice([np.nan, np.inf, -np.inf, 3e38, -3e38, 0.0])
+            if rng.random() < 0.5:
+                m["position"][int(rng.integers(0, n)), int(rng.integers(0, 3))] = bad
+            else:
+                m["radius"][int(rng.integers(0, n))] = bad
+        if rng.random() < 0.3:
+            m[int(rng.integers(0, n))] = m[int(rng.integers(0, n))]
+        nodes = brt.build_bvh(m)
+        assert len(nodes) == 2 * n - 1
+        assert brt.validate_scene(m, np.zeros(1, brt.MATERIAL_DTYPE), nodes) >= 0
+        leaves = nodes[nodes["model_count"] > 0]
+        assert sorted(leaves["index"].tolist()) == list(range(n))
+
+
 def test_cover_scene_material_lottery():
     b = brt.generate_scene(brt.SCENE_COVER, 1)
     small = b.materials[1:-3]

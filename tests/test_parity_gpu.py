@@ -348,6 +348,13 @@ def test_gpu_ploc_build_is_byte_identical_to_cpu_build(plugin, oracle):
     dup = np.zeros(300, brt.MODEL_DTYPE); dup["position"] = (1.0, 2.0, 3.0); dup["radius"] = 0.5    # all Morton codes and areas tie
     line = np.zeros(200, brt.MODEL_DTYPE); line["position"][:, 0] = np.arange(200, dtype=np.float32); line["radius"] = 0.25
     scenes += [dup, line]
+    for bad in (np.nan, np.inf, -np.inf, 3e38):       # non-finite spheres: same tree, same (canonical) NaN bits
+        m = np.zeros(150, brt.MODEL_DTYPE)
+        m["position"] = rng.uniform(-5, 5, (150, 3)).astype(np.float32)
+        m["radius"] = rng.uniform(0.1, 1.0, 150).astype(np.float32)
+        m["position"][::7, 2] = bad
+        m["radius"][3::11] = bad
+        scenes.append(m)
     for models in scenes:
         cpu = brt.build_bvh(models)
         gpu, ms = plugin.build_bvh(models)
@@ -361,6 +368,22 @@ def test_gpu_ploc_build_is_byte_identical_to_cpu_build(plugin, oracle):
     s1 = dict(plugin.node.last_stats)
     f2 = plugin.node.run(lvl, cam, win, 96, 54, buffers=brt.Buffers(b.models, b.materials, None), flags=brt.FLAG_COUNTERS)
     assert_frames_equal(f1, f2) and all(plugin.node.last_stats[k] == s1[k] for k in COUNTER_KEYS)
+
+
+@pytest.mark.parametrize("level", [0, 1, 2, 3])
+def test_sample_count_zero_is_zero_over_zero(plugin, oracle, level):
+    """raytrace.wgsl:161-170 with sample_count 0: every channel is 0/0 = NaN (and the depth test of
+    levels 1/2 sees NaN, so the raster never wins).  Regression: a compiler fold once dropped two channels."""
+    b = fixture_buffers()[0]
+    w, h = 23, 9
+    lvl, cam, win = uniforms(w, h, spp=0, bounces=4, pos=(13.0, 2.0, 3.0), target=(0.0, 0.0, 0.0), fov=0.4, seed=0.5,
+                             level=brt.Raytracing(level))
+    rng = np.random.default_rng(5)
+    for raster, depth in ((None, None), (rng.random((h, w, 4), dtype=np.float32), rng.random((h, w), dtype=np.float32))):
+        got, stats = render_both(plugin, oracle, b, lvl, cam, win, w, h, raster=raster, depth=depth)
+        assert stats["rays"] == 0
+        if level != 0:
+            assert np.isnan(got[..., :3]).all() and (got[..., 3] == 1.0).all()
 
 
 # ---- launch-shape and scheduling knobs must never change a pixel -------------------------------------------------
