@@ -49,8 +49,9 @@ def random_material(rng, wild):
 
 def random_case(rng):
     wild = rng.random() < 0.5            # half of the cases stay "sane" but structurally varied
-    n = int(rng.choice([1, 2, 3, int(rng.integers(4, 40)), int(rng.integers(40, 400)), int(rng.integers(400, 3000))],
-                       p=[0.05, 0.05, 0.05, 0.45, 0.3, 0.1]))
+    n = int(rng.choice([1, 2, 3, int(rng.integers(4, 40)), int(rng.integers(40, 400)), int(rng.integers(400, 3000)),
+                        int(rng.integers(8200, 12000))],      # > 16382 nodes: 32-bit descriptors
+                       p=[0.05, 0.05, 0.05, 0.45, 0.29, 0.1, 0.01]))
     spread = float(rng.choice([0.5, 4.0, 30.0]))
     data = []
     for i in range(n):
@@ -88,6 +89,8 @@ def random_case(rng):
 
     big = n > 400
     w, h = (int(rng.integers(1, 40)), int(rng.integers(1, 30))) if big else (int(rng.integers(1, 90)), int(rng.integers(1, 60)))
+    if rng.random() < 0.1:
+        h = int(rng.integers(60, 200))    # enough 8-row strips for every part of an 8-way split
     spp = int(rng.choice([0, 1, 2, 3, 5, 9, 33], p=[0.03, 0.3, 0.25, 0.2, 0.12, 0.07, 0.03]))
     bounces = int(rng.choice([0, 1, 3, 8, 20, 70], p=[0.1, 0.15, 0.3, 0.3, 0.1, 0.05]))
     per_ray = n if topo in (1, 3, 4) else 40          # sphere/box tests per ray, roughly
@@ -122,7 +125,9 @@ def random_case(rng):
         depth = rng.random((h, w), dtype=np.float32) * np.float32(rng.choice([0.05, 1.0]))
         if wild and rng.random() < 0.3:
             depth[rng.random((h, w)) < 0.1] = np.float32(special(rng))
-    return dict(buffers=b, level=lvl, camera=cam, window=win, w=w, h=h, raster=raster, depth=depth, wild=wild, topo=topo)
+    mode = str(rng.choice(["run", "multi", "parts", "simple"], p=[0.6, 0.15, 0.15, 0.1]))
+    return dict(buffers=b, level=lvl, camera=cam, window=win, w=w, h=h, raster=raster, depth=depth, wild=wild, topo=topo,
+                mode=mode, n_parts=int(rng.choice([2, 3, 5, 8])))
 
 
 def frames_differ(got, want):
@@ -140,9 +145,42 @@ def main():
     ap.add_argument("--seconds", type=float, default=1e9, help="stop after this much wall time")
     args = ap.parse_args()
 
+    import torch
+    from bevyray_amd.parallel import frame_rows_of_part
     oracle = oracle_loader.load()
     plugin = brt.RaytracePlugin([0])
+    multi = brt.RaytracePlugin([0, 0, 0])      # three sub-contexts on one GPU: the in-process strip split of brt_render
     node = plugin.node
+
+    def render(c, b):
+        """-> (frame, stats or None): the four ways a frame can be produced through the C ABI"""
+        args = (c["level"], c["camera"], c["window"], c["w"], c["h"])
+        if c["mode"] == "multi":
+            got = multi.node.run(*args, buffers=b, raster_rgba=c["raster"], raster_depth=c["depth"], flags=brt.FLAG_COUNTERS)
+            return got, multi.node.last_stats
+        if c["mode"] == "simple":
+            got = node.run(*args, buffers=b, raster_rgba=c["raster"], raster_depth=c["depth"],
+                           flags=brt.FLAG_COUNTERS | brt.FLAG_KERNEL_SIMPLE)
+            return got, node.last_stats
+        if c["mode"] == "parts":
+            w, h, n_parts = c["w"], c["h"], c["n_parts"]
+            node.write_buffers(b)
+            rows = brt.tile_rows(h, n_parts)
+            tiles = torch.zeros((n_parts, rows, w, 4), dtype=torch.float32, device="cuda")
+            d_r = None if c["raster"] is None else torch.from_numpy(c["raster"]).cuda()
+            d_d = None if c["depth"] is None else torch.from_numpy(c["depth"]).cuda()
+            rays = 0
+            for p in range(n_parts):
+                st = node.render_part_device(*args, p, n_parts, tiles[p].data_ptr(),
+                                             d_raster_rgba=0 if d_r is None else d_r.data_ptr(),
+                                             d_raster_depth=0 if d_d is None else d_d.data_ptr())
+                rays += st["rays"]
+            frame = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+            node.deinterleave_device(tiles.data_ptr(), n_parts, w, h, frame.data_ptr())
+            torch.cuda.synchronize()
+            return frame.cpu().numpy(), {"rays": rays}
+        got = node.run(*args, buffers=b, raster_rgba=c["raster"], raster_depth=c["depth"], flags=brt.FLAG_COUNTERS)
+        return got, node.last_stats
     rng = np.random.default_rng(args.seed)
     t_start = time.time()
     fails, done, pixels, rays, ploc_checked, rejected = 0, 0, 0, 0, 0, 0
@@ -163,8 +201,7 @@ def main():
             else:
                 ob = b
             try:
-                got = node.run(c["level"], c["camera"], c["window"], c["w"], c["h"], buffers=b, raster_rgba=c["raster"],
-                               raster_depth=c["depth"], flags=brt.FLAG_COUNTERS)
+                got, stats = render(c, b)
             except brt.BrtError as e:   # a poisoned scene may be refused: then the oracle's validator must agree
                 rejected += 1
                 lines.append(f"case {case}: refused by the library ({e})")
@@ -172,17 +209,17 @@ def main():
             want, cnt = oracle.render(ob, c["level"], c["camera"], c["window"], c["w"], c["h"], raster_rgba=c["raster"],
                                       raster_depth=c["depth"])
             bad = frames_differ(got, want)
-            stats = node.last_stats
             if bad:
                 raise AssertionError(f"{bad} of {got.size} frame values differ")
-            if {k: stats[k] for k in COUNTER_KEYS} != cnt:
-                raise AssertionError(f"counters differ: gpu { {k: stats[k] for k in COUNTER_KEYS} } oracle {cnt}")
+            keys = COUNTER_KEYS if c["mode"] != "parts" else ("rays",)
+            if {k: stats[k] for k in keys} != {k: cnt[k] for k in keys}:
+                raise AssertionError(f"counters differ: gpu { {k: stats[k] for k in keys} } oracle {cnt}")
             done += 1
             pixels += c["w"] * c["h"]
             rays += cnt["rays"]
         except AssertionError as e:
             fails += 1
-            msg = (f"case {case} FAILED: {e} | {len(b.models)} spheres, topo {c['topo']}, wild {c['wild']}, {c['w']}x{c['h']}, "
+            msg = (f"case {case} FAILED: {e} | {len(b.models)} spheres, topo {c['topo']}, wild {c['wild']}, mode {c['mode']}/{c['n_parts']}, {c['w']}x{c['h']}, "
                    f"level {int(c['level'][0]['level']) if hasattr(c['level'], 'dtype') else c['level']}")
             print(msg, flush=True)
             lines.append(msg)
@@ -200,6 +237,7 @@ def main():
         os.makedirs(os.path.dirname(os.path.abspath(args.log)), exist_ok=True)
         with open(args.log, "a") as f:
             f.write("\n".join(lines + [summary]) + "\n")
+    multi.close()
     plugin.close()
     sys.exit(1 if fails else 0)
 
