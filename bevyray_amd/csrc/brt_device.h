@@ -179,7 +179,12 @@ BRT_DEV void raycast(const ScenePtrs& sc, uint32_t root_desc, StackT* stk, uint3
             n = has ? n - 1u : 0u;
             const uint32_t popped = stk[n * STRIDE];
             cur = has ? popped : DS::DONE;
-        } else {
+        }
+        // NOT `else`: a lane that has just tested a leaf and popped an interior node takes the
+        // interior step in the same iteration (the wave runs both bodies in almost every iteration
+        // anyway), so the bodies alternate L I L I ... and a lane only waits when it needs the same
+        // body twice in a row.  DONE has the LEAF bit set, so it never enters here.
+        if (!(cur & DS::LEAF) && (SIMPLE_TREE || n < 31u)) {
             if (COUNTERS) { hc.node_pops++; hc.interior++; }
             if (STRIDE == 64) prof_section<COUNTERS>(hc, SEC_INTERIOR, true);
             const float4 A = sc.q0[cur], B = sc.q1[cur], C = sc.q2[cur];
