@@ -522,9 +522,8 @@ int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, co
 
     // one blob per device, sections 256-byte aligned
     struct Sec { const void* src; size_t bytes; size_t off; };
-    Sec secs[8] = {
-        {e.q0.data(), e.q0.size() * 4, 0}, {e.q1.data(), e.q1.size() * 4, 0}, {e.q2.data(), e.q2.size() * 4, 0},
-        {e.qd.data(), e.qd.size() * 4, 0}, {e.spheres.data(), e.spheres.size() * 4, 0},
+    Sec secs[5] = {
+        {e.pairs.data(), e.pairs.size() * 4, 0}, {e.spheres.data(), e.spheres.size() * 4, 0},
         {e.sphere_material.data(), e.sphere_material.size() * 4, 0}, {e.materials.data(), e.materials.size() * 4, 0},
         {e.leaf_table.data(), e.leaf_table.size() * 4, 0}};
     size_t total = 0;
@@ -537,14 +536,11 @@ int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, co
         for (auto& s : secs)
             if (s.bytes) HIP_TRY(ctx, hipMemcpyAsync(dc.d_scene + s.off, s.src, s.bytes, hipMemcpyHostToDevice, dc.stream));
         DeviceSceneView v{};
-        v.q0 = reinterpret_cast<const float*>(dc.d_scene + secs[0].off);
-        v.q1 = reinterpret_cast<const float*>(dc.d_scene + secs[1].off);
-        v.q2 = reinterpret_cast<const float*>(dc.d_scene + secs[2].off);
-        v.qd = reinterpret_cast<const uint32_t*>(dc.d_scene + secs[3].off);
-        v.spheres = reinterpret_cast<const float*>(dc.d_scene + secs[4].off);
-        v.sphere_material = reinterpret_cast<const uint32_t*>(dc.d_scene + secs[5].off);
-        v.materials = reinterpret_cast<const float*>(dc.d_scene + secs[6].off);
-        v.leaf_table = reinterpret_cast<const uint32_t*>(dc.d_scene + secs[7].off);
+        v.pairs = reinterpret_cast<const float*>(dc.d_scene + secs[0].off);
+        v.spheres = reinterpret_cast<const float*>(dc.d_scene + secs[1].off);
+        v.sphere_material = reinterpret_cast<const uint32_t*>(dc.d_scene + secs[2].off);
+        v.materials = reinterpret_cast<const float*>(dc.d_scene + secs[3].off);
+        v.leaf_table = reinterpret_cast<const uint32_t*>(dc.d_scene + secs[4].off);
         v.n_pairs = e.n_pairs;
         v.n_models = e.n_models;
         v.n_materials = e.n_materials;

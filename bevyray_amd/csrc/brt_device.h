@@ -80,9 +80,10 @@ BRT_DEV bool slab_push(f3 o, f3 inv, f3 bmin, f3 bmax, float closest) {
     const float t_far = min_f(min_f(max_f(tminx, tmaxx), max_f(tminy, tmaxy)), max_f(tminz, tmaxz));
     const bool hit = (t_far >= t_near) && (t_far > 0.0f);
     // dst = hit ? (t_near > 0 ? t_near : 0) : INF;  pushed iff dst != INF && dst < closest.
-    // closest <= INF always, so `dst < closest` already implies `dst != INF`; and for a hit
-    // t_near is not NaN, so select(0, t_near, t_near > 0) == max(t_near, 0) in the compare.
-    return hit && (max_f(t_near, 0.0f) < closest);
+    // closest <= INF always, so `dst < closest` already implies `dst != INF`.  closest is INF or an
+    // accepted t > 0.001 (sphere_test), i.e. always > 0, and for a hit t_near is not NaN, so
+    // `max(t_near, 0) < closest` == `t_near < closest`: the clamp never changes the outcome.
+    return hit && (t_near < closest);
 }
 
 // raytrace.wgsl:371-383 + the accept test of :353-354.  `a` = dot(d,d) hoisted per ray,
@@ -102,10 +103,7 @@ BRT_DEV void sphere_test(f3 o, f3 d, float a, float4 s, uint32_t idx, float& clo
 // Scene accessors.  The persistent kernel instantiates with LDS pointers, the bring-up
 // kernel and the large-scene variant with global pointers.
 struct ScenePtrs {
-    const float4* q0;
-    const float4* q1;
-    const float4* q2;
-    const uint2* qd;
+    const float4* pairs;     // 4 per record: boxes of both children, then the two descriptors
     const float4* spheres;
     const uint32_t* sphere_material;
     const float4* materials;
@@ -161,7 +159,7 @@ BRT_DEV void raycast(const ScenePtrs& sc, uint32_t root_desc, StackT* stk, uint3
     uint32_t cur = root_desc;
     uint32_t n = 0;
     while (cur != DS::DONE && (SIMPLE_TREE || n < 31u)) {
-        if (cur & DS::LEAF) {
+        if (cur >= DS::LEAF) {                          // LEAF is the top bit in use: one compare, no mask
             if (COUNTERS) hc.node_pops++;
             if (STRIDE == 64) prof_section<COUNTERS>(hc, SEC_LEAF, true);
             const uint32_t first = cur & DS::INDEX_MASK;
@@ -184,18 +182,22 @@ BRT_DEV void raycast(const ScenePtrs& sc, uint32_t root_desc, StackT* stk, uint3
         // interior step in the same iteration (the wave runs both bodies in almost every iteration
         // anyway), so the bodies alternate L I L I ... and a lane only waits when it needs the same
         // body twice in a row.  DONE has the LEAF bit set, so it never enters here.
-        if (!(cur & DS::LEAF) && (SIMPLE_TREE || n < 31u)) {
+        if (cur < DS::LEAF && (SIMPLE_TREE || n < 31u)) {
             if (COUNTERS) { hc.node_pops++; hc.interior++; }
             if (STRIDE == 64) prof_section<COUNTERS>(hc, SEC_INTERIOR, true);
-            const float4 A = sc.q0[cur], B = sc.q1[cur], C = sc.q2[cur];
-            const uint2 D = sc.qd[cur];
+            const float4* rec = sc.pairs + 4u * cur;
+            const float4 A = rec[0], B = rec[1], C = rec[2];
+            const uint2 D = *reinterpret_cast<const uint2*>(rec + 3);
+            // the would-be pop, issued with the node reads so that its LDS latency hides behind the slab
+            // arithmetic.  It never aliases the store below (entry n or the dummy) when it is used:
+            // with n == 0 it reads entry 0, which a both-push overwrites, but then nothing is popped.
+            const uint32_t popped = stk[(n > 0u ? n - 1u : 0u) * STRIDE];
             const bool p1 = slab_push(o, inv, mk3(A.x, A.y, A.z), mk3(A.w, B.x, B.y), closest);
             const bool p2 = slab_push(o, inv, mk3(B.z, B.w, C.x), mk3(C.y, C.z, C.w), closest);
             // reference: push `index` (D.x) then `index+1` (D.y); the later push is popped first
             const bool both = p1 && p2, none = !p1 && !p2;
             stk[(both ? n : dummy_entry) * STRIDE] = (StackT)D.x;
             const bool can_pop = none && n > 0u;
-            const uint32_t popped = stk[(n > 0u ? n - 1u : 0u) * STRIDE];   // != the slot just written
             cur = p2 ? D.y : (p1 ? D.x : (can_pop ? popped : DS::DONE));
             n = both ? n + 1u : (can_pop ? n - 1u : n);
         }

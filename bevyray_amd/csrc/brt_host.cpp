@@ -90,10 +90,7 @@ int32_t validate_and_encode(const Model* models, uint32_t n_models, const Materi
     EncodedScene& e = *out;
     e = EncodedScene();
     e.n_pairs = (uint32_t)order.size();
-    e.q0.resize(4 * (size_t)e.n_pairs);
-    e.q1.resize(4 * (size_t)e.n_pairs);
-    e.q2.resize(4 * (size_t)e.n_pairs);
-    e.qd.resize(2 * (size_t)e.n_pairs);
+    e.pairs.assign(16 * (size_t)e.n_pairs, 0.0f);
 
     // 16-bit descriptors when every index fits 14 bits (general leaves <= nodes)
     e.desc16 = (n_models <= DESC16_MAX_INDEX) && (n_nodes <= DESC16_MAX_INDEX);
@@ -114,14 +111,14 @@ int32_t validate_and_encode(const Model* models, uint32_t n_models, const Materi
         const BVHNode& nd = nodes[order[i]];
         const BVHNode& L = nodes[nd.index];
         const BVHNode& R = nodes[nd.index + 1];
-        float* a = &e.q0[4 * (size_t)i];
-        float* b = &e.q1[4 * (size_t)i];
-        float* c = &e.q2[4 * (size_t)i];
+        float* a = &e.pairs[16 * (size_t)i];
+        float* b = a + 4;
+        float* c = a + 8;
         a[0] = L.bounds_min[0]; a[1] = L.bounds_min[1]; a[2] = L.bounds_min[2]; a[3] = L.bounds_max[0];
         b[0] = L.bounds_max[1]; b[1] = L.bounds_max[2]; b[2] = R.bounds_min[0]; b[3] = R.bounds_min[1];
         c[0] = R.bounds_min[2]; c[1] = R.bounds_max[0]; c[2] = R.bounds_max[1]; c[3] = R.bounds_max[2];
-        e.qd[2 * (size_t)i] = desc_of(nd.index);
-        e.qd[2 * (size_t)i + 1] = desc_of(nd.index + 1);
+        const uint32_t dd[2] = {desc_of(nd.index), desc_of(nd.index + 1)};
+        std::memcpy(a + 12, dd, sizeof dd);
     }
 
     e.n_models = n_models;

@@ -14,8 +14,7 @@ int32_t fail(int32_t code, const std::string& msg);
 
 // Scene in the device encoding (brt_layout.h), still in host vectors.
 struct EncodedScene {
-    std::vector<float> q0, q1, q2;       // 4 floats per pair record each
-    std::vector<uint32_t> qd;            // 2 per pair record
+    std::vector<float> pairs;            // 16 floats per pair record (brt_layout.h)
     std::vector<float> spheres;          // 4 per model
     std::vector<uint32_t> sphere_material;
     std::vector<float> materials;        // 8 per material

@@ -154,37 +154,26 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     StackT* stacks;
     sc.materials = reinterpret_cast<const float4*>(sv.materials);
     if (LDS_SCENE) {
-        // carve: q0 | q1 | q2 | spheres | qd | leaf_table | sphere_material | stacks
+        // carve: pair records | spheres | leaf_table | sphere_material | stacks
         float4* p = reinterpret_cast<float4*>(smem);
-        float4* l_q0 = p; p += sv.n_pairs;
-        float4* l_q1 = p; p += sv.n_pairs;
-        float4* l_q2 = p; p += sv.n_pairs;
+        float4* l_pairs = p; p += 4u * sv.n_pairs;
         float4* l_sp = p; p += sv.n_models;
         uint2* p2 = reinterpret_cast<uint2*>(p);
-        uint2* l_qd = p2; p2 += sv.n_pairs;
         uint2* l_lt = p2; p2 += sv.n_leaf_table;
         uint32_t* p1 = reinterpret_cast<uint32_t*>(p2);
         uint32_t* l_sm = p1; p1 += sv.n_models;
         stacks = reinterpret_cast<StackT*>(p1);
-        const float4* g_q0 = reinterpret_cast<const float4*>(sv.q0);
-        const float4* g_q1 = reinterpret_cast<const float4*>(sv.q1);
-        const float4* g_q2 = reinterpret_cast<const float4*>(sv.q2);
+        const float4* g_pairs = reinterpret_cast<const float4*>(sv.pairs);
         const float4* g_sp = reinterpret_cast<const float4*>(sv.spheres);
-        const uint2* g_qd = reinterpret_cast<const uint2*>(sv.qd);
         const uint2* g_lt = reinterpret_cast<const uint2*>(sv.leaf_table);
-        for (uint32_t i = threadIdx.x; i < sv.n_pairs; i += blockDim.x) {
-            l_q0[i] = g_q0[i]; l_q1[i] = g_q1[i]; l_q2[i] = g_q2[i]; l_qd[i] = g_qd[i];
-        }
+        for (uint32_t i = threadIdx.x; i < 4u * sv.n_pairs; i += blockDim.x) l_pairs[i] = g_pairs[i];
         for (uint32_t i = threadIdx.x; i < sv.n_models; i += blockDim.x) { l_sp[i] = g_sp[i]; l_sm[i] = sv.sphere_material[i]; }
         for (uint32_t i = threadIdx.x; i < sv.n_leaf_table; i += blockDim.x) l_lt[i] = g_lt[i];
-        sc.q0 = l_q0; sc.q1 = l_q1; sc.q2 = l_q2; sc.qd = l_qd;
+        sc.pairs = l_pairs;
         sc.spheres = l_sp; sc.sphere_material = l_sm; sc.leaf_table = l_lt;
         __syncthreads();
     } else {
-        sc.q0 = reinterpret_cast<const float4*>(sv.q0);
-        sc.q1 = reinterpret_cast<const float4*>(sv.q1);
-        sc.q2 = reinterpret_cast<const float4*>(sv.q2);
-        sc.qd = reinterpret_cast<const uint2*>(sv.qd);
+        sc.pairs = reinterpret_cast<const float4*>(sv.pairs);
         sc.spheres = reinterpret_cast<const float4*>(sv.spheres);
         sc.sphere_material = sv.sphere_material;
         sc.leaf_table = reinterpret_cast<const uint2*>(sv.leaf_table);
@@ -321,23 +310,17 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_bench_trace(DeviceSceneView sv, c
     extern __shared__ uint4 smem[];
     ScenePtrs sc;
     float4* p = reinterpret_cast<float4*>(smem);
-    float4* l_q0 = p; p += sv.n_pairs;
-    float4* l_q1 = p; p += sv.n_pairs;
-    float4* l_q2 = p; p += sv.n_pairs;
+    float4* l_pairs = p; p += 4u * sv.n_pairs;
     float4* l_sp = p; p += sv.n_models;
     float4* l_ra = p; p += BENCH_CHUNK;          // ray chunk: {o.xyz, d.x}
     uint2* p2 = reinterpret_cast<uint2*>(p);
     uint2* l_rb = p2; p2 += BENCH_CHUNK;         //            {d.y, d.z}
-    uint2* l_qd = p2; p2 += sv.n_pairs;
     uint32_t* pw = reinterpret_cast<uint32_t*>(p2);
     uint32_t* l_head = pw; pw += 4;
     uint16_t* stacks = reinterpret_cast<uint16_t*>(pw);
-    for (uint32_t i = threadIdx.x; i < sv.n_pairs; i += blockDim.x) {
-        l_q0[i] = reinterpret_cast<const float4*>(sv.q0)[i]; l_q1[i] = reinterpret_cast<const float4*>(sv.q1)[i];
-        l_q2[i] = reinterpret_cast<const float4*>(sv.q2)[i]; l_qd[i] = reinterpret_cast<const uint2*>(sv.qd)[i];
-    }
+    for (uint32_t i = threadIdx.x; i < 4u * sv.n_pairs; i += blockDim.x) l_pairs[i] = reinterpret_cast<const float4*>(sv.pairs)[i];
     for (uint32_t i = threadIdx.x; i < sv.n_models; i += blockDim.x) l_sp[i] = reinterpret_cast<const float4*>(sv.spheres)[i];
-    sc.q0 = l_q0; sc.q1 = l_q1; sc.q2 = l_q2; sc.qd = l_qd; sc.spheres = l_sp;
+    sc.pairs = l_pairs; sc.spheres = l_sp;
     sc.sphere_material = sv.sphere_material; sc.materials = nullptr; sc.leaf_table = nullptr;
     const uint32_t lane = lane_id();
     uint16_t* stk = stacks + (threadIdx.x >> 6) * ((sv.stack_entries + 1u) * 64u) + lane;
@@ -395,8 +378,9 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_bench_trace(DeviceSceneView sv, c
                     const uint32_t popped = stk[n * 64];
                     cur = has ? popped : DS::DONE;
                 } else {
-                    const float4 A = sc.q0[cur], B = sc.q1[cur], C = sc.q2[cur];
-                    const uint2 D = sc.qd[cur];
+                    const float4* rec = sc.pairs + 4u * cur;
+                    const float4 A = rec[0], B = rec[1], C = rec[2];
+                    const uint2 D = *reinterpret_cast<const uint2*>(rec + 3);
                     const bool p1 = slab_push(o, inv, mk3(A.x, A.y, A.z), mk3(A.w, B.x, B.y), closest);
                     const bool p2b = slab_push(o, inv, mk3(B.z, B.w, C.x), mk3(C.y, C.z, C.w), closest);
                     const bool both = p1 && p2b, none = !p1 && !p2b;
@@ -420,7 +404,7 @@ hipError_t launch_bench_trace(int mode, const DeviceSceneView& sv, const float* 
     const char* ec = getenv("BRT_BENCH_CHUNK");
     const uint32_t block = eb ? (uint32_t)atoi(eb) : (uint32_t)BRT_BLOCK;
     const uint32_t chunk = ec ? (uint32_t)atoi(ec) : 2048u;
-    const size_t lds = (size_t)sv.n_pairs * 56 + (size_t)sv.n_models * 16 + (size_t)chunk * 24 + 16 +
+    const size_t lds = (size_t)sv.n_pairs * 64 + (size_t)sv.n_models * 16 + (size_t)chunk * 24 + 16 +
                        (size_t)(block / 64) * (sv.stack_entries + 1) * 64 * 2;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bench_trace), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -438,10 +422,7 @@ __global__ __launch_bounds__(256) void k_trace_simple(DeviceSceneView sv, FrameP
                                                       unsigned long long* __restrict__ counters) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     ScenePtrs sc;
-    sc.q0 = reinterpret_cast<const float4*>(sv.q0);
-    sc.q1 = reinterpret_cast<const float4*>(sv.q1);
-    sc.q2 = reinterpret_cast<const float4*>(sv.q2);
-    sc.qd = reinterpret_cast<const uint2*>(sv.qd);
+    sc.pairs = reinterpret_cast<const float4*>(sv.pairs);
     sc.spheres = reinterpret_cast<const float4*>(sv.spheres);
     sc.sphere_material = sv.sphere_material;
     sc.materials = reinterpret_cast<const float4*>(sv.materials);
@@ -561,8 +542,8 @@ __global__ void k_debug_eval(uint32_t op, const float* __restrict__ in, float* _
 size_t trace_lds_bytes(const DeviceSceneView& sv, bool lds_scene, uint32_t block) {
     size_t bytes = 0;
     if (lds_scene) {
-        bytes += (size_t)sv.n_pairs * 48 + (size_t)sv.n_models * 16;
-        bytes += (size_t)sv.n_pairs * 8 + (size_t)sv.n_leaf_table * 8 + (size_t)sv.n_models * 4;
+        bytes += (size_t)sv.n_pairs * 64 + (size_t)sv.n_models * 16;
+        bytes += (size_t)sv.n_leaf_table * 8 + (size_t)sv.n_models * 4;
     }
     bytes += (size_t)(block / 64) * (sv.stack_entries + 1) * 64 * (sv.desc16 ? 2 : 4);   // + 1: dummy entry
     return (bytes + 15) & ~(size_t)15;

@@ -93,19 +93,18 @@ constexpr uint32_t DESC16_MAX_INDEX = 0x3FFEu;
 // Pair records are stored as four parallel arrays of 16-byte (12 for the last) granules so
 // that 64 lanes reading 64 different records spread over all LDS banks (a 64-byte
 // array-of-structs stride would alias to 4 bank groups).
-//   q0[i] = { L.min.x, L.min.y, L.min.z, L.max.x }
-//   q1[i] = { L.max.y, L.max.z, R.min.x, R.min.y }
-//   q2[i] = { R.min.z, R.max.x, R.max.y, R.max.z }
-//   qd[i] = { descL, descR }            (L = node `index`, R = node `index + 1`)
+//   pairs[4i + 0] = { L.min.x, L.min.y, L.min.z, L.max.x }
+//   pairs[4i + 1] = { L.max.y, L.max.z, R.min.x, R.min.y }
+//   pairs[4i + 2] = { R.min.z, R.max.x, R.max.y, R.max.z }
+//   pairs[4i + 3] = { descL, descR, 0, 0 } (as u32; L = node `index`, R = node `index + 1`)
+// i.e. one 64-byte record per interior node: one address computation and four LDS reads with
+// immediate offsets per visit; from global memory, one half cache line instead of four lines.
 // Spheres: { center.x, center.y, center.z, radius*radius } (hit_sphere only uses r*r,
 // raytrace.wgsl:375), material ids in a parallel u32 array.
 // Materials: two float4 per material, as on the wire.
 
 struct DeviceSceneView {
-    const float* q0;         // float4[n_pairs]
-    const float* q1;
-    const float* q2;
-    const uint32_t* qd;      // uint2[n_pairs]
+    const float* pairs;      // float4[4 * n_pairs], 64-byte aligned records
     const float* spheres;    // float4[n_models]
     const uint32_t* sphere_material;  // u32[n_models]
     const float* materials;  // float4[2*n_materials]
