@@ -157,12 +157,19 @@ BRT_DEV void raycast(const ScenePtrs& sc, uint32_t root_desc, StackT* stk, uint3
     float closest = kInf;
     uint32_t closest_idx = 0xffffffffu;
     uint32_t cur = root_desc;
-    uint32_t n = 0;
+    // Stack convention: entry 0 holds DONE for ever, pushed nodes live in entries 1..n, `sp` points at
+    // entry n.  A pop is then `cur = *sp; sp -= STRIDE` with no emptiness test (the empty stack pops
+    // DONE and the walk ends), a push is a store to sp[STRIDE]; the address is carried instead of n.
+    stk[0] = (StackT)DS::DONE;
+    StackT* sp = stk;
+    StackT* const dummy_below = stk + (dummy_entry - 1u) * STRIDE;   // "push" target when nothing is pushed
+    uint32_t n = 0;                                                  // entries in use (overflow rule only)
     while (cur != DS::DONE && (SIMPLE_TREE || n < 31u)) {
         if (cur >= DS::LEAF) {                          // LEAF is the top bit in use: one compare, no mask
             if (COUNTERS) hc.node_pops++;
             if (STRIDE == 64) prof_section<COUNTERS>(hc, SEC_LEAF, true);
             const uint32_t first = cur & DS::INDEX_MASK;
+            const uint32_t popped = *sp;                // issued before the sphere arithmetic
             if (SIMPLE_TREE || (cur & DS::LEAF1)) {      // one sphere (what PLOC produces)
                 if (COUNTERS) hc.sphere_tests++;
                 sphere_test(o, d, a, sc.spheres[first], first, closest, closest_idx);
@@ -173,10 +180,9 @@ BRT_DEV void raycast(const ScenePtrs& sc, uint32_t root_desc, StackT* stk, uint3
                     sphere_test(o, d, a, sc.spheres[i], i, closest, closest_idx);
                 }
             }
-            const bool has = n > 0u;
-            n = has ? n - 1u : 0u;
-            const uint32_t popped = stk[n * STRIDE];
-            cur = has ? popped : DS::DONE;
+            cur = popped;
+            sp -= STRIDE;                               // below entry 0 only after DONE was popped: never used again
+            n--;                                        // wraps with it; only read while cur != DONE
         }
         // NOT `else`: a lane that has just tested a leaf and popped an interior node takes the
         // interior step in the same iteration (the wave runs both bodies in almost every iteration
@@ -189,17 +195,17 @@ BRT_DEV void raycast(const ScenePtrs& sc, uint32_t root_desc, StackT* stk, uint3
             const float4 A = rec[0], B = rec[1], C = rec[2];
             const uint2 D = *reinterpret_cast<const uint2*>(rec + 3);
             // the would-be pop, issued with the node reads so that its LDS latency hides behind the slab
-            // arithmetic.  It never aliases the store below (entry n or the dummy) when it is used:
-            // with n == 0 it reads entry 0, which a both-push overwrites, but then nothing is popped.
-            const uint32_t popped = stk[(n > 0u ? n - 1u : 0u) * STRIDE];
+            // arithmetic; the store below goes to the entry above it (or to the dummy), never to it
+            const uint32_t popped = *sp;
             const bool p1 = slab_push(o, inv, mk3(A.x, A.y, A.z), mk3(A.w, B.x, B.y), closest);
             const bool p2 = slab_push(o, inv, mk3(B.z, B.w, C.x), mk3(C.y, C.z, C.w), closest);
             // reference: push `index` (D.x) then `index+1` (D.y); the later push is popped first
             const bool both = p1 && p2, none = !p1 && !p2;
-            stk[(both ? n : dummy_entry) * STRIDE] = (StackT)D.x;
-            const bool can_pop = none && n > 0u;
-            cur = p2 ? D.y : (p1 ? D.x : (can_pop ? popped : DS::DONE));
-            n = both ? n + 1u : (can_pop ? n - 1u : n);
+            (both ? sp : dummy_below)[STRIDE] = (StackT)D.x;
+            cur = p2 ? D.y : (p1 ? D.x : popped);
+            const int step = both ? 1 : (none ? -1 : 0);
+            sp += step * STRIDE;
+            n += (uint32_t)step;
         }
     }
     t_out = closest;

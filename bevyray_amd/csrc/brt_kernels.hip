@@ -181,7 +181,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     }
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
-    StackT* stk = stacks + wave * ((sv.stack_entries + 1u) * 64u) + lane;   // + 1: dummy entry
+    StackT* stk = stacks + wave * ((sv.stack_entries + 2u) * 64u) + lane;   // + 2: DONE sentinel (entry 0) and dummy entry
 
     PixelState ps;
     ps.sample = 0; ps.rng = 0; ps.out_index = 0; ps.frame_index = 0; ps.tile = 0; ps.rays_begin = 0;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                 }
             }
         }
-        if (active) raycast<64, COUNTERS, D16, SIMPLE>(sc, sv.root_desc, stk, sv.stack_entries, o, d, t, idx, hc);
+        if (active) raycast<64, COUNTERS, D16, SIMPLE>(sc, sv.root_desc, stk, sv.stack_entries + 1u, o, d, t, idx, hc);
         prof_section<COUNTERS>(hc, SEC_SCATTER, active && t != kInf);
         prof_section<COUNTERS>(hc, SEC_SKY, active && t == kInf);
         if (active) {
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void k_trace_simple(DeviceSceneView sv, FrameP
         if (c.inside) {
             PixelState ps;
             pixel_begin(fp, c, ps);
-            uint32_t stack[33];   // 32 entries + the dummy slot
+            uint32_t stack[34];   // DONE sentinel + 32 entries + the dummy slot
             for (uint32_t s = 0; s < fp.sample_count; s++) {          // raytrace.wgsl:161
                 f3 d = camera_ray_dir(fp, ps.ndc0x, ps.ndc0y, ps.rng);
                 f3 o = mk3(fp.cam_pos[0], fp.cam_pos[1], fp.cam_pos[2]);
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void k_trace_simple(DeviceSceneView sv, FrameP
                 for (;;) {
                     float t;
                     uint32_t idx;
-                    raycast<1, COUNTERS, D16, false>(sc, sv.root_desc, stack, 32u, o, d, t, idx, hc);
+                    raycast<1, COUNTERS, D16, false>(sc, sv.root_desc, stack, 33u, o, d, t, idx, hc);
                     n_rays++;
                     if (shade_segment(sc, fp, o, d, tput, bounce, first_depth, t, idx, ps.rng, color, hc.hits)) break;
                 }
@@ -545,7 +545,7 @@ size_t trace_lds_bytes(const DeviceSceneView& sv, bool lds_scene, uint32_t block
         bytes += (size_t)sv.n_pairs * 64 + (size_t)sv.n_models * 16;
         bytes += (size_t)sv.n_leaf_table * 8 + (size_t)sv.n_models * 4;
     }
-    bytes += (size_t)(block / 64) * (sv.stack_entries + 1) * 64 * (sv.desc16 ? 2 : 4);   // + 1: dummy entry
+    bytes += (size_t)(block / 64) * (sv.stack_entries + 2) * 64 * (sv.desc16 ? 2 : 4);   // + 2: DONE sentinel, dummy entry
     return (bytes + 15) & ~(size_t)15;
 }
 
