@@ -57,6 +57,16 @@ BRT_DEV float rng_float(uint32_t& state) {
     state = rng_next(state);
     return (float)state * 2.3283064365386963e-10f;
 }
+// 2x - 1 of random.wgsl:21-23: 2x is exact in binary floating point, so the single rounding of
+// fma(x, 2, -1) is bit for bit the rounding of the shader's (2*x) - 1 -- one instruction instead of two
+// without touching the "no contraction" policy (nothing is rounded differently).
+BRT_DEV float two_x_minus_one(float x) { return __builtin_fmaf(x, 2.0f, -1.0f); }
+// 2 * rngNextFloat() - 1 in one step: f32(state) * 2^-32 and the doubling are both exact scalings, so
+// fma(f32(state), 2^-31, -1) rounds exactly once, where the shader's expression rounds.
+BRT_DEV float rng_ball_coord(uint32_t& state) {
+    state = rng_next(state);
+    return __builtin_fmaf((float)state, 4.656612873077392578125e-10f, -1.0f);
+}
 // random.wgsl:17-30 (a point INSIDE the unit ball, not normalised)
 BRT_DEV f3 rng_unit_ball(uint32_t& state) {
     f3 p;
@@ -64,7 +74,7 @@ BRT_DEV f3 rng_unit_ball(uint32_t& state) {
         const float x = rng_float(state);
         const float y = rng_float(state);
         const float z = rng_float(state);
-        p = mk3(2.0f * x - 1.0f, 2.0f * y - 1.0f, 2.0f * z - 1.0f);
+        p = mk3(two_x_minus_one(x), two_x_minus_one(y), two_x_minus_one(z));
         if (dot3(p, p) <= 1.0f) break;
     }
     return p;
@@ -252,18 +262,23 @@ BRT_DEV bool scatter(const ScenePtrs& sc, f3& o, f3& d, float t, uint32_t idx, u
 
     // balls: metal fuzz = roughness * ball (:238); diffuse normal + ball + roughness * ball (:285)
     uint32_t need = metal ? 1u : (diffuse ? 2u : 0u);
-    f3 acc = mk3(0.0f, 0.0f, 0.0f);
+    // Branch-free accept: candidate = base + scale * p with (base, scale) = (normal, 1) for the first
+    // diffuse ball (1 * p == p), (acc, roughness) for the second, (-0, roughness) for metal fuzz --
+    // adding to -0 returns the other operand bit for bit, signed zeros included, so each case is the
+    // shader's own expression.
+    f3 acc = mk3(-0.0f, -0.0f, -0.0f);
     while (need != 0u) {                                                      // random.wgsl:19-24
-        const float x = rng_float(rng);
-        const float y = rng_float(rng);
-        const float z = rng_float(rng);
-        const f3 p = mk3(2.0f * x - 1.0f, 2.0f * y - 1.0f, 2.0f * z - 1.0f);
-        if (dot3(p, p) <= 1.0f) {
-            if (diffuse && need == 2u) acc = nrm + p;
-            else if (diffuse) acc = acc + m1.x * p;
-            else acc = m1.x * p;
-            need--;
-        }
+        const float px = rng_ball_coord(rng);
+        const float py = rng_ball_coord(rng);
+        const float pz = rng_ball_coord(rng);
+        const f3 p = mk3(px, py, pz);
+        const bool ok = dot3(p, p) <= 1.0f;
+        const bool first = diffuse && need == 2u;
+        const f3 base = mk3(first ? nrm.x : acc.x, first ? nrm.y : acc.y, first ? nrm.z : acc.z);
+        const float scale = first ? 1.0f : m1.x;
+        const f3 cand = base + scale * p;
+        acc = mk3(ok ? cand.x : acc.x, ok ? cand.y : acc.y, ok ? cand.z : acc.z);
+        need -= ok ? 1u : 0u;
     }
 
     bool absorbed = false;
