@@ -159,6 +159,8 @@ int32_t make_frame_params(brt_ctx* ctx, const void* camera80, const void* window
     fp.refill_min = env_u32("BRT_REFILL_MIN", 1);
     if (fp.refill_min < 1u) fp.refill_min = 1u;
     if (fp.refill_min > 64u) fp.refill_min = 64u;
+    fp.walk_exit_lanes = env_u32("BRT_WALK_EXIT", 8);
+    if (fp.walk_exit_lanes > 63u) fp.walk_exit_lanes = 63u;
     *out = fp;
     return BRT_OK;
 }

@@ -158,23 +158,73 @@ BRT_DEV void prof_section(HitCounters& hc, int sec, bool pred) {
 // SIMPLE_TREE (decided at upload): every leaf holds one sphere and the tree is shallower than
 // 31 levels, so neither the leaf table nor the stack-overflow rule can come into play and
 // both checks are compiled out.
-template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, typename StackT>
-BRT_DEV void raycast(const ScenePtrs& sc, uint32_t root_desc, StackT* stk, uint32_t dummy_entry, f3 o, f3 d,
-                     float& t_out, uint32_t& idx_out, HitCounters& hc) {
-    using DS = Desc<D16>;
-    const float a = dot3(d, d);
-    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    float closest = kInf;
-    uint32_t closest_idx = 0xffffffffu;
-    uint32_t cur = root_desc;
+//
+// The walk is SUSPENDABLE: its state (WalkState) survives walk_run returning early.  With
+// `exit_lanes` > 0 a wave stops iterating as soon as no more than min(exit_lanes, half of the
+// lanes that entered) are still walking; the finished lanes are shaded and given their next ray
+// by the caller, and the stragglers continue next to those new rays in the next call instead of
+// keeping the whole wave in the loop with a handful of live lanes.  Per lane nothing changes:
+// the same steps in the same order.
+template <typename StackT>
+struct WalkState {
+    float a;                 // dot(d, d)
+    f3 inv;                  // 1 / d
+    float closest;
+    uint32_t closest_idx;
+    uint32_t cur;            // DONE when the walk has ended
+    StackT* sp;
+    uint32_t n;              // entries in use (overflow rule of general trees only)
+};
+
+template <bool D16, typename StackT>
+BRT_DEV void walk_begin(WalkState<StackT>& w, uint32_t root_desc, StackT* stk, f3 d) {
+    w.a = dot3(d, d);
+    w.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    w.closest = kInf;
+    w.closest_idx = 0xffffffffu;
+    w.cur = root_desc;
     // Stack convention: entry 0 holds DONE for ever, pushed nodes live in entries 1..n, `sp` points at
     // entry n.  A pop is then `cur = *sp; sp -= STRIDE` with no emptiness test (the empty stack pops
     // DONE and the walk ends), a push is a store to sp[STRIDE]; the address is carried instead of n.
-    stk[0] = (StackT)DS::DONE;
-    StackT* sp = stk;
+    stk[0] = (StackT)Desc<D16>::DONE;
+    w.sp = stk;
+    w.n = 0;
+}
+
+// true while this lane's walk has not ended (general trees: also ended by the overflow rule)
+template <bool D16, bool SIMPLE_TREE, typename StackT>
+BRT_DEV bool walk_pending(const WalkState<StackT>& w) {
+    return w.cur != Desc<D16>::DONE && (SIMPLE_TREE || w.n < 31u);
+}
+
+template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, typename StackT>
+BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, uint32_t dummy_entry, f3 o, f3 d,
+                      uint32_t exit_lanes, HitCounters& hc) {
+    using DS = Desc<D16>;
+    const float a = w.a;
+    const f3 inv = w.inv;
+    float closest = w.closest;
+    uint32_t closest_idx = w.closest_idx;
+    uint32_t cur = w.cur;
+    StackT* sp = w.sp;
+    uint32_t n = w.n;
     StackT* const dummy_below = stk + (dummy_entry - 1u) * STRIDE;   // "push" target when nothing is pushed
-    uint32_t n = 0;                                                  // entries in use (overflow rule only)
-    while (cur != DS::DONE && (SIMPLE_TREE || n < 31u)) {
+    // Wave-level loop (STRIDE 64): leave when no more than exit_at lanes are still walking.  exit_at <
+    // the number that entered, so every call makes progress; exit_lanes == 0 runs all walks to the end.
+    uint32_t exit_at = 0;
+    if (STRIDE == 64) {
+        const uint32_t entered = (uint32_t)__popcll(__ballot(cur != DS::DONE && (SIMPLE_TREE || n < 31u)));
+        exit_at = entered >> 1;
+        exit_at = exit_at < exit_lanes ? exit_at : exit_lanes;
+    }
+    for (;;) {
+        const bool walking = cur != DS::DONE && (SIMPLE_TREE || n < 31u);
+        if (STRIDE == 64) {
+            if ((uint32_t)__popcll(__ballot(walking)) <= exit_at) break;
+        } else if (!walking) {
+            break;
+        }
+        if (!walking) continue;
         if (cur >= DS::LEAF) {                          // LEAF is the top bit in use: one compare, no mask
             if (COUNTERS) hc.node_pops++;
             if (STRIDE == 64) prof_section<COUNTERS>(hc, SEC_LEAF, true);
@@ -218,8 +268,22 @@ BRT_DEV void raycast(const ScenePtrs& sc, uint32_t root_desc, StackT* stk, uint3
             n += (uint32_t)step;
         }
     }
-    t_out = closest;
-    idx_out = closest_idx;
+    w.closest = closest;
+    w.closest_idx = closest_idx;
+    w.cur = cur;
+    w.sp = sp;
+    w.n = n;
+}
+
+// whole walk in one call (bring-up kernel, probes)
+template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, typename StackT>
+BRT_DEV void raycast(const ScenePtrs& sc, uint32_t root_desc, StackT* stk, uint32_t dummy_entry, f3 o, f3 d,
+                     float& t_out, uint32_t& idx_out, HitCounters& hc) {
+    WalkState<StackT> w;
+    walk_begin<D16>(w, root_desc, stk, d);
+    walk_run<STRIDE, COUNTERS, D16, SIMPLE_TREE>(sc, w, stk, dummy_entry, o, d, 0u, hc);
+    t_out = w.closest;
+    idx_out = w.closest_idx;
 }
 
 // raytrace.wgsl:400-402

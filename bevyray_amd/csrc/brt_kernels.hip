@@ -190,6 +190,10 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     uint32_t bounce = 0;
     float first_depth = kInf;
     bool active = false, exhausted = false;
+    bool in_flight = false;           // this lane's walk was suspended by walk_run's early exit
+    WalkState<StackT> walk;
+    walk.a = 0.0f; walk.inv = mk3(0.0f, 0.0f, 0.0f); walk.closest = kInf; walk.closest_idx = 0xffffffffu;
+    walk.cur = Desc<D16>::DONE; walk.sp = stk; walk.n = 0;
     uint32_t n_rays = 0;
     HitCounters hc = {};
 
@@ -229,34 +233,38 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         if (__ballot(active) == 0) break;
 
         prof_section<COUNTERS>(hc, SEC_ROUND, active);
-        prof_section<COUNTERS>(hc, SEC_CAMERA, active && bounce == 0);
-        if (active && bounce == 0) {
+        const bool fresh = active && !in_flight;       // starts a ray segment in this round
+        prof_section<COUNTERS>(hc, SEC_CAMERA, fresh && bounce == 0);
+        if (fresh && bounce == 0) {
             // new sample: raytrace.wgsl:162 + :175-186
             d = camera_ray_dir(fp, ps.ndc0x, ps.ndc0y, ps.rng);
             o = mk3(fp.cam_pos[0], fp.cam_pos[1], fp.cam_pos[2]);
             tput = mk3(1.0f, 1.0f, 1.0f);
             first_depth = kInf;
         }
-        float t = kInf;
-        uint32_t idx = 0xffffffffu;
         if (COUNTERS) {   // diagnostic ray dump for the trace microbenchmark (brt_debug_trace_bench)
             float* dump = reinterpret_cast<float*>(counters[24]);
             if (dump != nullptr) {
-                const uint64_t m = __ballot(active);
+                const uint64_t m = __ballot(fresh);
                 unsigned long long base = 0;
-                if (active && mbcnt64(m) == 0) base = atomicAdd(&counters[26], (unsigned long long)__popcll(m));
+                if (fresh && mbcnt64(m) == 0) base = atomicAdd(&counters[26], (unsigned long long)__popcll(m));
                 base = __shfl(base, (int)(__ffsll((long long)m) - 1), 64);
                 const unsigned long long slot = base + mbcnt64(m);
-                if (active && slot < counters[25]) {
+                if (fresh && slot < counters[25]) {
                     float* r = dump + slot * 8;
                     r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z; r[6] = 0.0f; r[7] = 0.0f;
                 }
             }
         }
-        if (active) raycast<64, COUNTERS, D16, SIMPLE>(sc, sv.root_desc, stk, sv.stack_entries + 1u, o, d, t, idx, hc);
-        prof_section<COUNTERS>(hc, SEC_SCATTER, active && t != kInf);
-        prof_section<COUNTERS>(hc, SEC_SKY, active && t == kInf);
-        if (active) {
+        if (fresh) walk_begin<D16>(walk, sv.root_desc, stk, d);
+        if (active) walk_run<64, COUNTERS, D16, SIMPLE>(sc, walk, stk, sv.stack_entries + 1u, o, d, fp.walk_exit_lanes, hc);
+        in_flight = active && walk_pending<D16, SIMPLE>(walk);
+        const bool landed = active && !in_flight;      // walk finished: shade this segment now
+        const float t = walk.closest;
+        const uint32_t idx = walk.closest_idx;
+        prof_section<COUNTERS>(hc, SEC_SCATTER, landed && t != kInf);
+        prof_section<COUNTERS>(hc, SEC_SKY, landed && t == kInf);
+        if (landed) {
             n_rays++;
             f3 color;
             if (shade_segment(sc, fp, o, d, tput, bounce, first_depth, t, idx, ps.rng, color, hc.hits)) {

@@ -139,6 +139,7 @@ struct FrameParams {
     // lower rows see ground and objects, the upper rows sky (one ray per sample).
     uint32_t bottom_up;
     uint32_t refill_min;             // lanes that must be free before a wave takes new pixels (1..64)
+    uint32_t walk_exit_lanes;        // a wave leaves the walk loop when <= this many lanes still walk (0: never)
     // Longest-first dispatch: tile_order[k] = k-th tile to hand out (tiles sorted by the ray count
     // they needed in the previous frame of the same view), tile_cost[tile] += rays of each finished
     // pixel (this frame's measurement for the next one).  Either may be null.
