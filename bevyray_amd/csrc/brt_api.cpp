@@ -161,6 +161,8 @@ int32_t make_frame_params(brt_ctx* ctx, const void* camera80, const void* window
     if (fp.refill_min > 64u) fp.refill_min = 64u;
     fp.walk_exit_lanes = env_u32("BRT_WALK_EXIT", 8);
     if (fp.walk_exit_lanes > 63u) fp.walk_exit_lanes = 63u;
+    fp.leaf_vote = env_u32("BRT_LEAF_VOTE", 8);
+    if (fp.leaf_vote > 64u) fp.leaf_vote = 64u;
     *out = fp;
     return BRT_OK;
 }

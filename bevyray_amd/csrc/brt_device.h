@@ -199,7 +199,7 @@ BRT_DEV bool walk_pending(const WalkState<StackT>& w) {
 
 template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, typename StackT>
 BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, uint32_t dummy_entry, f3 o, f3 d,
-                      uint32_t exit_lanes, HitCounters& hc) {
+                      uint32_t exit_lanes, uint32_t leaf_vote, HitCounters& hc) {
     using DS = Desc<D16>;
     const float a = w.a;
     const f3 inv = w.inv;
@@ -217,15 +217,20 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, ui
         exit_at = entered >> 1;
         exit_at = exit_at < exit_lanes ? exit_at : exit_lanes;
     }
-    for (;;) {
-        const bool walking = cur != DS::DONE && (SIMPLE_TREE || n < 31u);
+    bool walking = cur != DS::DONE && (SIMPLE_TREE || n < 31u);
+    uint32_t n_walking = STRIDE == 64 ? (uint32_t)__popcll(__ballot(walking)) : (walking ? 1u : 0u);
+    if (n_walking > exit_at) do {
+        if (walking) {
+        // Leaf vote: the leaf body costs the wave ~66 instructions however few lanes need it (8 on
+        // average).  While fewer than `leaf_vote` lanes wait at a leaf AND some lane can take an interior
+        // step, the waiting lanes sit the iteration out; they are served together a little later.  Only
+        // the interleaving of lanes changes, never a lane's own sequence of steps.
+        bool run_leaf = cur >= DS::LEAF;
         if (STRIDE == 64) {
-            if ((uint32_t)__popcll(__ballot(walking)) <= exit_at) break;
-        } else if (!walking) {
-            break;
+            const uint32_t want_leaf = (uint32_t)__popcll(__ballot(run_leaf));
+            if (want_leaf < leaf_vote && want_leaf < n_walking) run_leaf = false;
         }
-        if (!walking) continue;
-        if (cur >= DS::LEAF) {                          // LEAF is the top bit in use: one compare, no mask
+        if (run_leaf) {                          // LEAF is the top bit in use: one compare, no mask
             if (COUNTERS) hc.node_pops++;
             if (STRIDE == 64) prof_section<COUNTERS>(hc, SEC_LEAF, true);
             const uint32_t first = cur & DS::INDEX_MASK;
@@ -267,7 +272,10 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, ui
             sp += step * STRIDE;
             n += (uint32_t)step;
         }
-    }
+        }
+        walking = cur != DS::DONE && (SIMPLE_TREE || n < 31u);
+        n_walking = STRIDE == 64 ? (uint32_t)__popcll(__ballot(walking)) : (walking ? 1u : 0u);
+    } while (n_walking > exit_at);
     w.closest = closest;
     w.closest_idx = closest_idx;
     w.cur = cur;
@@ -281,7 +289,7 @@ BRT_DEV void raycast(const ScenePtrs& sc, uint32_t root_desc, StackT* stk, uint3
                      float& t_out, uint32_t& idx_out, HitCounters& hc) {
     WalkState<StackT> w;
     walk_begin<D16>(w, root_desc, stk, d);
-    walk_run<STRIDE, COUNTERS, D16, SIMPLE_TREE>(sc, w, stk, dummy_entry, o, d, 0u, hc);
+    walk_run<STRIDE, COUNTERS, D16, SIMPLE_TREE>(sc, w, stk, dummy_entry, o, d, 0u, 0u, hc);
     t_out = w.closest;
     idx_out = w.closest_idx;
 }

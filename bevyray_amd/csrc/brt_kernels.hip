@@ -257,7 +257,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             }
         }
         if (fresh) walk_begin<D16>(walk, sv.root_desc, stk, d);
-        if (active) walk_run<64, COUNTERS, D16, SIMPLE>(sc, walk, stk, sv.stack_entries + 1u, o, d, fp.walk_exit_lanes, hc);
+        if (active) walk_run<64, COUNTERS, D16, SIMPLE>(sc, walk, stk, sv.stack_entries + 1u, o, d, fp.walk_exit_lanes, fp.leaf_vote, hc);
         in_flight = active && walk_pending<D16, SIMPLE>(walk);
         const bool landed = active && !in_flight;      // walk finished: shade this segment now
         const float t = walk.closest;

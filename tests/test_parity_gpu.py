@@ -393,6 +393,8 @@ def test_sample_count_zero_is_zero_over_zero(plugin, oracle, level):
     {"BRT_FORCE_GLOBAL_SCENE": "1"}, {"BRT_REFILL_MIN": "64"}, {"BRT_REFILL_MIN": "17", "BRT_BOTTOM_UP": "1"},
     {"BRT_CPU_BVH": "1"}, {"BRT_WALK_EXIT": "0"}, {"BRT_WALK_EXIT": "1"}, {"BRT_WALK_EXIT": "23"},
     {"BRT_WALK_EXIT": "63", "BRT_REFILL_MIN": "9"}, {"BRT_WALK_EXIT": "40", "BRT_FORCE_GLOBAL_SCENE": "1"},
+    {"BRT_LEAF_VOTE": "0"}, {"BRT_LEAF_VOTE": "64"}, {"BRT_LEAF_VOTE": "20", "BRT_WALK_EXIT": "0"},
+    {"BRT_LEAF_VOTE": "3", "BRT_WALK_EXIT": "30", "BRT_BLOCK_THREADS": "256"},
 ])
 def test_tuning_knobs_do_not_change_results(plugin, oracle, env):
     b = brt.generate_scene(brt.SCENE_COVER, 1)
