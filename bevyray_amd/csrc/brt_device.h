@@ -186,7 +186,7 @@ BRT_DEV void walk_begin(WalkState<StackT>& w, uint32_t root_desc, StackT* stk, f
     // Stack convention: entry 0 holds DONE for ever, pushed nodes live in entries 1..n, `sp` points at
     // entry n.  A pop is then `cur = *sp; sp -= STRIDE` with no emptiness test (the empty stack pops
     // DONE and the walk ends), a push is a store to sp[STRIDE]; the address is carried instead of n.
-    stk[0] = (StackT)Desc<D16>::DONE;
+    stk[0] = (StackT)-1;                   // Desc::DONE in stack form
     w.sp = stk;
     w.n = 0;
 }
@@ -195,6 +195,55 @@ BRT_DEV void walk_begin(WalkState<StackT>& w, uint32_t root_desc, StackT* stk, f
 template <bool D16, bool SIMPLE_TREE, typename StackT>
 BRT_DEV bool walk_pending(const WalkState<StackT>& w) {
     return w.cur != Desc<D16>::DONE && (SIMPLE_TREE || w.n < 31u);
+}
+
+// Leaf step of the walk (raytrace.wgsl:325-326, 348-362) for a lane whose `cur` is a leaf: test its
+// sphere(s), then pop.
+template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, typename StackT>
+BRT_DEV void walk_leaf_step(const ScenePtrs& sc, f3 o, f3 d, float a, float& closest, uint32_t& closest_idx, uint32_t& cur,
+                            StackT*& sp, uint32_t& n, HitCounters& hc) {
+    using DS = Desc<D16>;
+    if (COUNTERS) hc.node_pops++;
+    if (STRIDE == 64) prof_section<COUNTERS>(hc, SEC_LEAF, true);
+    const uint32_t first = cur & DS::INDEX_MASK;
+    const uint32_t popped = (uint32_t)(int32_t)*sp;  // issued before the sphere arithmetic (sign-extending load)
+    if (SIMPLE_TREE || (cur & DS::LEAF1)) {           // one sphere (what PLOC produces)
+        if (COUNTERS) hc.sphere_tests++;
+        sphere_test(o, d, a, sc.spheres[first], first, closest, closest_idx);
+    } else {                                          // general leaf: {first, count} from the leaf table
+        const uint2 lt = sc.leaf_table[first];
+        for (uint32_t i = lt.x; i < lt.x + lt.y; i++) {
+            if (COUNTERS) hc.sphere_tests++;
+            sphere_test(o, d, a, sc.spheres[i], i, closest, closest_idx);
+        }
+    }
+    cur = popped;
+    sp -= STRIDE;                                     // below entry 0 only after DONE was popped: never used again
+    n--;                                              // wraps with it; only read while cur != DONE
+}
+
+// Interior step (raytrace.wgsl:327-342) for a lane whose `cur` is a pair record: both slab tests,
+// push/pop as selects.
+template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, typename StackT>
+BRT_DEV void walk_interior_step(const ScenePtrs& sc, f3 o, f3 inv, float closest, uint32_t& cur, StackT*& sp, uint32_t& n,
+                                StackT* dummy_below, HitCounters& hc) {
+    if (COUNTERS) { hc.node_pops++; hc.interior++; }
+    if (STRIDE == 64) prof_section<COUNTERS>(hc, SEC_INTERIOR, true);
+    const float4* rec = sc.pairs + 4u * cur;
+    const float4 A = rec[0], B = rec[1], C = rec[2];
+    const uint2 D = *reinterpret_cast<const uint2*>(rec + 3);
+    // the would-be pop, issued with the node reads so that its LDS latency hides behind the slab
+    // arithmetic; the store below goes to the entry above it (or to the dummy), never to it
+    const uint32_t popped = (uint32_t)(int32_t)*sp;
+    const bool p1 = slab_push(o, inv, mk3(A.x, A.y, A.z), mk3(A.w, B.x, B.y), closest);
+    const bool p2 = slab_push(o, inv, mk3(B.z, B.w, C.x), mk3(C.y, C.z, C.w), closest);
+    // reference: push `index` (D.x) then `index+1` (D.y); the later push is popped first
+    const bool both = p1 && p2, none = !p1 && !p2;
+    (both ? sp : dummy_below)[STRIDE] = (StackT)D.x;
+    cur = p2 ? D.y : (p1 ? D.x : popped);
+    const int step = both ? 1 : (none ? -1 : 0);
+    sp += step * STRIDE;
+    n += (uint32_t)step;
 }
 
 template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, typename StackT>
@@ -209,73 +258,43 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, ui
     StackT* sp = w.sp;
     uint32_t n = w.n;
     StackT* const dummy_below = stk + (dummy_entry - 1u) * STRIDE;   // "push" target when nothing is pushed
-    // Wave-level loop (STRIDE 64): leave when no more than exit_at lanes are still walking.  exit_at <
-    // the number that entered, so every call makes progress; exit_lanes == 0 runs all walks to the end.
-    uint32_t exit_at = 0;
     if (STRIDE == 64) {
-        const uint32_t entered = (uint32_t)__popcll(__ballot(cur != DS::DONE && (SIMPLE_TREE || n < 31u)));
-        exit_at = entered >> 1;
+        // Wave-level loop.  The kernel is bound by instruction issue, the two bodies cost the wave ~70
+        // instructions each however few lanes take part, and a ray needs ~6 interior steps per leaf step:
+        //   inner loop   interior steps only, until `leaf_vote` lanes wait at a leaf or no lane has an
+        //                interior node left (a waiting lane sits those iterations out);
+        //   then         ONE leaf step for all waiting lanes -- a lane that pops an interior node there
+        //                continues in the next inner iteration;
+        //   leave        when no more than exit_at lanes still walk.  exit_at < the number that entered,
+        //                so every call makes progress; exit_lanes == 0 runs all walks to the end.
+        // Only the interleaving of lanes changes, never a lane's own sequence of steps.  With the signed
+        // descriptor form (brt_layout.h) a finished lane fails both body tests by itself.
+        uint32_t n_walking = (uint32_t)__popcll(__ballot(cur != DS::DONE && (SIMPLE_TREE || n < 31u)));
+        uint32_t exit_at = n_walking >> 1;
         exit_at = exit_at < exit_lanes ? exit_at : exit_lanes;
-    }
-    bool walking = cur != DS::DONE && (SIMPLE_TREE || n < 31u);
-    uint32_t n_walking = STRIDE == 64 ? (uint32_t)__popcll(__ballot(walking)) : (walking ? 1u : 0u);
-    if (n_walking > exit_at) do {
-        if (walking) {
-        // Leaf vote: the leaf body costs the wave ~66 instructions however few lanes need it (8 on
-        // average).  While fewer than `leaf_vote` lanes wait at a leaf AND some lane can take an interior
-        // step, the waiting lanes sit the iteration out; they are served together a little later.  Only
-        // the interleaving of lanes changes, never a lane's own sequence of steps.
-        bool run_leaf = cur >= DS::LEAF;
-        if (STRIDE == 64) {
-            const uint32_t want_leaf = (uint32_t)__popcll(__ballot(run_leaf));
-            if (want_leaf < leaf_vote && want_leaf < n_walking) run_leaf = false;
-        }
-        if (run_leaf) {                          // LEAF is the top bit in use: one compare, no mask
-            if (COUNTERS) hc.node_pops++;
-            if (STRIDE == 64) prof_section<COUNTERS>(hc, SEC_LEAF, true);
-            const uint32_t first = cur & DS::INDEX_MASK;
-            const uint32_t popped = *sp;                // issued before the sphere arithmetic
-            if (SIMPLE_TREE || (cur & DS::LEAF1)) {      // one sphere (what PLOC produces)
-                if (COUNTERS) hc.sphere_tests++;
-                sphere_test(o, d, a, sc.spheres[first], first, closest, closest_idx);
-            } else {                                     // general leaf: {first, count} from the leaf table
-                const uint2 lt = sc.leaf_table[first];
-                for (uint32_t i = lt.x; i < lt.x + lt.y; i++) {
-                    if (COUNTERS) hc.sphere_tests++;
-                    sphere_test(o, d, a, sc.spheres[i], i, closest, closest_idx);
-                }
+        const uint32_t vote = leaf_vote < 1u ? 1u : leaf_vote;
+        if (n_walking > exit_at) for (;;) {
+            for (;;) {
+                const bool interior = DS::is_interior(cur) && (SIMPLE_TREE || n < 31u);
+                if (__ballot(interior) == 0ull) break;
+                if (interior)
+                    walk_interior_step<STRIDE, COUNTERS, D16, SIMPLE_TREE>(sc, o, inv, closest, cur, sp, n, dummy_below, hc);
+                const uint32_t want_leaf = (uint32_t)__popcll(__ballot(DS::is_leaf(cur) && (SIMPLE_TREE || n < 31u)));
+                if (want_leaf >= vote) break;
             }
-            cur = popped;
-            sp -= STRIDE;                               // below entry 0 only after DONE was popped: never used again
-            n--;                                        // wraps with it; only read while cur != DONE
+            if (DS::is_leaf(cur) && (SIMPLE_TREE || n < 31u))
+                walk_leaf_step<STRIDE, COUNTERS, D16, SIMPLE_TREE>(sc, o, d, a, closest, closest_idx, cur, sp, n, hc);
+            n_walking = (uint32_t)__popcll(__ballot(cur != DS::DONE && (SIMPLE_TREE || n < 31u)));
+            if (n_walking <= exit_at) break;
         }
-        // NOT `else`: a lane that has just tested a leaf and popped an interior node takes the
-        // interior step in the same iteration (the wave runs both bodies in almost every iteration
-        // anyway), so the bodies alternate L I L I ... and a lane only waits when it needs the same
-        // body twice in a row.  DONE has the LEAF bit set, so it never enters here.
-        if (cur < DS::LEAF && (SIMPLE_TREE || n < 31u)) {
-            if (COUNTERS) { hc.node_pops++; hc.interior++; }
-            if (STRIDE == 64) prof_section<COUNTERS>(hc, SEC_INTERIOR, true);
-            const float4* rec = sc.pairs + 4u * cur;
-            const float4 A = rec[0], B = rec[1], C = rec[2];
-            const uint2 D = *reinterpret_cast<const uint2*>(rec + 3);
-            // the would-be pop, issued with the node reads so that its LDS latency hides behind the slab
-            // arithmetic; the store below goes to the entry above it (or to the dummy), never to it
-            const uint32_t popped = *sp;
-            const bool p1 = slab_push(o, inv, mk3(A.x, A.y, A.z), mk3(A.w, B.x, B.y), closest);
-            const bool p2 = slab_push(o, inv, mk3(B.z, B.w, C.x), mk3(C.y, C.z, C.w), closest);
-            // reference: push `index` (D.x) then `index+1` (D.y); the later push is popped first
-            const bool both = p1 && p2, none = !p1 && !p2;
-            (both ? sp : dummy_below)[STRIDE] = (StackT)D.x;
-            cur = p2 ? D.y : (p1 ? D.x : popped);
-            const int step = both ? 1 : (none ? -1 : 0);
-            sp += step * STRIDE;
-            n += (uint32_t)step;
+    } else {
+        while (cur != DS::DONE && (SIMPLE_TREE || n < 31u)) {
+            if (DS::is_leaf(cur))
+                walk_leaf_step<STRIDE, COUNTERS, D16, SIMPLE_TREE>(sc, o, d, a, closest, closest_idx, cur, sp, n, hc);
+            else
+                walk_interior_step<STRIDE, COUNTERS, D16, SIMPLE_TREE>(sc, o, inv, closest, cur, sp, n, dummy_below, hc);
         }
-        }
-        walking = cur != DS::DONE && (SIMPLE_TREE || n < 31u);
-        n_walking = STRIDE == 64 ? (uint32_t)__popcll(__ballot(walking)) : (walking ? 1u : 0u);
-    } while (n_walking > exit_at);
+    }
     w.closest = closest;
     w.closest_idx = closest_idx;
     w.cur = cur;

@@ -106,6 +106,7 @@ int32_t validate_and_encode(const Model* models, uint32_t n_models, const Materi
         return LEAF | id;
     };
 
+    // (for the 16-bit form LEAF is 0xFFFF8000: the register form, sign-extended -- brt_layout.h)
     e.root_desc = desc_of(0);
     for (uint32_t i = 0; i < e.n_pairs; i++) {
         const BVHNode& nd = nodes[order[i]];

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                                                                 const float* __restrict__ raster_depth,
                                                                 unsigned long long* __restrict__ counters) {
     static_assert(!LDS_SCENE || D16, "an LDS-resident scene always uses 16-bit descriptors");
-    using StackT = typename std::conditional<D16, uint16_t, uint32_t>::type;
+    using StackT = typename std::conditional<D16, int16_t, int32_t>::type;   // sign-extending loads: brt_layout.h
     extern __shared__ uint4 smem[];
     ScenePtrs sc;
     StackT* stacks;
@@ -325,13 +325,13 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_bench_trace(DeviceSceneView sv, c
     uint2* l_rb = p2; p2 += BENCH_CHUNK;         //            {d.y, d.z}
     uint32_t* pw = reinterpret_cast<uint32_t*>(p2);
     uint32_t* l_head = pw; pw += 4;
-    uint16_t* stacks = reinterpret_cast<uint16_t*>(pw);
+    int16_t* stacks = reinterpret_cast<int16_t*>(pw);
     for (uint32_t i = threadIdx.x; i < 4u * sv.n_pairs; i += blockDim.x) l_pairs[i] = reinterpret_cast<const float4*>(sv.pairs)[i];
     for (uint32_t i = threadIdx.x; i < sv.n_models; i += blockDim.x) l_sp[i] = reinterpret_cast<const float4*>(sv.spheres)[i];
     sc.pairs = l_pairs; sc.spheres = l_sp;
     sc.sphere_material = sv.sphere_material; sc.materials = nullptr; sc.leaf_table = nullptr;
     const uint32_t lane = lane_id();
-    uint16_t* stk = stacks + (threadIdx.x >> 6) * ((sv.stack_entries + 1u) * 64u) + lane;
+    int16_t* stk = stacks + (threadIdx.x >> 6) * ((sv.stack_entries + 1u) * 64u) + lane;
     const uint32_t dummy = sv.stack_entries;
     uint32_t iters = 0, lanes = 0;
 
@@ -378,12 +378,12 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_bench_trace(DeviceSceneView sv, c
             iters++;
             lanes += (uint32_t)__popcll(__ballot(cur != DS::DONE));
             if (cur != DS::DONE) {
-                if (cur & DS::LEAF) {
+                if (DS::is_leaf(cur)) {
                     const uint32_t first = cur & DS::INDEX_MASK;
                     sphere_test(o, d, a, sc.spheres[first], first, closest, closest_idx);
                     const bool has = n > 0u;
                     n = has ? n - 1u : 0u;
-                    const uint32_t popped = stk[n * 64];
+                    const uint32_t popped = (uint32_t)(int32_t)stk[n * 64];
                     cur = has ? popped : DS::DONE;
                 } else {
                     const float4* rec = sc.pairs + 4u * cur;
@@ -392,9 +392,9 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_bench_trace(DeviceSceneView sv, c
                     const bool p1 = slab_push(o, inv, mk3(A.x, A.y, A.z), mk3(A.w, B.x, B.y), closest);
                     const bool p2b = slab_push(o, inv, mk3(B.z, B.w, C.x), mk3(C.y, C.z, C.w), closest);
                     const bool both = p1 && p2b, none = !p1 && !p2b;
-                    stk[(both ? n : dummy) * 64] = (uint16_t)D.x;
+                    stk[(both ? n : dummy) * 64] = (int16_t)D.x;
                     const bool can_pop = none && n > 0u;
-                    const uint32_t popped = stk[(n > 0u ? n - 1u : 0u) * 64];
+                    const uint32_t popped = (uint32_t)(int32_t)stk[(n > 0u ? n - 1u : 0u) * 64];
                     cur = p2b ? D.y : (p1 ? D.x : (can_pop ? popped : DS::DONE));
                     n = both ? n + 1u : (can_pop ? n - 1u : n);
                 }

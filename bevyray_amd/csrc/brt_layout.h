@@ -78,14 +78,21 @@ static_assert(sizeof(Window) == 16 && offsetof(Window, height) == 4, "Window");
 //   bit31 = 1, bit30 = 1      leaf with exactly one sphere: bits[29:0] = model index
 //   bit31 = 1, bit30 = 0      general leaf: bits[29:0] = index into the leaf table {first, count}
 // 16-bit form (every index < 16384, always the case for an LDS-resident scene): the same three
-// cases with the flags in bits 15/14 and a 14-bit index, so that a traversal-stack entry is a
-// u16 and 32 waves' stacks fit beside the scene in a CU's LDS.
+// cases with the flags in bits 15/14 and a 14-bit index, so that a traversal-stack entry is 16 bits
+// and 32 waves' stacks fit beside the scene in a CU's LDS.
+// REGISTER form (what the kernels compare, what pair records and root_desc hold): the 16-bit form
+// SIGN-EXTENDED to 32 bits, the 32-bit form as it is.  All-ones (-1) is the "walk finished" marker,
+// so as signed integers:   interior >= 0,   leaf < -1,   finished == -1   -- one compare each, and a
+// finished lane fails both body tests without a separate guard.  A 16-bit stack entry is read
+// back with a sign-extending load (ds_read_i16).
 template <bool D16>
 struct Desc {
-    static constexpr uint32_t LEAF = D16 ? 0x8000u : 0x80000000u;
-    static constexpr uint32_t LEAF1 = D16 ? 0x4000u : 0x40000000u;   // set together with LEAF
+    static constexpr uint32_t LEAF = D16 ? 0xFFFF8000u : 0x80000000u;   // OR-mask that makes a leaf descriptor
+    static constexpr uint32_t LEAF1 = D16 ? 0x4000u : 0x40000000u;      // set together with LEAF
     static constexpr uint32_t INDEX_MASK = D16 ? 0x3FFFu : 0x3FFFFFFFu;
-    static constexpr uint32_t DONE = D16 ? 0xFFFFu : 0xFFFFFFFFu;    // "walk finished" marker, never a real descriptor
+    static constexpr uint32_t DONE = 0xFFFFFFFFu;                       // "walk finished" marker, never a real descriptor
+    static constexpr bool is_interior(uint32_t d) { return (int32_t)d >= 0; }
+    static constexpr bool is_leaf(uint32_t d) { return (int32_t)d < -1; }
 };
 constexpr uint32_t DESC32_MAX_INDEX = 0x3FFFFFFEu;   // largest encodable index (all-ones is DONE)
 constexpr uint32_t DESC16_MAX_INDEX = 0x3FFEu;
