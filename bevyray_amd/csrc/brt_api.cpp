@@ -553,6 +553,7 @@ int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, co
         v.stack_entries = e.stack_entries;
         v.desc16 = e.desc16 ? 1u : 0u;
         v.simple_tree = e.simple_tree ? 1u : 0u;
+        v.boxes_ordered = e.boxes_ordered ? 1u : 0u;
         dc.view = v;
     }
     for (auto& dc : ctx->devs) {
@@ -749,67 +750,6 @@ int32_t brt_build_bvh_device(brt_ctx* ctx, const void* models, uint32_t n_models
         return ctx_fail(ctx, BRT_ERR_CAPACITY, "BVH needs " + std::to_string(nodes.size()) + " nodes, capacity " + std::to_string(capacity));
     std::memcpy(out_nodes, nodes.data(), nodes.size() * sizeof(BVHNode));
     return BRT_OK;
-}
-
-// Diagnostic microbenchmark (not part of the product path): renders the frame once with the
-// COUNTERS kernel while recording up to max_rays rays, then times the trace-only kernel in
-// mode 0 (64 rays per wave, no refill) and mode 1 (in-loop refill at refill_min idle lanes).
-// out6 = {n_rays, ms_mode0, ms_mode1, iterations_mode1, lanes_mode1, results_equal}
-int32_t brt_debug_trace_bench(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t width, uint32_t height,
-                              uint32_t max_rays, uint32_t refill_min, double* out6) {
-    if (!ctx || !out6) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
-    if (!ctx->has_scene) return ctx_fail(ctx, BRT_ERR_NO_SCENE, "no scene");
-    DeviceCtx& dc = ctx->devs[0];
-    HIP_TRY(ctx, hipSetDevice(dc.device));
-    FrameParams fp;
-    int32_t rc = make_frame_params(ctx, camera80, window16, 3u, width, height, 0, 1, &fp);
-    if (rc != BRT_OK) return rc;
-    float *d_rays = nullptr, *d_out0 = nullptr, *d_out1 = nullptr, *d_tile = nullptr;
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_rays), (size_t)max_rays * 32));
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_out0), (size_t)max_rays * 8));
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_out1), (size_t)max_rays * 8));
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_tile), (size_t)width * height * 16));
-    auto body = [&]() -> int32_t {
-        HIP_TRY(ctx, hipMemsetAsync(dc.d_ctrl, 0, 512, dc.stream));
-        unsigned long long words[2] = {(unsigned long long)(uintptr_t)d_rays, (unsigned long long)max_rays};
-        HIP_TRY(ctx, hipMemcpyAsync(dc.d_ctrl + 24 * 8, words, sizeof words, hipMemcpyHostToDevice, dc.stream));
-        TraceLaunch tl{};
-        tl.scene = dc.view; tl.frame = fp;
-        tl.queue_counter = reinterpret_cast<uint32_t*>(dc.d_ctrl + 256);
-        tl.out_tile = d_tile; tl.counters = reinterpret_cast<unsigned long long*>(dc.d_ctrl);
-        tl.counters_on = true; tl.stream = dc.stream;
-        LaunchPlan lp = plan_launch(dc, fp);
-        tl.lds_scene = lp.lds_scene; tl.grid = lp.grid; tl.block = lp.block; tl.lds_bytes = lp.lds_bytes;
-        HIP_TRY(ctx, launch_trace_persistent(tl));
-        unsigned long long n_dumped = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&n_dumped, dc.d_ctrl + 26 * 8, 8, hipMemcpyDeviceToHost, dc.stream));
-        HIP_TRY(ctx, hipStreamSynchronize(dc.stream));
-        const uint32_t n = (uint32_t)(n_dumped < max_rays ? n_dumped : max_rays);
-        float ms[2] = {0, 0};
-        unsigned long long prof[2] = {0, 0};
-        for (int mode = 0; mode < 2; mode++) {
-            for (int rep = 0; rep < 2; rep++) {
-                HIP_TRY(ctx, hipMemsetAsync(dc.d_ctrl, 0, 512, dc.stream));
-                HIP_TRY(ctx, hipEventRecord(dc.ev0, dc.stream));
-                HIP_TRY(ctx, launch_bench_trace(mode, dc.view, d_rays, n, refill_min, reinterpret_cast<uint32_t*>(dc.d_ctrl + 256),
-                                                mode == 0 ? d_out0 : d_out1, reinterpret_cast<unsigned long long*>(dc.d_ctrl),
-                                                (uint32_t)dc.num_cus, dc.stream));
-                HIP_TRY(ctx, hipEventRecord(dc.ev1, dc.stream));
-                HIP_TRY(ctx, hipStreamSynchronize(dc.stream));
-                HIP_TRY(ctx, hipEventElapsedTime(&ms[mode], dc.ev0, dc.ev1));
-            }
-            if (mode == 1) HIP_TRY(ctx, hipMemcpy(prof, dc.d_ctrl, sizeof prof, hipMemcpyDeviceToHost));
-        }
-        std::vector<float> h0((size_t)n * 2), h1((size_t)n * 2);
-        HIP_TRY(ctx, hipMemcpy(h0.data(), d_out0, h0.size() * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(h1.data(), d_out1, h1.size() * 4, hipMemcpyDeviceToHost));
-        out6[0] = n; out6[1] = ms[0]; out6[2] = ms[1]; out6[3] = (double)prof[0]; out6[4] = (double)prof[1];
-        out6[5] = std::memcmp(h0.data(), h1.data(), h0.size() * 4) == 0 ? 1.0 : 0.0;
-        return BRT_OK;
-    };
-    rc = body();
-    (void)hipFree(d_rays); (void)hipFree(d_out0); (void)hipFree(d_out1); (void)hipFree(d_tile);
-    return rc;
 }
 
 int32_t brt_debug_profile(brt_ctx* ctx, uint64_t* out32) {

@@ -113,7 +113,8 @@ BRT_DEV void sphere_test(f3 o, f3 d, float a, float4 s, uint32_t idx, float& clo
 // Scene accessors.  The persistent kernel instantiates with LDS pointers, the bring-up
 // kernel and the large-scene variant with global pointers.
 struct ScenePtrs {
-    const float4* pairs;     // 4 per record: boxes of both children, then the two descriptors
+    const char* pairs;       // pair records of PAIR_BYTES (brt_layout.h): near/far planes by read offset, descriptors
+    bool boxes_ordered;      // every child box finite with min <= max (decided at upload)
     const float4* spheres;
     const uint32_t* sphere_material;
     const float4* materials;
@@ -174,12 +175,18 @@ struct WalkState {
     uint32_t cur;            // DONE when the walk has ended
     StackT* sp;
     uint32_t n;              // entries in use (overflow rule of general trees only)
+    // record base + the read offset this ray's direction selects on each axis (brt_layout.h): offset 8
+    // reads {min, max} = {near, far} for a direction >= 0, offset 0 reads {max, min} for a direction < 0
+    const char *px, *py, *pz;
 };
 
 template <bool D16, typename StackT>
-BRT_DEV void walk_begin(WalkState<StackT>& w, uint32_t root_desc, StackT* stk, f3 d) {
+BRT_DEV void walk_begin(WalkState<StackT>& w, const ScenePtrs& sc, uint32_t root_desc, StackT* stk, f3 d) {
     w.a = dot3(d, d);
     w.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    w.px = sc.pairs + PAIR_X + (w.inv.x < 0.0f ? 0u : 8u);
+    w.py = sc.pairs + PAIR_Y + (w.inv.y < 0.0f ? 0u : 8u);
+    w.pz = sc.pairs + PAIR_Z + (w.inv.z < 0.0f ? 0u : 8u);
     w.closest = kInf;
     w.closest_idx = 0xffffffffu;
     w.cur = root_desc;
@@ -222,21 +229,54 @@ BRT_DEV void walk_leaf_step(const ScenePtrs& sc, f3 o, f3 d, float a, float& clo
     n--;                                              // wraps with it; only read while cur != DONE
 }
 
-// Interior step (raytrace.wgsl:327-342) for a lane whose `cur` is a pair record: both slab tests,
-// push/pop as selects.
-template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, typename StackT>
-BRT_DEV void walk_interior_step(const ScenePtrs& sc, f3 o, f3 inv, float closest, uint32_t& cur, StackT*& sp, uint32_t& n,
-                                StackT* dummy_below, HitCounters& hc) {
+// A ray is "safe" for the near/far read offsets (brt_layout.h) when its origin is finite and every
+// component of 1/direction is finite and non-zero: then, for a finite box with min <= max,
+// (b - o) * inv is monotone in b and never NaN, so the value read as "near" IS min(t_min, t_max) and
+// the value read as "far" IS max(t_min, t_max) of raytrace.wgsl:391-392 (up to the sign of a zero,
+// which no comparison below can see).
+BRT_DEV bool ray_is_safe(f3 o, f3 inv) {
+    constexpr int kFinite = 0x1F8;          // -normal, -denormal, -0, +0, +denormal, +normal
+    constexpr int kFiniteNonZero = 0x198;   // -normal, -denormal, +denormal, +normal
+    return __builtin_amdgcn_classf(o.x, kFinite) && __builtin_amdgcn_classf(o.y, kFinite) &&
+           __builtin_amdgcn_classf(o.z, kFinite) && __builtin_amdgcn_classf(inv.x, kFiniteNonZero) &&
+           __builtin_amdgcn_classf(inv.y, kFiniteNonZero) && __builtin_amdgcn_classf(inv.z, kFiniteNonZero);
+}
+
+// Interior step (raytrace.wgsl:327-342, 387-398) for a lane whose `cur` is a pair record: both slab
+// tests, push/pop as selects.  FIX: apply min/max to the {near, far} values read (needed when some ray
+// of the wave is not safe or the boxes are not ordered); without it the read offset has already made
+// that choice.
+template <int STRIDE, bool COUNTERS, bool FIX, typename StackT>
+BRT_DEV void walk_interior_step(f3 o, f3 inv, const char* px, const char* py, const char* pz, float closest,
+                                uint32_t& cur, StackT*& sp, uint32_t& n, StackT* dummy_below, HitCounters& hc) {
     if (COUNTERS) { hc.node_pops++; hc.interior++; }
     if (STRIDE == 64) prof_section<COUNTERS>(hc, SEC_INTERIOR, true);
-    const float4* rec = sc.pairs + 4u * cur;
-    const float4 A = rec[0], B = rec[1], C = rec[2];
-    const uint2 D = *reinterpret_cast<const uint2*>(rec + 3);
+    const uint32_t ro = cur << 3;           // interior descriptor = record offset in 8-byte units
+    float2 nx = *reinterpret_cast<const float2*>(px + ro), fx = *reinterpret_cast<const float2*>(px + ro + 8);
+    const uint2 D = *reinterpret_cast<const uint2*>(px + ro + PAIR_DESC);
+    float2 ny = *reinterpret_cast<const float2*>(py + ro), fy = *reinterpret_cast<const float2*>(py + ro + 8);
+    float2 nz = *reinterpret_cast<const float2*>(pz + ro), fz = *reinterpret_cast<const float2*>(pz + ro + 8);
     // the would-be pop, issued with the node reads so that its LDS latency hides behind the slab
     // arithmetic; the store below goes to the entry above it (or to the dummy), never to it
     const uint32_t popped = (uint32_t)(int32_t)*sp;
-    const bool p1 = slab_push(o, inv, mk3(A.x, A.y, A.z), mk3(A.w, B.x, B.y), closest);
-    const bool p2 = slab_push(o, inv, mk3(B.z, B.w, C.x), mk3(C.y, C.z, C.w), closest);
+    // .x = child L (`index`), .y = child R (`index + 1`); (b - o) * (1/d) as in raytrace.wgsl:388-390
+    float nLx = (nx.x - o.x) * inv.x, fLx = (fx.x - o.x) * inv.x, nRx = (nx.y - o.x) * inv.x, fRx = (fx.y - o.x) * inv.x;
+    float nLy = (ny.x - o.y) * inv.y, fLy = (fy.x - o.y) * inv.y, nRy = (ny.y - o.y) * inv.y, fRy = (fy.y - o.y) * inv.y;
+    float nLz = (nz.x - o.z) * inv.z, fLz = (fz.x - o.z) * inv.z, nRz = (nz.y - o.z) * inv.z, fRz = (fz.y - o.z) * inv.z;
+    if (FIX) {
+        float t;
+        t = min_f(nLx, fLx); fLx = max_f(nLx, fLx); nLx = t;
+        t = min_f(nRx, fRx); fRx = max_f(nRx, fRx); nRx = t;
+        t = min_f(nLy, fLy); fLy = max_f(nLy, fLy); nLy = t;
+        t = min_f(nRy, fRy); fRy = max_f(nRy, fRy); nRy = t;
+        t = min_f(nLz, fLz); fLz = max_f(nLz, fLz); nLz = t;
+        t = min_f(nRz, fRz); fRz = max_f(nRz, fRz); nRz = t;
+    }
+    const float tnL = max_f(max_f(nLx, nLy), nLz), tfL = min_f(min_f(fLx, fLy), fLz);   // :393-394
+    const float tnR = max_f(max_f(nRx, nRy), nRz), tfR = min_f(min_f(fRx, fRy), fRz);
+    // pushed iff hit && dst < closest (raytrace.wgsl:331,338); see slab_push for why t_near serves as dst
+    const bool p1 = (tfL >= tnL) && (tfL > 0.0f) && (tnL < closest);
+    const bool p2 = (tfR >= tnR) && (tfR > 0.0f) && (tnR < closest);
     // reference: push `index` (D.x) then `index+1` (D.y); the later push is popped first
     const bool both = p1 && p2, none = !p1 && !p2;
     (both ? sp : dummy_below)[STRIDE] = (StackT)D.x;
@@ -244,6 +284,27 @@ BRT_DEV void walk_interior_step(const ScenePtrs& sc, f3 o, f3 inv, float closest
     const int step = both ? 1 : (none ? -1 : 0);
     sp += step * STRIDE;
     n += (uint32_t)step;
+}
+
+// The wave-level walk loop (see walk_run).
+template <bool COUNTERS, bool D16, bool SIMPLE_TREE, bool FIX, typename StackT>
+BRT_DEV void walk_loop_wave(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, const char* px, const char* py, const char* pz,
+                            float& closest, uint32_t& closest_idx, uint32_t& cur, StackT*& sp, uint32_t& n,
+                            StackT* dummy_below, uint32_t exit_at, uint32_t vote, HitCounters& hc) {
+    using DS = Desc<D16>;
+    for (;;) {
+        for (;;) {
+            const bool interior = DS::is_interior(cur) && (SIMPLE_TREE || n < 31u);
+            if (__ballot(interior) == 0ull) break;
+            if (interior) walk_interior_step<64, COUNTERS, FIX>(o, inv, px, py, pz, closest, cur, sp, n, dummy_below, hc);
+            const uint32_t want_leaf = (uint32_t)__popcll(__ballot(DS::is_leaf(cur) && (SIMPLE_TREE || n < 31u)));
+            if (want_leaf >= vote) break;
+        }
+        if (DS::is_leaf(cur) && (SIMPLE_TREE || n < 31u))
+            walk_leaf_step<64, COUNTERS, D16, SIMPLE_TREE>(sc, o, d, a, closest, closest_idx, cur, sp, n, hc);
+        const uint32_t n_walking = (uint32_t)__popcll(__ballot(cur != DS::DONE && (SIMPLE_TREE || n < 31u)));
+        if (n_walking <= exit_at) break;
+    }
 }
 
 template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, typename StackT>
@@ -258,8 +319,13 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, ui
     StackT* sp = w.sp;
     uint32_t n = w.n;
     StackT* const dummy_below = stk + (dummy_entry - 1u) * STRIDE;   // "push" target when nothing is pushed
+    const char* const px = w.px;
+    const char* const py = w.py;
+    const char* const pz = w.pz;
+    const bool pending = cur != DS::DONE && (SIMPLE_TREE || n < 31u);
+    const bool unsafe = !sc.boxes_ordered || (pending && !ray_is_safe(o, inv));
     if (STRIDE == 64) {
-        // Wave-level loop.  The kernel is bound by instruction issue, the two bodies cost the wave ~70
+        // Wave-level loop.  The kernel is bound by instruction issue, the two bodies cost the wave ~60-70
         // instructions each however few lanes take part, and a ray needs ~6 interior steps per leaf step:
         //   inner loop   interior steps only, until `leaf_vote` lanes wait at a leaf or no lane has an
         //                interior node left (a waiting lane sits those iterations out);
@@ -269,30 +335,28 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, ui
         //                so every call makes progress; exit_lanes == 0 runs all walks to the end.
         // Only the interleaving of lanes changes, never a lane's own sequence of steps.  With the signed
         // descriptor form (brt_layout.h) a finished lane fails both body tests by itself.
-        uint32_t n_walking = (uint32_t)__popcll(__ballot(cur != DS::DONE && (SIMPLE_TREE || n < 31u)));
+        // The loop exists twice: without and with the min/max repair of the near/far reads
+        // (walk_interior_step); the wave takes the second one only when one of its rays needs it.
+        const uint32_t n_walking = (uint32_t)__popcll(__ballot(pending));
         uint32_t exit_at = n_walking >> 1;
         exit_at = exit_at < exit_lanes ? exit_at : exit_lanes;
         const uint32_t vote = leaf_vote < 1u ? 1u : leaf_vote;
-        if (n_walking > exit_at) for (;;) {
-            for (;;) {
-                const bool interior = DS::is_interior(cur) && (SIMPLE_TREE || n < 31u);
-                if (__ballot(interior) == 0ull) break;
-                if (interior)
-                    walk_interior_step<STRIDE, COUNTERS, D16, SIMPLE_TREE>(sc, o, inv, closest, cur, sp, n, dummy_below, hc);
-                const uint32_t want_leaf = (uint32_t)__popcll(__ballot(DS::is_leaf(cur) && (SIMPLE_TREE || n < 31u)));
-                if (want_leaf >= vote) break;
-            }
-            if (DS::is_leaf(cur) && (SIMPLE_TREE || n < 31u))
-                walk_leaf_step<STRIDE, COUNTERS, D16, SIMPLE_TREE>(sc, o, d, a, closest, closest_idx, cur, sp, n, hc);
-            n_walking = (uint32_t)__popcll(__ballot(cur != DS::DONE && (SIMPLE_TREE || n < 31u)));
-            if (n_walking <= exit_at) break;
+        if (n_walking > exit_at) {
+            if (__ballot(unsafe) == 0ull)
+                walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, false>(sc, o, d, a, inv, px, py, pz, closest, closest_idx, cur, sp, n,
+                                                                  dummy_below, exit_at, vote, hc);
+            else
+                walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, true>(sc, o, d, a, inv, px, py, pz, closest, closest_idx, cur, sp, n,
+                                                                 dummy_below, exit_at, vote, hc);
         }
     } else {
         while (cur != DS::DONE && (SIMPLE_TREE || n < 31u)) {
             if (DS::is_leaf(cur))
                 walk_leaf_step<STRIDE, COUNTERS, D16, SIMPLE_TREE>(sc, o, d, a, closest, closest_idx, cur, sp, n, hc);
+            else if (unsafe)
+                walk_interior_step<STRIDE, COUNTERS, true>(o, inv, px, py, pz, closest, cur, sp, n, dummy_below, hc);
             else
-                walk_interior_step<STRIDE, COUNTERS, D16, SIMPLE_TREE>(sc, o, inv, closest, cur, sp, n, dummy_below, hc);
+                walk_interior_step<STRIDE, COUNTERS, false>(o, inv, px, py, pz, closest, cur, sp, n, dummy_below, hc);
         }
     }
     w.closest = closest;
@@ -307,7 +371,7 @@ template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, typename StackT
 BRT_DEV void raycast(const ScenePtrs& sc, uint32_t root_desc, StackT* stk, uint32_t dummy_entry, f3 o, f3 d,
                      float& t_out, uint32_t& idx_out, HitCounters& hc) {
     WalkState<StackT> w;
-    walk_begin<D16>(w, root_desc, stk, d);
+    walk_begin<D16>(w, sc, root_desc, stk, d);
     walk_run<STRIDE, COUNTERS, D16, SIMPLE_TREE>(sc, w, stk, dummy_entry, o, d, 0u, 0u, hc);
     t_out = w.closest;
     idx_out = w.closest_idx;

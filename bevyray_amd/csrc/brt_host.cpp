@@ -90,15 +90,17 @@ int32_t validate_and_encode(const Model* models, uint32_t n_models, const Materi
     EncodedScene& e = *out;
     e = EncodedScene();
     e.n_pairs = (uint32_t)order.size();
-    e.pairs.assign(16 * (size_t)e.n_pairs, 0.0f);
+    if ((uint64_t)e.n_pairs * PAIR_UNITS > 0x7FFFFFFFull) { *err = "scene too large for 31-bit record offsets"; return BRT_ERR_UNSUPPORTED; }
+    e.pairs.assign(pair_array_bytes(e.n_pairs) / 4, 0.0f);
 
     // 16-bit descriptors when every index fits 14 bits (general leaves <= nodes)
-    e.desc16 = (n_models <= DESC16_MAX_INDEX) && (n_nodes <= DESC16_MAX_INDEX);
+    e.desc16 = (n_models <= DESC16_MAX_INDEX) && (n_nodes <= DESC16_MAX_INDEX) &&
+               ((uint64_t)e.n_pairs * PAIR_UNITS <= 0x7FFFu);
     const uint32_t LEAF = e.desc16 ? Desc<true>::LEAF : Desc<false>::LEAF;
     const uint32_t LEAF1 = e.desc16 ? Desc<true>::LEAF1 : Desc<false>::LEAF1;
     auto desc_of = [&](uint32_t n) -> uint32_t {
         const BVHNode& nd = nodes[n];
-        if (nd.model_count == 0) return pair_id[n];
+        if (nd.model_count == 0) return pair_id[n] * PAIR_UNITS;   // record offset in 8-byte units
         if (nd.model_count == 1) return LEAF | LEAF1 | nd.index;
         uint32_t id = (uint32_t)(e.leaf_table.size() / 2);
         e.leaf_table.push_back(nd.index);
@@ -108,18 +110,25 @@ int32_t validate_and_encode(const Model* models, uint32_t n_models, const Materi
 
     // (for the 16-bit form LEAF is 0xFFFF8000: the register form, sign-extended -- brt_layout.h)
     e.root_desc = desc_of(0);
+    e.boxes_ordered = true;
     for (uint32_t i = 0; i < e.n_pairs; i++) {
         const BVHNode& nd = nodes[order[i]];
         const BVHNode& L = nodes[nd.index];
         const BVHNode& R = nodes[nd.index + 1];
-        float* a = &e.pairs[16 * (size_t)i];
-        float* b = a + 4;
-        float* c = a + 8;
-        a[0] = L.bounds_min[0]; a[1] = L.bounds_min[1]; a[2] = L.bounds_min[2]; a[3] = L.bounds_max[0];
-        b[0] = L.bounds_max[1]; b[1] = L.bounds_max[2]; b[2] = R.bounds_min[0]; b[3] = R.bounds_min[1];
-        c[0] = R.bounds_min[2]; c[1] = R.bounds_max[0]; c[2] = R.bounds_max[1]; c[3] = R.bounds_max[2];
-        const uint32_t dd[2] = {desc_of(nd.index), desc_of(nd.index + 1)};
-        std::memcpy(a + 12, dd, sizeof dd);
+        float* rec = &e.pairs[(size_t)PAIR_WORDS * i];
+        const uint32_t block[3] = {PAIR_X / 4, PAIR_Y / 4, PAIR_Z / 4};
+        for (int k = 0; k < 3; k++) {
+            float* a = rec + block[k];
+            a[0] = L.bounds_max[k]; a[1] = R.bounds_max[k];
+            a[2] = L.bounds_min[k]; a[3] = R.bounds_min[k];
+            a[4] = L.bounds_max[k]; a[5] = R.bounds_max[k];
+            for (const BVHNode* c : {&L, &R})
+                if (!(std::isfinite(c->bounds_min[k]) && std::isfinite(c->bounds_max[k]) && c->bounds_min[k] <= c->bounds_max[k]))
+                    e.boxes_ordered = false;
+        }
+        const uint32_t dl = desc_of(nd.index), dr = desc_of(nd.index + 1);
+        const uint32_t dd[4] = {dl, dr, dl, dr};
+        std::memcpy(rec + 6, dd, sizeof dd);
     }
 
     e.n_models = n_models;

@@ -14,7 +14,7 @@ int32_t fail(int32_t code, const std::string& msg);
 
 // Scene in the device encoding (brt_layout.h), still in host vectors.
 struct EncodedScene {
-    std::vector<float> pairs;            // 16 floats per pair record (brt_layout.h)
+    std::vector<float> pairs;            // PAIR_WORDS per pair record, padded to 16 bytes (brt_layout.h)
     std::vector<float> spheres;          // 4 per model
     std::vector<uint32_t> sphere_material;
     std::vector<float> materials;        // 8 per material
@@ -25,6 +25,7 @@ struct EncodedScene {
     uint32_t stack_entries = 2;
     bool desc16 = false;                 // descriptors in the 16-bit form (brt_layout.h)
     bool simple_tree = false;            // single-sphere leaves only, depth below the stack-overflow rule
+    bool boxes_ordered = false;          // every child box finite with min <= max
 };
 
 int32_t validate_and_encode(const Model* models, uint32_t n_models, const Material* materials, uint32_t n_materials,

@@ -34,8 +34,6 @@ hipError_t launch_trace_simple(const TraceLaunch& tl);
 hipError_t launch_passthrough(const FrameParams& fp, float* out_tile, const float* raster_rgba, hipStream_t stream);
 hipError_t launch_deinterleave(const float* tiles, float* frame, uint32_t width, uint32_t height, uint32_t n_parts,
                                uint32_t tile_rows, hipStream_t stream);
-hipError_t launch_bench_trace(int mode, const DeviceSceneView& sv, const float* rays, uint32_t n_rays, uint32_t refill_min,
-                              uint32_t* queue_counter, float* out, unsigned long long* prof, uint32_t grid, hipStream_t stream);
 hipError_t launch_debug_eval(uint32_t op, const float* in, float* out, uint32_t n, hipStream_t stream);
 
 // GPU PLOC builder (brt_bvh.hip): scratch size for n models, and the launch; *d_out / *d_info

@@ -23,7 +23,6 @@
 //                     stack.  Kept as an independent second implementation for debugging.
 // k_deinterleave      root side of the multi-GPU gather.
 // k_debug_eval        evaluates single device functions for per-function parity tests.
-// k_bench_trace       trace-only microbenchmark on recorded rays (diagnostic, scripts/trace_bench.py).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -153,10 +152,12 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     ScenePtrs sc;
     StackT* stacks;
     sc.materials = reinterpret_cast<const float4*>(sv.materials);
+    sc.boxes_ordered = sv.boxes_ordered != 0u;
     if (LDS_SCENE) {
         // carve: pair records | spheres | leaf_table | sphere_material | stacks
+        const uint32_t pair_granules = (uint32_t)(pair_array_bytes(sv.n_pairs) / 16);
         float4* p = reinterpret_cast<float4*>(smem);
-        float4* l_pairs = p; p += 4u * sv.n_pairs;
+        float4* l_pairs = p; p += pair_granules;
         float4* l_sp = p; p += sv.n_models;
         uint2* p2 = reinterpret_cast<uint2*>(p);
         uint2* l_lt = p2; p2 += sv.n_leaf_table;
@@ -166,14 +167,14 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         const float4* g_pairs = reinterpret_cast<const float4*>(sv.pairs);
         const float4* g_sp = reinterpret_cast<const float4*>(sv.spheres);
         const uint2* g_lt = reinterpret_cast<const uint2*>(sv.leaf_table);
-        for (uint32_t i = threadIdx.x; i < 4u * sv.n_pairs; i += blockDim.x) l_pairs[i] = g_pairs[i];
+        for (uint32_t i = threadIdx.x; i < pair_granules; i += blockDim.x) l_pairs[i] = g_pairs[i];
         for (uint32_t i = threadIdx.x; i < sv.n_models; i += blockDim.x) { l_sp[i] = g_sp[i]; l_sm[i] = sv.sphere_material[i]; }
         for (uint32_t i = threadIdx.x; i < sv.n_leaf_table; i += blockDim.x) l_lt[i] = g_lt[i];
-        sc.pairs = l_pairs;
+        sc.pairs = reinterpret_cast<const char*>(l_pairs);
         sc.spheres = l_sp; sc.sphere_material = l_sm; sc.leaf_table = l_lt;
         __syncthreads();
     } else {
-        sc.pairs = reinterpret_cast<const float4*>(sv.pairs);
+        sc.pairs = reinterpret_cast<const char*>(sv.pairs);
         sc.spheres = reinterpret_cast<const float4*>(sv.spheres);
         sc.sphere_material = sv.sphere_material;
         sc.leaf_table = reinterpret_cast<const uint2*>(sv.leaf_table);
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     WalkState<StackT> walk;
     walk.a = 0.0f; walk.inv = mk3(0.0f, 0.0f, 0.0f); walk.closest = kInf; walk.closest_idx = 0xffffffffu;
     walk.cur = Desc<D16>::DONE; walk.sp = stk; walk.n = 0;
+    walk.px = walk.py = walk.pz = sc.pairs;
     uint32_t n_rays = 0;
     HitCounters hc = {};
 
@@ -242,21 +244,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             tput = mk3(1.0f, 1.0f, 1.0f);
             first_depth = kInf;
         }
-        if (COUNTERS) {   // diagnostic ray dump for the trace microbenchmark (brt_debug_trace_bench)
-            float* dump = reinterpret_cast<float*>(counters[24]);
-            if (dump != nullptr) {
-                const uint64_t m = __ballot(fresh);
-                unsigned long long base = 0;
-                if (fresh && mbcnt64(m) == 0) base = atomicAdd(&counters[26], (unsigned long long)__popcll(m));
-                base = __shfl(base, (int)(__ffsll((long long)m) - 1), 64);
-                const unsigned long long slot = base + mbcnt64(m);
-                if (fresh && slot < counters[25]) {
-                    float* r = dump + slot * 8;
-                    r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z; r[6] = 0.0f; r[7] = 0.0f;
-                }
-            }
-        }
-        if (fresh) walk_begin<D16>(walk, sv.root_desc, stk, d);
+        if (fresh) walk_begin<D16>(walk, sc, sv.root_desc, stk, d);
         if (active) walk_run<64, COUNTERS, D16, SIMPLE>(sc, walk, stk, sv.stack_entries + 1u, o, d, fp.walk_exit_lanes, fp.leaf_vote, hc);
         in_flight = active && walk_pending<D16, SIMPLE>(walk);
         const bool landed = active && !in_flight;      // walk finished: shade this segment now
@@ -305,122 +293,6 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     }
 }
 
-// ---- trace-only microbenchmark (diagnostic) ----------------------------------------------------------
-// Walks a buffer of recorded rays (8 floats each: o, d, 2 pad), writes (t, idx) per ray.  Models the
-// trace phase of a workgroup-local ray pool: the scene AND a chunk of BENCH_CHUNK rays are staged in
-// LDS; a lane that finishes its ray takes the next one from the chunk (LDS atomic, wave-aggregated)
-// as soon as refill_min lanes of its wave are idle.  refill_min = 64 is the behaviour of
-// k_trace_persistent's rounds (64 rays per wave walked to completion).
-__global__ __launch_bounds__(BRT_BLOCK) void k_bench_trace(DeviceSceneView sv, const float4* __restrict__ rays, uint32_t n_rays,
-                                                          uint32_t refill_min, uint32_t BENCH_CHUNK, float2* __restrict__ out,
-                                                          unsigned long long* __restrict__ prof) {
-    using DS = Desc<true>;
-    extern __shared__ uint4 smem[];
-    ScenePtrs sc;
-    float4* p = reinterpret_cast<float4*>(smem);
-    float4* l_pairs = p; p += 4u * sv.n_pairs;
-    float4* l_sp = p; p += sv.n_models;
-    float4* l_ra = p; p += BENCH_CHUNK;          // ray chunk: {o.xyz, d.x}
-    uint2* p2 = reinterpret_cast<uint2*>(p);
-    uint2* l_rb = p2; p2 += BENCH_CHUNK;         //            {d.y, d.z}
-    uint32_t* pw = reinterpret_cast<uint32_t*>(p2);
-    uint32_t* l_head = pw; pw += 4;
-    int16_t* stacks = reinterpret_cast<int16_t*>(pw);
-    for (uint32_t i = threadIdx.x; i < 4u * sv.n_pairs; i += blockDim.x) l_pairs[i] = reinterpret_cast<const float4*>(sv.pairs)[i];
-    for (uint32_t i = threadIdx.x; i < sv.n_models; i += blockDim.x) l_sp[i] = reinterpret_cast<const float4*>(sv.spheres)[i];
-    sc.pairs = l_pairs; sc.spheres = l_sp;
-    sc.sphere_material = sv.sphere_material; sc.materials = nullptr; sc.leaf_table = nullptr;
-    const uint32_t lane = lane_id();
-    int16_t* stk = stacks + (threadIdx.x >> 6) * ((sv.stack_entries + 1u) * 64u) + lane;
-    const uint32_t dummy = sv.stack_entries;
-    uint32_t iters = 0, lanes = 0;
-
-    for (uint32_t chunk = blockIdx.x * BENCH_CHUNK; chunk < n_rays; chunk += gridDim.x * BENCH_CHUNK) {
-        const uint32_t cnt = (n_rays - chunk < BENCH_CHUNK) ? n_rays - chunk : BENCH_CHUNK;
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-            const float4 a = rays[2 * (chunk + i)], b = rays[2 * (chunk + i) + 1];
-            l_ra[i] = a;
-            l_rb[i] = make_uint2(__float_as_uint(b.x), __float_as_uint(b.y));
-        }
-        if (threadIdx.x == 0) l_head[0] = 0u;
-        __syncthreads();
-
-        f3 o = mk3(0, 0, 0), inv = mk3(1, 1, 1), d = mk3(0, 0, 1);
-        float a = 1.0f, closest = kInf;
-        uint32_t closest_idx = 0xffffffffu, cur = DS::DONE, n = 0, ray_id = 0xffffffffu;
-        bool exhausted = false;
-        for (;;) {
-            // ---- checkpoint: flush finished lanes, refill idle ones from the LDS chunk ----
-            const bool idle = (cur == DS::DONE);
-            const uint64_t mi = __ballot(idle);
-            const uint32_t ci = (uint32_t)__popcll(mi);
-            if (ci == 64u || (ci >= refill_min && !exhausted)) {
-                if (idle && ray_id != 0xffffffffu) { out[chunk + ray_id] = make_float2(closest, __uint_as_float(closest_idx)); ray_id = 0xffffffffu; }
-                if (!exhausted) {
-                    uint32_t base = 0;
-                    if (idle && mbcnt64(mi) == 0) base = atomicAdd(&l_head[0], ci);
-                    base = __shfl(base, (int)(__ffsll((long long)mi) - 1), 64);
-                    if (base + ci >= cnt) exhausted = true;
-                    const uint32_t r = base + mbcnt64(mi);
-                    if (idle && r < cnt) {
-                        const float4 ra = l_ra[r];
-                        const uint2 rb = l_rb[r];
-                        o = mk3(ra.x, ra.y, ra.z); d = mk3(ra.w, __uint_as_float(rb.x), __uint_as_float(rb.y));
-                        a = dot3(d, d);
-                        inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                        closest = kInf; closest_idx = 0xffffffffu; cur = sv.root_desc; n = 0; ray_id = r;
-                    }
-                }
-                if (__ballot(cur != DS::DONE) == 0ull) break;
-            }
-            // ---- one walk step for every walking lane (the bodies of raycast) ----
-            iters++;
-            lanes += (uint32_t)__popcll(__ballot(cur != DS::DONE));
-            if (cur != DS::DONE) {
-                if (DS::is_leaf(cur)) {
-                    const uint32_t first = cur & DS::INDEX_MASK;
-                    sphere_test(o, d, a, sc.spheres[first], first, closest, closest_idx);
-                    const bool has = n > 0u;
-                    n = has ? n - 1u : 0u;
-                    const uint32_t popped = (uint32_t)(int32_t)stk[n * 64];
-                    cur = has ? popped : DS::DONE;
-                } else {
-                    const float4* rec = sc.pairs + 4u * cur;
-                    const float4 A = rec[0], B = rec[1], C = rec[2];
-                    const uint2 D = *reinterpret_cast<const uint2*>(rec + 3);
-                    const bool p1 = slab_push(o, inv, mk3(A.x, A.y, A.z), mk3(A.w, B.x, B.y), closest);
-                    const bool p2b = slab_push(o, inv, mk3(B.z, B.w, C.x), mk3(C.y, C.z, C.w), closest);
-                    const bool both = p1 && p2b, none = !p1 && !p2b;
-                    stk[(both ? n : dummy) * 64] = (int16_t)D.x;
-                    const bool can_pop = none && n > 0u;
-                    const uint32_t popped = (uint32_t)(int32_t)stk[(n > 0u ? n - 1u : 0u) * 64];
-                    cur = p2b ? D.y : (p1 ? D.x : (can_pop ? popped : DS::DONE));
-                    n = both ? n + 1u : (can_pop ? n - 1u : n);
-                }
-            }
-        }
-    }
-    if (lane == 0) { atomicAdd(&prof[0], (unsigned long long)iters); atomicAdd(&prof[1], (unsigned long long)lanes); }
-}
-
-hipError_t launch_bench_trace(int mode, const DeviceSceneView& sv, const float* rays, uint32_t n_rays, uint32_t refill_min,
-                              uint32_t* queue_counter, float* out, unsigned long long* prof, uint32_t grid, hipStream_t stream) {
-    (void)queue_counter;
-    if (!sv.desc16 || !sv.simple_tree) return hipErrorInvalidValue;   // microbenchmark: 16-bit descriptors, simple trees
-    const char* eb = getenv("BRT_BENCH_BLOCK");
-    const char* ec = getenv("BRT_BENCH_CHUNK");
-    const uint32_t block = eb ? (uint32_t)atoi(eb) : (uint32_t)BRT_BLOCK;
-    const uint32_t chunk = ec ? (uint32_t)atoi(ec) : 2048u;
-    const size_t lds = (size_t)sv.n_pairs * 64 + (size_t)sv.n_models * 16 + (size_t)chunk * 24 + 16 +
-                       (size_t)(block / 64) * (sv.stack_entries + 1) * 64 * 2;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bench_trace), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_bench_trace, dim3(grid), dim3(block), lds, stream, sv, reinterpret_cast<const float4*>(rays), n_rays,
-                       mode == 0 ? 64u : refill_min, chunk, reinterpret_cast<float2*>(out), prof);
-    return hipGetLastError();
-}
-
 // ---- bring-up kernel ---------------------------------------------------------------------------
 
 template <bool D16, bool COUNTERS>
@@ -430,7 +302,8 @@ __global__ __launch_bounds__(256) void k_trace_simple(DeviceSceneView sv, FrameP
                                                       unsigned long long* __restrict__ counters) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     ScenePtrs sc;
-    sc.pairs = reinterpret_cast<const float4*>(sv.pairs);
+    sc.pairs = reinterpret_cast<const char*>(sv.pairs);
+    sc.boxes_ordered = sv.boxes_ordered != 0u;
     sc.spheres = reinterpret_cast<const float4*>(sv.spheres);
     sc.sphere_material = sv.sphere_material;
     sc.materials = reinterpret_cast<const float4*>(sv.materials);
@@ -550,7 +423,7 @@ __global__ void k_debug_eval(uint32_t op, const float* __restrict__ in, float* _
 size_t trace_lds_bytes(const DeviceSceneView& sv, bool lds_scene, uint32_t block) {
     size_t bytes = 0;
     if (lds_scene) {
-        bytes += (size_t)sv.n_pairs * 64 + (size_t)sv.n_models * 16;
+        bytes += pair_array_bytes(sv.n_pairs) + (size_t)sv.n_models * 16;
         bytes += (size_t)sv.n_leaf_table * 8 + (size_t)sv.n_models * 4;
     }
     bytes += (size_t)(block / 64) * (sv.stack_entries + 2) * 64 * (sv.desc16 ? 2 : 4);   // + 2: DONE sentinel, dummy entry

@@ -74,7 +74,8 @@ static_assert(sizeof(Window) == 16 && offsetof(Window, height) == 4, "Window");
 // The push/pop ORDER is the reference's, so results (ties, stack-overflow rule) are the same.
 //
 // Descriptor (32-bit form; scenes too large for LDS):
-//   bit31 = 0                 interior: bits[30:0] = pair-record index
+//   bit31 = 0                 interior: bits[30:0] = offset of the pair record in 8-byte units (index * 11), so that
+//                             a record address is one shift-add per axis
 //   bit31 = 1, bit30 = 1      leaf with exactly one sphere: bits[29:0] = model index
 //   bit31 = 1, bit30 = 0      general leaf: bits[29:0] = index into the leaf table {first, count}
 // 16-bit form (every index < 16384, always the case for an LDS-resident scene): the same three
@@ -97,21 +98,32 @@ struct Desc {
 constexpr uint32_t DESC32_MAX_INDEX = 0x3FFFFFFEu;   // largest encodable index (all-ones is DONE)
 constexpr uint32_t DESC16_MAX_INDEX = 0x3FFEu;
 
-// Pair records are stored as four parallel arrays of 16-byte (12 for the last) granules so
-// that 64 lanes reading 64 different records spread over all LDS banks (a 64-byte
-// array-of-structs stride would alias to 4 bank groups).
-//   pairs[4i + 0] = { L.min.x, L.min.y, L.min.z, L.max.x }
-//   pairs[4i + 1] = { L.max.y, L.max.z, R.min.x, R.min.y }
-//   pairs[4i + 2] = { R.min.z, R.max.x, R.max.y, R.max.z }
-//   pairs[4i + 3] = { descL, descR, 0, 0 } (as u32; L = node `index`, R = node `index + 1`)
-// i.e. one 64-byte record per interior node: one address computation and four LDS reads with
-// immediate offsets per visit; from global memory, one half cache line instead of four lines.
+// Pair record: 88 bytes (22 words) per interior node, children L = node `index`, R = `index + 1`.
+// The slab test needs, per axis, the plane the ray ENTERS through and the plane it LEAVES through;
+// which of {min, max} that is depends only on the sign of the ray direction on that axis.  Each axis
+// block therefore holds   max L R | min L R | max L R   (8 bytes per pair), and a lane reads 16 bytes
+// at offset 8 (direction >= 0: {min, max} = {near, far}) or at offset 0 (direction < 0: {max, min}):
+// the reference's min()/max() per axis (raytrace.wgsl:391-392) become an address chosen once per ray.
+//   word  0.. 5   x block: max.x L R, min.x L R, max.x L R
+//   word  6.. 9   descL descR descL descR  (register form) -- 24 bytes after EITHER read offset of the x block
+//   word 10..15   y block
+//   word 16..21   z block
+// That choice is exact when the ray is "safe" (origin finite, 1/direction finite and non-zero) and the
+// boxes are finite with min <= max (checked at upload, `boxes_ordered`): then (b - o) * inv is monotone in b
+// and no NaN can arise.  Otherwise the kernels apply min/max to the two values they read, which is the
+// reference's expression whatever the read offset was.
+// The array is padded to a multiple of 16 bytes.
+constexpr uint32_t PAIR_WORDS = 22;
+constexpr uint32_t PAIR_BYTES = 88;
+constexpr uint32_t PAIR_UNITS = PAIR_BYTES / 8;   // an interior descriptor counts records in these units
+constexpr uint32_t PAIR_X = 0, PAIR_DESC = 24, PAIR_Y = 40, PAIR_Z = 64;   // byte offsets (PAIR_DESC relative to the x read address)
+constexpr size_t pair_array_bytes(uint32_t n_pairs) { return ((size_t)n_pairs * PAIR_BYTES + 15) & ~(size_t)15; }
 // Spheres: { center.x, center.y, center.z, radius*radius } (hit_sphere only uses r*r,
 // raytrace.wgsl:375), material ids in a parallel u32 array.
 // Materials: two float4 per material, as on the wire.
 
 struct DeviceSceneView {
-    const float* pairs;      // float4[4 * n_pairs], 64-byte aligned records
+    const float* pairs;      // n_pairs records of PAIR_BYTES, array padded to 16 bytes
     const float* spheres;    // float4[n_models]
     const uint32_t* sphere_material;  // u32[n_models]
     const float* materials;  // float4[2*n_materials]
@@ -121,6 +133,7 @@ struct DeviceSceneView {
     uint32_t stack_entries;  // min(32, max leaf depth + 1)
     uint32_t desc16;         // 1: descriptors are in the 16-bit form
     uint32_t simple_tree;    // 1: every leaf holds one sphere and max leaf depth + 1 < 31
+    uint32_t boxes_ordered;  // 1: every child box is finite with min <= max
 };
 
 // Frame-uniform values, evaluated once on the host with the reference's expressions

@@ -174,13 +174,6 @@ int32_t brt_debug_eval(brt_ctx* ctx, uint32_t op, const float* in16, float* out8
  * (k: 0 interior step, 1 leaf step, 2 camera ray, 3 scatter, 4 sky, 5 -, 6 -, 7 ray round). */
 int32_t brt_debug_profile(brt_ctx* ctx, uint64_t* out32);
 
-/* Diagnostic microbenchmark: renders the frame once while recording up to max_rays rays, then
- * times a trace-only kernel on them with and without in-loop lane refill from an LDS ray chunk
- * (scripts/trace_bench.py).  out6 = {rays, ms without refill, ms with,
- * iterations, walking-lane sum, results equal}. */
-int32_t brt_debug_trace_bench(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t width, uint32_t height,
-                              uint32_t max_rays, uint32_t refill_min, double* out6);
-
 /* ---- host-only helpers (no GPU needed) --------------------------------------------- */
 
 /* Replaces: obvhs::ploc::build_ploc::<24>(aabbs, identity, SortPrecision::U64, 0) and the
