@@ -110,6 +110,10 @@ BRT_DEV void sphere_test(f3 o, f3 d, float a, float4 s, uint32_t idx, float& clo
     closest_idx = accept ? idx : closest_idx;
 }
 
+// closest is INF (FLT_MAX) or an accepted t > 0.001: a positive normal float, whose predecessor is its
+// bit pattern minus one
+BRT_DEV float float_below(float closest) { return __uint_as_float(__float_as_uint(closest) - 1u); }
+
 // Scene accessors.  The persistent kernel instantiates with LDS pointers, the bring-up
 // kernel and the large-scene variant with global pointers.
 struct ScenePtrs {
@@ -247,7 +251,7 @@ BRT_DEV bool ray_is_safe(f3 o, f3 inv) {
 // of the wave is not safe or the boxes are not ordered); without it the read offset has already made
 // that choice.
 template <int STRIDE, bool COUNTERS, bool FIX, typename StackT>
-BRT_DEV void walk_interior_step(f3 o, f3 inv, const char* px, const char* py, const char* pz, float closest,
+BRT_DEV void walk_interior_step(f3 o, f3 inv, const char* px, const char* py, const char* pz, float below,
                                 uint32_t& cur, StackT*& sp, uint32_t& n, StackT* dummy_below, HitCounters& hc) {
     if (COUNTERS) { hc.node_pops++; hc.interior++; }
     if (STRIDE == 64) prof_section<COUNTERS>(hc, SEC_INTERIOR, true);
@@ -274,9 +278,20 @@ BRT_DEV void walk_interior_step(f3 o, f3 inv, const char* px, const char* py, co
     }
     const float tnL = max_f(max_f(nLx, nLy), nLz), tfL = min_f(min_f(fLx, fLy), fLz);   // :393-394
     const float tnR = max_f(max_f(nRx, nRy), nRz), tfR = min_f(min_f(fRx, fRy), fRz);
-    // pushed iff hit && dst < closest (raytrace.wgsl:331,338); see slab_push for why t_near serves as dst
-    const bool p1 = (tfL >= tnL) && (tfL > 0.0f) && (tnL < closest);
-    const bool p2 = (tfR >= tnR) && (tfR > 0.0f) && (tnR < closest);
+    // pushed iff hit && dst < closest (raytrace.wgsl:331,338); see slab_push for why t_near serves as dst.
+    // `below` is the largest float under closest, so t_near < closest == t_near <= below.  Without NaNs
+    // (FIX off) the three compares fold into one: t_far > 0 == t_far >= the smallest denormal, hence
+    //   t_far >= t_near && t_far > 0 && t_near <= below   ==   max(t_near, denorm_min) <= min(t_far, below)
+    // (below >= 0.001 > denorm_min always; f32 denormals are not flushed in this build).
+    bool p1, p2;
+    if (FIX) {
+        p1 = (tfL >= tnL) && (tfL > 0.0f) && (tnL <= below);
+        p2 = (tfR >= tnR) && (tfR > 0.0f) && (tnR <= below);
+    } else {
+        const float dmin = __uint_as_float(1u);
+        p1 = max_f(tnL, dmin) <= min_f(tfL, below);
+        p2 = max_f(tnR, dmin) <= min_f(tfR, below);
+    }
     // reference: push `index` (D.x) then `index+1` (D.y); the later push is popped first
     const bool both = p1 && p2, none = !p1 && !p2;
     (both ? sp : dummy_below)[STRIDE] = (StackT)D.x;
@@ -292,16 +307,19 @@ BRT_DEV void walk_loop_wave(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, co
                             float& closest, uint32_t& closest_idx, uint32_t& cur, StackT*& sp, uint32_t& n,
                             StackT* dummy_below, uint32_t exit_at, uint32_t vote, HitCounters& hc) {
     using DS = Desc<D16>;
+    float below = float_below(closest);
     for (;;) {
         for (;;) {
             const bool interior = DS::is_interior(cur) && (SIMPLE_TREE || n < 31u);
             if (__ballot(interior) == 0ull) break;
-            if (interior) walk_interior_step<64, COUNTERS, FIX>(o, inv, px, py, pz, closest, cur, sp, n, dummy_below, hc);
+            if (interior) walk_interior_step<64, COUNTERS, FIX>(o, inv, px, py, pz, below, cur, sp, n, dummy_below, hc);
             const uint32_t want_leaf = (uint32_t)__popcll(__ballot(DS::is_leaf(cur) && (SIMPLE_TREE || n < 31u)));
             if (want_leaf >= vote) break;
         }
-        if (DS::is_leaf(cur) && (SIMPLE_TREE || n < 31u))
+        if (DS::is_leaf(cur) && (SIMPLE_TREE || n < 31u)) {
             walk_leaf_step<64, COUNTERS, D16, SIMPLE_TREE>(sc, o, d, a, closest, closest_idx, cur, sp, n, hc);
+            below = float_below(closest);
+        }
         const uint32_t n_walking = (uint32_t)__popcll(__ballot(cur != DS::DONE && (SIMPLE_TREE || n < 31u)));
         if (n_walking <= exit_at) break;
     }
@@ -354,9 +372,9 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, ui
             if (DS::is_leaf(cur))
                 walk_leaf_step<STRIDE, COUNTERS, D16, SIMPLE_TREE>(sc, o, d, a, closest, closest_idx, cur, sp, n, hc);
             else if (unsafe)
-                walk_interior_step<STRIDE, COUNTERS, true>(o, inv, px, py, pz, closest, cur, sp, n, dummy_below, hc);
+                walk_interior_step<STRIDE, COUNTERS, true>(o, inv, px, py, pz, float_below(closest), cur, sp, n, dummy_below, hc);
             else
-                walk_interior_step<STRIDE, COUNTERS, false>(o, inv, px, py, pz, closest, cur, sp, n, dummy_below, hc);
+                walk_interior_step<STRIDE, COUNTERS, false>(o, inv, px, py, pz, float_below(closest), cur, sp, n, dummy_below, hc);
         }
     }
     w.closest = closest;
