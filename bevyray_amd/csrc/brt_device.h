@@ -131,7 +131,7 @@ struct HitCounters {
     // lanes (lane-utilisation profile; read by brt_debug_profile)
     uint32_t sec_exec[8], sec_lanes[8];
 };
-enum { SEC_INTERIOR = 0, SEC_LEAF, SEC_CAMERA, SEC_SCATTER, SEC_SKY, SEC_END_SAMPLE, SEC_REFILL, SEC_ROUND };
+enum { SEC_INTERIOR = 0, SEC_LEAF, SEC_CAMERA, SEC_SCATTER, SEC_SKY, SEC_BALL, SEC_REFILL, SEC_ROUND };
 
 // Counts one execution of a code section and its active lanes.  May be called under divergent
 // control flow: the ballot only sees the lanes that reached the call; the first of them books it.
@@ -147,17 +147,16 @@ BRT_DEV void prof_section(HitCounters& hc, int sec, bool pred) {
 }
 
 // raytrace.wgsl:313-362: closest hit of one ray.  `stk` points at this lane's column of a
-// [entries + 1][STRIDE] array (LDS: u16 entries when descriptors are 16-bit; bring-up kernel:
-// a private array, STRIDE 1); entry `dummy_entry` (the extra one) absorbs the stores of lanes
-// that push nothing.
+// [entries][STRIDE] array (LDS: 16-bit entries when descriptors are 16-bit; bring-up kernel:
+// a private array, STRIDE 1).
 // Reference bookkeeping: stack_index == (entries in stk) + (cur valid ? 1 : 0); the loop
 // condition stack_index > 0 && stack_index < 32 (raytrace.wgsl:320) is `cur != DONE && n < 31`.
 //
 // The kernel is bound by TOTAL instruction issue (VALU + scalar + branches), and a
 // divergent if/else nest costs scalar exec-mask bookkeeping on every level.  So both bodies
 // are straight-line: the child selection, push and pop of raytrace.wgsl:331-341 become
-// selects, the push is an unconditional LDS store (to the dummy entry when nothing is
-// pushed), the pop an unconditional LDS load.  hit_sphere's `discriminant < 0 -> -1`
+// selects, the push is an unconditional LDS store (above the top when nothing is pushed, where
+// it is dead), the pop an unconditional LDS load.  hit_sphere's `discriminant < 0 -> -1`
 // (raytrace.wgsl:378-380) needs no branch either: sqrt of a negative is NaN and a NaN t
 // fails `t > 0.001`, exactly like -1 does.
 // SIMPLE_TREE (decided at upload): every leaf holds one sphere and the tree is shallower than
@@ -252,7 +251,7 @@ BRT_DEV bool ray_is_safe(f3 o, f3 inv) {
 // that choice.
 template <int STRIDE, bool COUNTERS, bool FIX, typename StackT>
 BRT_DEV void walk_interior_step(f3 o, f3 inv, const char* px, const char* py, const char* pz, float below,
-                                uint32_t& cur, StackT*& sp, uint32_t& n, StackT* dummy_below, HitCounters& hc) {
+                                uint32_t& cur, StackT*& sp, uint32_t& n, HitCounters& hc) {
     if (COUNTERS) { hc.node_pops++; hc.interior++; }
     if (STRIDE == 64) prof_section<COUNTERS>(hc, SEC_INTERIOR, true);
     const uint32_t ro = cur << 3;           // interior descriptor = record offset in 8-byte units
@@ -261,7 +260,7 @@ BRT_DEV void walk_interior_step(f3 o, f3 inv, const char* px, const char* py, co
     float2 ny = *reinterpret_cast<const float2*>(py + ro), fy = *reinterpret_cast<const float2*>(py + ro + 8);
     float2 nz = *reinterpret_cast<const float2*>(pz + ro), fz = *reinterpret_cast<const float2*>(pz + ro + 8);
     // the would-be pop, issued with the node reads so that its LDS latency hides behind the slab
-    // arithmetic; the store below goes to the entry above it (or to the dummy), never to it
+    // arithmetic; the store below goes to the entry above it, never to it
     const uint32_t popped = (uint32_t)(int32_t)*sp;
     // .x = child L (`index`), .y = child R (`index + 1`); (b - o) * (1/d) as in raytrace.wgsl:388-390
     float nLx = (nx.x - o.x) * inv.x, fLx = (fx.x - o.x) * inv.x, nRx = (nx.y - o.x) * inv.x, fRx = (fx.y - o.x) * inv.x;
@@ -294,7 +293,9 @@ BRT_DEV void walk_interior_step(f3 o, f3 inv, const char* px, const char* py, co
     }
     // reference: push `index` (D.x) then `index+1` (D.y); the later push is popped first
     const bool both = p1 && p2, none = !p1 && !p2;
-    (both ? sp : dummy_below)[STRIDE] = (StackT)D.x;
+    // stored even when it is not pushed: the entry above the top is dead, and it exists (an interior node
+    // of depth k sees at most k entries below it; brt_host.cpp sizes the stack by the deepest LEAF)
+    sp[STRIDE] = (StackT)D.x;
     cur = p2 ? D.y : (p1 ? D.x : popped);
     const int step = both ? 1 : (none ? -1 : 0);
     sp += step * STRIDE;
@@ -305,14 +306,14 @@ BRT_DEV void walk_interior_step(f3 o, f3 inv, const char* px, const char* py, co
 template <bool COUNTERS, bool D16, bool SIMPLE_TREE, bool FIX, typename StackT>
 BRT_DEV void walk_loop_wave(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, const char* px, const char* py, const char* pz,
                             float& closest, uint32_t& closest_idx, uint32_t& cur, StackT*& sp, uint32_t& n,
-                            StackT* dummy_below, uint32_t exit_at, uint32_t vote, HitCounters& hc) {
+                            uint32_t exit_at, uint32_t vote, HitCounters& hc) {
     using DS = Desc<D16>;
     float below = float_below(closest);
     for (;;) {
         for (;;) {
             const bool interior = DS::is_interior(cur) && (SIMPLE_TREE || n < 31u);
             if (__ballot(interior) == 0ull) break;
-            if (interior) walk_interior_step<64, COUNTERS, FIX>(o, inv, px, py, pz, below, cur, sp, n, dummy_below, hc);
+            if (interior) walk_interior_step<64, COUNTERS, FIX>(o, inv, px, py, pz, below, cur, sp, n, hc);
             const uint32_t want_leaf = (uint32_t)__popcll(__ballot(DS::is_leaf(cur) && (SIMPLE_TREE || n < 31u)));
             if (want_leaf >= vote) break;
         }
@@ -326,7 +327,7 @@ BRT_DEV void walk_loop_wave(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, co
 }
 
 template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, typename StackT>
-BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, uint32_t dummy_entry, f3 o, f3 d,
+BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, f3 o, f3 d,
                       uint32_t exit_lanes, uint32_t leaf_vote, HitCounters& hc) {
     using DS = Desc<D16>;
     const float a = w.a;
@@ -336,7 +337,6 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, ui
     uint32_t cur = w.cur;
     StackT* sp = w.sp;
     uint32_t n = w.n;
-    StackT* const dummy_below = stk + (dummy_entry - 1u) * STRIDE;   // "push" target when nothing is pushed
     const char* const px = w.px;
     const char* const py = w.py;
     const char* const pz = w.pz;
@@ -362,19 +362,19 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, ui
         if (n_walking > exit_at) {
             if (__ballot(unsafe) == 0ull)
                 walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, false>(sc, o, d, a, inv, px, py, pz, closest, closest_idx, cur, sp, n,
-                                                                  dummy_below, exit_at, vote, hc);
+                                                                  exit_at, vote, hc);
             else
                 walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, true>(sc, o, d, a, inv, px, py, pz, closest, closest_idx, cur, sp, n,
-                                                                 dummy_below, exit_at, vote, hc);
+                                                                 exit_at, vote, hc);
         }
     } else {
         while (cur != DS::DONE && (SIMPLE_TREE || n < 31u)) {
             if (DS::is_leaf(cur))
                 walk_leaf_step<STRIDE, COUNTERS, D16, SIMPLE_TREE>(sc, o, d, a, closest, closest_idx, cur, sp, n, hc);
             else if (unsafe)
-                walk_interior_step<STRIDE, COUNTERS, true>(o, inv, px, py, pz, float_below(closest), cur, sp, n, dummy_below, hc);
+                walk_interior_step<STRIDE, COUNTERS, true>(o, inv, px, py, pz, float_below(closest), cur, sp, n, hc);
             else
-                walk_interior_step<STRIDE, COUNTERS, false>(o, inv, px, py, pz, float_below(closest), cur, sp, n, dummy_below, hc);
+                walk_interior_step<STRIDE, COUNTERS, false>(o, inv, px, py, pz, float_below(closest), cur, sp, n, hc);
         }
     }
     w.closest = closest;
@@ -386,11 +386,11 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, ui
 
 // whole walk in one call (bring-up kernel, probes)
 template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, typename StackT>
-BRT_DEV void raycast(const ScenePtrs& sc, uint32_t root_desc, StackT* stk, uint32_t dummy_entry, f3 o, f3 d,
+BRT_DEV void raycast(const ScenePtrs& sc, uint32_t root_desc, StackT* stk, f3 o, f3 d,
                      float& t_out, uint32_t& idx_out, HitCounters& hc) {
     WalkState<StackT> w;
     walk_begin<D16>(w, sc, root_desc, stk, d);
-    walk_run<STRIDE, COUNTERS, D16, SIMPLE_TREE>(sc, w, stk, dummy_entry, o, d, 0u, 0u, hc);
+    walk_run<STRIDE, COUNTERS, D16, SIMPLE_TREE>(sc, w, stk, o, d, 0u, 0u, hc);
     t_out = w.closest;
     idx_out = w.closest_idx;
 }
@@ -422,7 +422,8 @@ BRT_DEV float schlick(float cosine, float ri) {
 // the kind, then ONE rejection loop serves every lane that still needs a ball (metal 1,
 // diffuse 2, glass 0) and ONE normalize serves metal (reflected direction) and glass (incoming
 // direction).  Per lane the RNG draws and the arithmetic are the shader's, in its order.
-BRT_DEV bool scatter(const ScenePtrs& sc, f3& o, f3& d, float t, uint32_t idx, uint32_t& rng, f3& attenuation) {
+template <bool COUNTERS>
+BRT_DEV bool scatter(const ScenePtrs& sc, f3& o, f3& d, float t, uint32_t idx, uint32_t& rng, f3& attenuation, HitCounters& hc) {
     const float4 s = sc.spheres[idx];
     const f3 pos = mk3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);          // ray_at, :130-132
     const f3 nrm = normalize3(mk3(pos.x - s.x, pos.y - s.y, pos.z - s.z));    // :356
@@ -435,22 +436,22 @@ BRT_DEV bool scatter(const ScenePtrs& sc, f3& o, f3& d, float t, uint32_t idx, u
 
     // balls: metal fuzz = roughness * ball (:238); diffuse normal + ball + roughness * ball (:285)
     uint32_t need = metal ? 1u : (diffuse ? 2u : 0u);
-    // Branch-free accept: candidate = base + scale * p with (base, scale) = (normal, 1) for the first
-    // diffuse ball (1 * p == p), (acc, roughness) for the second, (-0, roughness) for metal fuzz --
-    // adding to -0 returns the other operand bit for bit, signed zeros included, so each case is the
-    // shader's own expression.
-    f3 acc = mk3(-0.0f, -0.0f, -0.0f);
+    // Branch-free accept with ONE running sum: candidate = acc + scale * p.  Diffuse starts from
+    // (acc, scale) = (normal, 1) -- 1 * p == p -- and continues with (normal + ball, roughness); metal
+    // starts from (-0, roughness): adding to -0 returns the other operand bit for bit, signed zeros
+    // included.  Each accepted candidate is the shader's own expression.
+    f3 acc = diffuse ? nrm : mk3(-0.0f, -0.0f, -0.0f);
+    float scale = diffuse ? 1.0f : m1.x;
     while (need != 0u) {                                                      // random.wgsl:19-24
+        if (COUNTERS) prof_section<COUNTERS>(hc, SEC_BALL, true);
         const float px = rng_ball_coord(rng);
         const float py = rng_ball_coord(rng);
         const float pz = rng_ball_coord(rng);
         const f3 p = mk3(px, py, pz);
         const bool ok = dot3(p, p) <= 1.0f;
-        const bool first = diffuse && need == 2u;
-        const f3 base = mk3(first ? nrm.x : acc.x, first ? nrm.y : acc.y, first ? nrm.z : acc.z);
-        const float scale = first ? 1.0f : m1.x;
-        const f3 cand = base + scale * p;
+        const f3 cand = acc + scale * p;
         acc = mk3(ok ? cand.x : acc.x, ok ? cand.y : acc.y, ok ? cand.z : acc.z);
+        scale = ok ? m1.x : scale;
         need -= ok ? 1u : 0u;
     }
 

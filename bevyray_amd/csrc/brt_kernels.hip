@@ -106,8 +106,9 @@ BRT_DEV void pixel_finish(const FrameParams& fp, const PixelState& ps, float* ou
 
 // One ray segment of the bounce loop, raytrace.wgsl:189-212, after raycast returned (t, idx).
 // Returns true when the sample has ended; then `color` is its gamma-encoded colour (:223).
+template <bool COUNTERS>
 BRT_DEV bool shade_segment(const ScenePtrs& sc, const FrameParams& fp, f3& o, f3& d, f3& tput, uint32_t& bounce,
-                           float& first_depth, float t, uint32_t idx, uint32_t& rng, f3& color, uint32_t& hits) {
+                           float& first_depth, float t, uint32_t idx, uint32_t& rng, f3& color, HitCounters& hc) {
     if (bounce == 0) first_depth = t;                               // :193-195
     f3 light = mk3(0.0f, 0.0f, 0.0f);
     bool ended;
@@ -115,9 +116,9 @@ BRT_DEV bool shade_segment(const ScenePtrs& sc, const FrameParams& fp, f3& o, f3
         light = background_gradient(d);
         ended = true;
     } else {
-        hits++;
+        hc.hits++;
         f3 att;
-        const bool absorbed = scatter(sc, o, d, t, idx, rng, att);  // :204
+        const bool absorbed = scatter<COUNTERS>(sc, o, d, t, idx, rng, att, hc);  // :204
         if (absorbed) {
             ended = true;                                           // :207-209, light stays 0
         } else {
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     }
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
-    StackT* stk = stacks + wave * ((sv.stack_entries + 2u) * 64u) + lane;   // + 2: DONE sentinel (entry 0) and dummy entry
+    StackT* stk = stacks + wave * ((sv.stack_entries + 2u) * 64u) + lane;   // + 2: DONE sentinel (entry 0) and one spare entry
 
     PixelState ps;
     ps.sample = 0; ps.rng = 0; ps.out_index = 0; ps.frame_index = 0; ps.tile = 0; ps.rays_begin = 0;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             first_depth = kInf;
         }
         if (fresh) walk_begin<D16>(walk, sc, sv.root_desc, stk, d);
-        if (active) walk_run<64, COUNTERS, D16, SIMPLE>(sc, walk, stk, sv.stack_entries + 1u, o, d, fp.walk_exit_lanes, fp.leaf_vote, hc);
+        if (active) walk_run<64, COUNTERS, D16, SIMPLE>(sc, walk, stk, o, d, fp.walk_exit_lanes, fp.leaf_vote, hc);
         in_flight = active && walk_pending<D16, SIMPLE>(walk);
         const bool landed = active && !in_flight;      // walk finished: shade this segment now
         const float t = walk.closest;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         if (landed) {
             n_rays++;
             f3 color;
-            if (shade_segment(sc, fp, o, d, tput, bounce, first_depth, t, idx, ps.rng, color, hc.hits)) {
+            if (shade_segment<COUNTERS>(sc, fp, o, d, tput, bounce, first_depth, t, idx, ps.rng, color, hc)) {
                 ps.sum = ps.sum + color;                                                   // :165
                 ps.dsum = ps.dsum + (first_depth == kInf ? fp.fallback_far : first_depth); // :166,219-221
                 ps.sample++;
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void k_trace_simple(DeviceSceneView sv, FrameP
         if (c.inside) {
             PixelState ps;
             pixel_begin(fp, c, ps);
-            uint32_t stack[34];   // DONE sentinel + 32 entries + the dummy slot
+            uint32_t stack[34];   // DONE sentinel + 32 entries + one spare
             for (uint32_t s = 0; s < fp.sample_count; s++) {          // raytrace.wgsl:161
                 f3 d = camera_ray_dir(fp, ps.ndc0x, ps.ndc0y, ps.rng);
                 f3 o = mk3(fp.cam_pos[0], fp.cam_pos[1], fp.cam_pos[2]);
@@ -326,9 +327,9 @@ __global__ __launch_bounds__(256) void k_trace_simple(DeviceSceneView sv, FrameP
                 for (;;) {
                     float t;
                     uint32_t idx;
-                    raycast<1, COUNTERS, D16, false>(sc, sv.root_desc, stack, 33u, o, d, t, idx, hc);
+                    raycast<1, COUNTERS, D16, false>(sc, sv.root_desc, stack, o, d, t, idx, hc);
                     n_rays++;
-                    if (shade_segment(sc, fp, o, d, tput, bounce, first_depth, t, idx, ps.rng, color, hc.hits)) break;
+                    if (shade_segment<COUNTERS>(sc, fp, o, d, tput, bounce, first_depth, t, idx, ps.rng, color, hc)) break;
                 }
                 ps.sum = ps.sum + color;
                 ps.dsum = ps.dsum + (first_depth == kInf ? fp.fallback_far : first_depth);
@@ -426,7 +427,7 @@ size_t trace_lds_bytes(const DeviceSceneView& sv, bool lds_scene, uint32_t block
         bytes += pair_array_bytes(sv.n_pairs) + (size_t)sv.n_models * 16;
         bytes += (size_t)sv.n_leaf_table * 8 + (size_t)sv.n_models * 4;
     }
-    bytes += (size_t)(block / 64) * (sv.stack_entries + 2) * 64 * (sv.desc16 ? 2 : 4);   // + 2: DONE sentinel, dummy entry
+    bytes += (size_t)(block / 64) * (sv.stack_entries + 2) * 64 * (sv.desc16 ? 2 : 4);   // + 2: DONE sentinel, one spare entry
     return (bytes + 15) & ~(size_t)15;
 }
 

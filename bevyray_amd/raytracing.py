@@ -285,7 +285,7 @@ class RaytracePlugin:
         """Lane-utilisation profile of the last FLAG_COUNTERS launch: section -> (executions, lanes)."""
         raw = (C.c_uint64 * 32)()
         _lib.check(self._lib.brt_debug_profile(self._ctx, raw), self._ctx)
-        names = ["interior", "leaf", "camera", "scatter", "sky", "sec5", "sec6", "round"]
+        names = ["interior", "leaf", "camera", "scatter", "sky", "ball", "sec6", "round"]
         return {n: (int(raw[8 + 2 * k]), int(raw[9 + 2 * k])) for k, n in enumerate(names)}
 
     def debug_eval(self, op: int, inputs: np.ndarray) -> np.ndarray:
