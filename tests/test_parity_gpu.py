@@ -207,6 +207,40 @@ def test_stack_overflow_rule(plugin, oracle):
             assert not np.array_equal(got, want_flat)   # the overflow is visible
 
 
+def test_near_far_read_offsets_and_their_repair(plugin, oracle):
+    """The slab test reads {near, far} planes by the sign of the ray direction (brt_layout.h); rays with
+    a zero direction component (1/d infinite, 0 * inf = NaN on a slab plane) and boxes that are not
+    finite or not ordered must take the min/max repair loop and still match raytrace.wgsl:387-398."""
+    spheres = [((0.0, 0.0, -5.0), 0.5, brt.StandardMaterial(base_color=(0.8, 0.3, 0.3), perceptual_roughness=0.0)),
+               ((0.25, 0.25, -8.0), 1.0, brt.StandardMaterial(metallic=1.0, perceptual_roughness=0.3)),
+               ((-0.5, 0.1, -3.0), 0.25, brt.StandardMaterial(specular_transmission=1.0, ior=1.5)),
+               ((0.0, -100.5, -5.0), 100.0, brt.StandardMaterial(base_color=(0.5, 0.5, 0.5)))]
+    b = make_buffers(spheres, lambda m: median_split_bvh(m, 1))
+    # every primary ray parallel to -Z: `up` parallel to the view direction makes `right` the zero vector and
+    # the image-plane offsets multiples of (0, 0, -1); the camera x sits exactly on a padded slab plane
+    lvl, cam, win = uniforms(24, 24, spp=3, bounces=4, pos=(0.0, 0.0, 0.0), target=(0.0, 0.0, -1.0), fov=0.6, seed=0.5)
+    cam = cam.copy()
+    cam["up"] = (0.0, 0.0, -1.0)
+    plane = np.float32(0.0) - (np.float32(0.5) + np.float32(0.1))      # Model::aabb min.x of the first sphere
+    for x in (0.0, float(plane), -0.5):
+        cam["position"] = (x, 0.0, 0.0)
+        render_both(plugin, oracle, b, lvl, cam, win, 24, 24)
+    # boxes the reference never validates: swapped bounds, infinite bounds, a NaN bound
+    lvl, cam, win = uniforms(40, 24, spp=3, bounces=5, pos=(0.3, 0.4, 1.0), target=(0.0, 0.0, -5.0), fov=0.7, seed=0.25)
+    for victim, edit in ((1, "swap"), (2, "inf"), (3, "nan"), (4, "swap")):
+        bvh = median_split_bvh(b.models, 1).copy()
+        victim = min(victim, len(bvh) - 1)
+        if edit == "swap":
+            lo, hi = bvh[victim]["bounds_min"].copy(), bvh[victim]["bounds_max"].copy()
+            bvh[victim]["bounds_min"][0], bvh[victim]["bounds_max"][0] = hi[0], lo[0]
+        elif edit == "inf":
+            bvh[victim]["bounds_min"] = (-np.inf, -np.inf, -np.inf)
+            bvh[victim]["bounds_max"] = (np.inf, np.inf, np.inf)
+        else:
+            bvh[victim]["bounds_min"][1] = np.nan
+        render_both(plugin, oracle, brt.Buffers(b.models, b.materials, bvh), lvl, cam, win, 40, 24)
+
+
 def test_analytic_cases(plugin, oracle):
     b = make_buffers([((0, 0, 50), 0.5, brt.StandardMaterial())], single_leaf_bvh)
     lvl, cam, win = uniforms(16, 9, spp=2, bounces=3, pos=(0, 0, 0), target=(0, 0, -1), fov=0.8, seed=0.0)
