@@ -163,6 +163,9 @@ int32_t make_frame_params(brt_ctx* ctx, const void* camera80, const void* window
     if (fp.walk_exit_lanes > 63u) fp.walk_exit_lanes = 63u;
     fp.leaf_vote = env_u32("BRT_LEAF_VOTE", 8);
     if (fp.leaf_vote > 64u) fp.leaf_vote = 64u;
+    fp.drain_donate = env_u32("BRT_DRAIN_DONATE", 24);
+    if (fp.drain_donate > 48u) fp.drain_donate = 48u;
+    fp.pool_cap = 0;               // set by launch_part from the launch plan
     *out = fp;
     return BRT_OK;
 }
@@ -170,6 +173,7 @@ int32_t make_frame_params(brt_ctx* ctx, const void* camera80, const void* window
 struct LaunchPlan {
     bool lds_scene;
     uint32_t block, grid, wg_per_cu;
+    uint32_t pool_cap;           // records of the drain pool per workgroup (0: none)
     size_t lds_bytes;
 };
 
@@ -186,25 +190,32 @@ LaunchPlan plan_launch(const DeviceCtx& dc, const FrameParams& fp) {
     const uint32_t wg_env = env_u32("BRT_WG_PER_CU", 0);
     const uint32_t max_waves_cu = 32;
     lp.lds_scene = false;
+    // drain pool: every wave but one may hand over up to drain_donate paths
+    auto pool_of = [&](uint32_t block) { return fp.drain_donate * (block / 64u - 1u); };
     if (!force_global && dc.view.desc16) {
         struct Cand { uint32_t block, per_cu; };
         const Cand cands[] = {{1024, 1}, {512, 2}, {512, 3}, {1024, 2}, {512, 1}, {256, 1}};
-        for (const Cand& c : cands) {
-            if (block_env && c.block != block_env) continue;
-            if (wg_env && c.per_cu != wg_env) continue;
-            const size_t need = trace_lds_bytes(dc.view, true, c.block);
-            if (need * c.per_cu <= dc.max_lds && c.per_cu * (c.block / 64) <= max_waves_cu) {
-                lp.lds_scene = true;
-                lp.block = c.block;
-                lp.wg_per_cu = c.per_cu;
-                lp.lds_bytes = need;
-                break;
+        for (int with_pool = 1; with_pool >= 0 && !lp.lds_scene; with_pool--) {
+            for (const Cand& c : cands) {
+                if (block_env && c.block != block_env) continue;
+                if (wg_env && c.per_cu != wg_env) continue;
+                const uint32_t pool = with_pool ? pool_of(c.block) : 0u;
+                const size_t need = trace_lds_bytes(dc.view, true, c.block, pool);
+                if (need * c.per_cu <= dc.max_lds && c.per_cu * (c.block / 64) <= max_waves_cu) {
+                    lp.lds_scene = true;
+                    lp.block = c.block;
+                    lp.wg_per_cu = c.per_cu;
+                    lp.lds_bytes = need;
+                    lp.pool_cap = pool;
+                    break;
+                }
             }
         }
     }
     if (!lp.lds_scene) {
         lp.block = block_env ? block_env : 256u;
-        lp.lds_bytes = trace_lds_bytes(dc.view, false, lp.block);
+        lp.pool_cap = pool_of(lp.block);
+        lp.lds_bytes = trace_lds_bytes(dc.view, false, lp.block, lp.pool_cap);
         uint32_t per_cu = (uint32_t)(dc.max_lds / (lp.lds_bytes ? lp.lds_bytes : 1));
         const uint32_t by_waves = max_waves_cu / (lp.block / 64u);
         if (per_cu > by_waves) per_cu = by_waves;
@@ -327,6 +338,7 @@ int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const fl
             tl.grid = lp.grid;
             tl.block = lp.block;
             tl.lds_bytes = lp.lds_bytes;
+            tl.frame.pool_cap = lp.pool_cap;
             HIP_TRY(ctx, launch_trace_persistent(tl));
         }
     }

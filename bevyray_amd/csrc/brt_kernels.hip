@@ -135,6 +135,28 @@ BRT_DEV bool shade_segment(const ScenePtrs& sc, const FrameParams& fp, f3& o, f3
     return ended;
 }
 
+// ---- drain pool ------------------------------------------------------------------------------
+// When the pixel queue is empty a wave's lanes run out of pixels one by one, but a round costs the
+// wave the same instructions with 5 live lanes as with 60: on the cover frame 18 % of all rounds were
+// executed in that phase with 22 live lanes on average.  So the waves of a workgroup CONSOLIDATE:
+// a wave that is down to `drain_donate` live paths finishes the walks in flight, writes its paths
+// (pixel state + next ray segment, 23 words) to a pool in LDS and ends; waves with idle lanes take
+// them over and continue them.  A path is the same sequence of operations whichever lane runs it, so
+// pixels and counters do not change.
+// Control words {lock, count, alive waves}; all three only change under the lock.  Invariants: the
+// last alive wave never donates, and a wave only leaves when the pool is empty -- so every pooled
+// path is picked up.  The lock holder runs straight-line code (no waiting inside).
+BRT_DEV void pool_lock(uint32_t* ctl, uint32_t lane) {
+    if (lane == 0)
+        while (atomicCAS(&ctl[0], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+BRT_DEV void pool_unlock(uint32_t* ctl, uint32_t lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) atomicExch(&ctl[0], 0u);
+}
+BRT_DEV uint32_t pool_peek(const uint32_t* ctl, int i) { return __atomic_load_n(&ctl[i], __ATOMIC_RELAXED); }
+
 // ---- persistent kernel -----------------------------------------------------------------------
 
 // LDS_SCENE: pair records, spheres and material ids live in LDS (descriptors are then always
@@ -173,7 +195,6 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         for (uint32_t i = threadIdx.x; i < sv.n_leaf_table; i += blockDim.x) l_lt[i] = g_lt[i];
         sc.pairs = reinterpret_cast<const char*>(l_pairs);
         sc.spheres = l_sp; sc.sphere_material = l_sm; sc.leaf_table = l_lt;
-        __syncthreads();
     } else {
         sc.pairs = reinterpret_cast<const char*>(sv.pairs);
         sc.spheres = reinterpret_cast<const float4*>(sv.spheres);
@@ -183,7 +204,20 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     }
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t n_waves = blockDim.x >> 6;
     StackT* stk = stacks + wave * ((sv.stack_entries + 2u) * 64u) + lane;   // + 2: DONE sentinel (entry 0) and one spare entry
+    // drain pool behind the stacks (same sum as trace_lds_bytes): 4 control words, then the records
+    uint32_t* pool_ctl = nullptr;
+    float4* pool = nullptr;
+    if (fp.pool_cap != 0u) {
+        char* const lds = reinterpret_cast<char*>(smem);
+        uint32_t off = (uint32_t)(reinterpret_cast<char*>(stacks + n_waves * ((sv.stack_entries + 2u) * 64u)) - lds);
+        off = (off + 15u) & ~15u;
+        pool_ctl = reinterpret_cast<uint32_t*>(lds + off);
+        pool = reinterpret_cast<float4*>(lds + off + 16u);
+        if (threadIdx.x == 0) { pool_ctl[0] = 0u; pool_ctl[1] = 0u; pool_ctl[2] = n_waves; pool_ctl[3] = 0u; }
+    }
+    if (LDS_SCENE || fp.pool_cap != 0u) __syncthreads();
 
     PixelState ps;
     ps.sample = 0; ps.rng = 0; ps.out_index = 0; ps.frame_index = 0; ps.tile = 0; ps.rays_begin = 0;
@@ -199,6 +233,10 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     walk.px = walk.py = walk.pz = sc.pairs;
     uint32_t n_rays = 0;
     HitCounters hc = {};
+    // COUNTERS build: when this wave started, when it first found the pixel queue empty, when it ended
+    // (100 MHz wall clock; read by brt_debug_profile as words 24..29)
+    unsigned long long t_start = 0, t_empty = 0, drain_lane_rounds = 0;
+    if (COUNTERS) t_start = wall_clock64();
 
     for (;;) {
         // ---- refill empty lanes from the pixel queue (wave-aggregated) ----
@@ -217,6 +255,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                 const uint32_t q = base + mbcnt64(m);
                 if (q >= fp.queue_size) {
                     exhausted = true;
+                    if (COUNTERS && t_empty == 0) t_empty = wall_clock64();
                 } else {
                     const PixelCoord c = slot_to_pixel(fp, q);
                     if (c.inside) {
@@ -233,9 +272,65 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                 }
             }
         }
-        if (__ballot(active) == 0) break;
+        // ---- drain: hand the paths over / take paths over / leave (see "drain pool" above) ----
+        bool finish_walks = false;    // this round runs every walk to its end so that the wave can hand over next round
+        if (fp.pool_cap != 0u && __ballot(exhausted) != 0ull) {
+            const uint64_t am = __ballot(active);
+            const uint32_t live = (uint32_t)__popcll(am);
+            const bool quiet = __ballot(in_flight) == 0ull;              // no suspended walk: every live path is between two rays
+            const bool thin = live != 0u && live <= fp.drain_donate;
+            bool leave = false;
+            if (live == 0u || (thin && quiet && pool_peek(pool_ctl, 2) > 1u) || (live <= 56u && pool_peek(pool_ctl, 1) != 0u)) {
+                pool_lock(pool_ctl, lane);
+                const uint32_t count = pool_peek(pool_ctl, 1), alive = pool_peek(pool_ctl, 2);
+                if (thin && quiet && alive > 1u && count + live <= fp.pool_cap) {
+                    // hand over: live lane r writes record count + r
+                    if (active) {
+                        float4* rec = pool + 6u * (count + mbcnt64(am));
+                        rec[0] = make_float4(ps.ndc0x, ps.ndc0y, ps.sum.x, ps.sum.y);
+                        rec[1] = make_float4(ps.sum.z, ps.dsum, __uint_as_float(ps.rng), __uint_as_float(ps.sample));
+                        rec[2] = make_float4(__uint_as_float(ps.out_index), __uint_as_float(ps.frame_index), __uint_as_float(ps.tile),
+                                             __uint_as_float(n_rays - ps.rays_begin));
+                        rec[3] = make_float4(o.x, o.y, o.z, d.x);
+                        rec[4] = make_float4(d.y, d.z, tput.x, tput.y);
+                        rec[5] = make_float4(tput.z, __uint_as_float(bounce), first_depth, 0.0f);
+                        active = false;
+                    }
+                    if (lane == 0) { pool_ctl[1] = count + live; pool_ctl[2] = alive - 1u; }
+                    leave = true;
+                } else if (count != 0u && live < 64u) {
+                    // take over: idle lane r of k takes record count - k + r
+                    const uint64_t im = ~am;
+                    const uint32_t idle = 64u - live;
+                    const uint32_t k = idle < count ? idle : count;
+                    const uint32_t r = mbcnt64(im);
+                    if (!active && r < k) {
+                        const float4* rec = pool + 6u * (count - k + r);
+                        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5];
+                        ps.ndc0x = r0.x; ps.ndc0y = r0.y; ps.sum = mk3(r0.z, r0.w, r1.x); ps.dsum = r1.y;
+                        ps.rng = __float_as_uint(r1.z); ps.sample = __float_as_uint(r1.w);
+                        ps.out_index = __float_as_uint(r2.x); ps.frame_index = __float_as_uint(r2.y); ps.tile = __float_as_uint(r2.z);
+                        ps.rays_begin = n_rays - __float_as_uint(r2.w);
+                        o = mk3(r3.x, r3.y, r3.z); d = mk3(r3.w, r4.x, r4.y); tput = mk3(r4.z, r4.w, r5.x);
+                        bounce = __float_as_uint(r5.y); first_depth = r5.z;
+                        active = true; in_flight = false; exhausted = true;
+                    }
+                    if (lane == 0) pool_ctl[1] = count - k;
+                } else if (live == 0u && count == 0u) {
+                    if (lane == 0) pool_ctl[2] = alive - 1u;
+                    leave = true;
+                }
+                pool_unlock(pool_ctl, lane);
+            }
+            if (leave) break;
+            finish_walks = (uint32_t)__popcll(__ballot(active)) <= fp.drain_donate;
+        } else if (__ballot(active) == 0) {
+            break;
+        }
+        if (__ballot(active) == 0) continue;      // (pool on) nothing live but paths may still arrive
 
         prof_section<COUNTERS>(hc, SEC_ROUND, active);
+        if (COUNTERS && __ballot(exhausted) != 0ull) drain_lane_rounds += (unsigned long long)__popcll(__ballot(active)) | (1ull << 32);
         const bool fresh = active && !in_flight;       // starts a ray segment in this round
         prof_section<COUNTERS>(hc, SEC_CAMERA, fresh && bounce == 0);
         if (fresh && bounce == 0) {
@@ -246,7 +341,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             first_depth = kInf;
         }
         if (fresh) walk_begin<D16>(walk, sc, sv.root_desc, stk, d);
-        if (active) walk_run<64, COUNTERS, D16, SIMPLE>(sc, walk, stk, o, d, fp.walk_exit_lanes, fp.leaf_vote, hc);
+        if (active) walk_run<64, COUNTERS, D16, SIMPLE>(sc, walk, stk, o, d, finish_walks ? 0u : fp.walk_exit_lanes, fp.leaf_vote, hc);
         in_flight = active && walk_pending<D16, SIMPLE>(walk);
         const bool landed = active && !in_flight;      // walk finished: shade this segment now
         const float t = walk.closest;
@@ -279,6 +374,22 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             atomicAdd(&counters[1], (unsigned long long)a);
             atomicAdd(&counters[2], (unsigned long long)b);
             atomicAdd(&counters[3], (unsigned long long)c);
+        }
+    }
+    if (COUNTERS) {
+        const unsigned long long t_end = wall_clock64();
+        unsigned long long te = 0;   // earliest "queue empty" seen by a lane of this wave
+        for (int l = 0; l < 64; l++) {
+            const unsigned long long v = __shfl(t_empty, l, 64);
+            if (v != 0 && (te == 0 || v < te)) te = v;
+        }
+        if (lane == 0) {
+            atomicMax(&counters[24], ~t_start);                 // min start
+            if (te) { atomicMax(&counters[25], ~te); atomicMax(&counters[26], te); atomicAdd(&counters[28], t_end - te); }
+            atomicMax(&counters[27], t_end);
+            atomicAdd(&counters[29], 1ull);
+            atomicAdd(&counters[30], drain_lane_rounds & 0xffffffffull);   // live lanes summed over the rounds after "empty"
+            atomicAdd(&counters[31], drain_lane_rounds >> 32);              // those rounds
         }
     }
     if (COUNTERS) {
@@ -421,14 +532,16 @@ __global__ void k_debug_eval(uint32_t op, const float* __restrict__ in, float* _
 
 // ---- host-callable launchers ----------------------------------------------------------------------
 
-size_t trace_lds_bytes(const DeviceSceneView& sv, bool lds_scene, uint32_t block) {
+size_t trace_lds_bytes(const DeviceSceneView& sv, bool lds_scene, uint32_t block, uint32_t pool_cap) {
     size_t bytes = 0;
     if (lds_scene) {
         bytes += pair_array_bytes(sv.n_pairs) + (size_t)sv.n_models * 16;
         bytes += (size_t)sv.n_leaf_table * 8 + (size_t)sv.n_models * 4;
     }
     bytes += (size_t)(block / 64) * (sv.stack_entries + 2) * 64 * (sv.desc16 ? 2 : 4);   // + 2: DONE sentinel, one spare entry
-    return (bytes + 15) & ~(size_t)15;
+    bytes = (bytes + 15) & ~(size_t)15;
+    if (pool_cap) bytes += 16 + (size_t)pool_cap * POOL_RECORD_BYTES;                    // drain pool: control words + records
+    return bytes;
 }
 
 template <bool L, bool D, bool S, bool C>

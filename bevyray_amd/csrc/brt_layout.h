@@ -161,6 +161,9 @@ struct FrameParams {
     uint32_t refill_min;             // lanes that must be free before a wave takes new pixels (1..64)
     uint32_t walk_exit_lanes;        // a wave leaves the walk loop when <= this many lanes still walk (0: never)
     uint32_t leaf_vote;              // lanes that must wait at a leaf before the wave runs the leaf body (0/1: always)
+    // Drain (pixel queue empty): a wave with <= drain_donate live paths hands them to the workgroup's LDS pool
+    // (pool_cap records) and ends; waves with idle lanes take them over.  pool_cap == 0: off.
+    uint32_t drain_donate, pool_cap;
     // Longest-first dispatch: tile_order[k] = k-th tile to hand out (tiles sorted by the ray count
     // they needed in the previous frame of the same view), tile_cost[tile] += rays of each finished
     // pixel (this frame's measurement for the next one).  Either may be null.

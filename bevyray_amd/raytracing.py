@@ -286,7 +286,21 @@ class RaytracePlugin:
         raw = (C.c_uint64 * 32)()
         _lib.check(self._lib.brt_debug_profile(self._ctx, raw), self._ctx)
         names = ["interior", "leaf", "camera", "scatter", "sky", "ball", "sec6", "round"]
-        return {n: (int(raw[8 + 2 * k]), int(raw[9 + 2 * k])) for k, n in enumerate(names)}
+        prof = {n: (int(raw[8 + 2 * k]), int(raw[9 + 2 * k])) for k, n in enumerate(names)}
+        # wave time stamps (100 MHz wall clock): first start, first / last "pixel queue empty", last end
+        t0 = (~int(raw[24])) & (2**64 - 1)
+        if raw[29]:
+            first_empty = ((~int(raw[25])) & (2**64 - 1)) if raw[25] else 0
+            self.last_timeline = {
+                "waves": int(raw[29]),
+                "first_empty_ms": (first_empty - t0) / 1e5 if first_empty else None,
+                "last_empty_ms": (int(raw[26]) - t0) / 1e5 if raw[26] else None,
+                "end_ms": (int(raw[27]) - t0) / 1e5,
+                "mean_wave_drain_ms": int(raw[28]) / 1e5 / int(raw[29]),
+                "drain_rounds": int(raw[31]),
+                "drain_live_lanes_per_round": int(raw[30]) / max(1, int(raw[31])),
+            }
+        return prof
 
     def debug_eval(self, op: int, inputs: np.ndarray) -> np.ndarray:
         inputs = np.ascontiguousarray(inputs, np.float32)

@@ -28,6 +28,7 @@ with brt.RaytracePlugin([0]) as p:
     p.node.run(lvl, cam, win, a.w, a.h, flags=1)
     print({k: v for k, v in p.node.last_stats.items()})
     prof = p.debug_profile()
+    print("   timeline", getattr(p, "last_timeline", None))
     for k, (ex, ln) in prof.items():
         if ex:
             print(f"   section {k:9s} executions {ex:12d}  lanes {ln:14d}  avg lanes/exec {ln/ex:6.2f}")
