@@ -237,17 +237,25 @@ bool is_pinned(const brt_ctx* ctx, const void* p, size_t bytes) {
     return false;
 }
 
-// Expensive-tiles-first dispatch.  A pixel is one sequential chain of samples, so a frame ends
-// when its slowest pixels end: a tile that needs many rays must not be handed out late.  The cost
-// of a tile is not known in advance, but a renderer draws nearly the same frame again and again:
-// the kernel measures the rays each tile needed (one atomic per finished pixel, every
-// kLptRefresh-th frame of a view) and the next frames hand out the most expensive tenth of the
-// tiles first, the rest in raster order.  (A FULLY sorted order is slower: every wave then runs
-// the same phase at the same time -- all heavy tiles, later all sky -- which costs 11 % more wave
-// cycles at equal instruction count; raster order mixes phases.  A sorted cheap tail hurts too.)
-// Measured on MI355X, cover scene, one rank's share of the frame: 1/1 27.4 -> 27.1 ms,
-// 1/2 16.2 -> 14.2 ms, 1/4 11.9 -> 10.3 ms.  Pixels never change, only the queue order does.
-// BRT_LPT=0 disables; BRT_LPT_HEAD_PERMILLE sets the head size (default 100).
+// Dispatch order of the 8x8 tiles.  A pixel is one sequential chain of samples (the reference threads
+// one RNG state through them), so (1) a frame ends when its slowest pixels end -- a tile that needs
+// many rays must not be handed out late -- and (2) a lane that takes a one-ray-per-sample "sky" pixel
+// while its wave-mates walk the scene pays their round time for each of its samples.  The cost of a
+// tile is not known in advance, but a renderer draws nearly the same frame again and again: the kernel
+// measures the rays each tile needed (one atomic per finished pixel, every kLptRefresh-th frame of a
+// view) and the next frames hand out
+//   first   the sky tiles, in raster order: whole waves of them, each done in 64 short rounds
+//           (cover frame 18.9 -> 18.4 ms);
+//   then    the most expensive tenth of the other tiles, by cost (one rank's share of the frame:
+//           1/2 16.2 -> 14.2 ms, 1/4 11.9 -> 10.3 ms);
+//   then    the rest in raster order.
+// Measured and rejected: a FULLY sorted order -- the waves of a SIMD then run the same phase at the same
+// time (all in the walk, then all in the shading code) and compete for the same issue ports: +6..11 %
+// time at equal instruction counts; raster order lets them drift apart.  The cheapest tiles LAST: they
+// are dropped into waves that still carry expensive pixels (+1..3 ms).
+// Pixels never change, only the queue order does.
+// BRT_LPT=0 disables; BRT_LPT_HEAD_PERMILLE sets the head size (default 100); BRT_LPT_SKY_FIRST=0
+// keeps the sky tiles in the raster part.
 constexpr uint32_t kLptRefresh = 16;
 bool lpt_enabled() { return env_u32("BRT_LPT", 1) != 0; }
 
@@ -283,21 +291,30 @@ int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hi
     dc.h_cost.resize(n_tiles);
     HIP_TRY(ctx, hipMemcpyAsync(dc.h_cost.data(), dc.d_tile_cost, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));
-    uint32_t head = (uint32_t)((uint64_t)n_tiles * env_u32("BRT_LPT_HEAD_PERMILLE", 100) / 1000u);
-    if (head > n_tiles) head = n_tiles;
-    dc.h_keys.resize(n_tiles);
-    for (uint32_t i = 0; i < n_tiles; i++) dc.h_keys[i] = ((uint64_t)(~dc.h_cost[i]) << 32) | i;   // cost descending, index ascending
+    // order: "sky" tiles (at most ~one ray per sample: every path left the scene at once) in raster order,
+    // then the most expensive tenth of the others by cost, then the rest in raster order
+    const uint32_t sky_first = env_u32("BRT_LPT_SKY_FIRST", 1);
+    const uint64_t sky_cost = (uint64_t)64 * fp.sample_count * (1000 + env_u32("BRT_LPT_SKY_SLACK", 20)) / 1000;
+    dc.h_order.resize(n_tiles);
+    std::vector<uint8_t> where(n_tiles, 0);                                    // 0 middle, 1 head, 2 sky
+    uint32_t k = 0;
+    if (sky_first)
+        for (uint32_t tile = 0; tile < n_tiles; tile++)
+            if (dc.h_cost[tile] <= sky_cost) { where[tile] = 2; dc.h_order[k++] = tile; }
+    dc.h_keys.clear();
+    for (uint32_t i = 0; i < n_tiles; i++)
+        if (where[i] == 0) dc.h_keys.push_back(((uint64_t)(~dc.h_cost[i]) << 32) | i);   // cost descending, index ascending
+    uint32_t head = (uint32_t)((uint64_t)dc.h_keys.size() * env_u32("BRT_LPT_HEAD_PERMILLE", 100) / 1000u);
+    if (head > dc.h_keys.size()) head = (uint32_t)dc.h_keys.size();
     std::nth_element(dc.h_keys.begin(), dc.h_keys.begin() + head, dc.h_keys.end());
     std::sort(dc.h_keys.begin(), dc.h_keys.begin() + head);                    // head: most expensive first
-    dc.h_order.resize(n_tiles);
-    std::vector<uint8_t> in_head(n_tiles, 0);
     for (uint32_t i = 0; i < head; i++) {
-        dc.h_order[i] = (uint32_t)(dc.h_keys[i] & 0xffffffffu);
-        in_head[dc.h_order[i]] = 1;
+        const uint32_t t = (uint32_t)(dc.h_keys[i] & 0xffffffffu);
+        dc.h_order[k++] = t;
+        where[t] = 1;
     }
-    uint32_t k = head;
     for (uint32_t tile = 0; tile < n_tiles; tile++)                            // the rest: raster order
-        if (!in_head[tile]) dc.h_order[k++] = tile;
+        if (where[tile] == 0) dc.h_order[k++] = tile;
     int32_t rc = ensure(ctx, &dc.d_tile_order, &dc.tile_order_cap, (size_t)n_tiles * 4);
     if (rc != BRT_OK) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(dc.d_tile_order, dc.h_order.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, stream));
