@@ -117,7 +117,7 @@ BRT_DEV float float_below(float closest) { return __uint_as_float(__float_as_uin
 // Scene accessors.  The persistent kernel instantiates with LDS pointers, the bring-up
 // kernel and the large-scene variant with global pointers.
 struct ScenePtrs {
-    const char* pairs;       // pair records of PAIR_BYTES (brt_layout.h): near/far planes by read offset, descriptors
+    const char* pairs;       // pair records of PAIR_BYTES (brt_layout.h): near/far planes by granule, descriptors
     bool boxes_ordered;      // every child box finite with min <= max (decided at upload)
     const float4* spheres;
     const uint32_t* sphere_material;
@@ -178,8 +178,8 @@ struct WalkState {
     uint32_t cur;            // DONE when the walk has ended
     StackT* sp;
     uint32_t n;              // entries in use (overflow rule of general trees only)
-    // record base + the read offset this ray's direction selects on each axis (brt_layout.h): offset 8
-    // reads {min, max} = {near, far} for a direction >= 0, offset 0 reads {max, min} for a direction < 0
+    // record base + the granule this ray's direction selects on each axis (brt_layout.h): G0 reads
+    // {min, max} = {near, far} for a direction >= 0, G1 reads {max, min} for a direction < 0
     const char *px, *py, *pz;
 };
 
@@ -187,9 +187,9 @@ template <bool D16, typename StackT>
 BRT_DEV void walk_begin(WalkState<StackT>& w, const ScenePtrs& sc, uint32_t root_desc, StackT* stk, f3 d) {
     w.a = dot3(d, d);
     w.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    w.px = sc.pairs + PAIR_X + (w.inv.x < 0.0f ? 0u : 8u);
-    w.py = sc.pairs + PAIR_Y + (w.inv.y < 0.0f ? 0u : 8u);
-    w.pz = sc.pairs + PAIR_Z + (w.inv.z < 0.0f ? 0u : 8u);
+    w.px = sc.pairs + PAIR_X + (w.inv.x < 0.0f ? 16u : 0u);
+    w.py = sc.pairs + PAIR_Y + (w.inv.y < 0.0f ? 16u : 0u);
+    w.pz = sc.pairs + PAIR_Z + (w.inv.z < 0.0f ? 16u : 0u);
     w.closest = kInf;
     w.closest_idx = 0xffffffffu;
     w.cur = root_desc;
@@ -250,22 +250,22 @@ BRT_DEV bool ray_is_safe(f3 o, f3 inv) {
 // of the wave is not safe or the boxes are not ordered); without it the read offset has already made
 // that choice.
 template <int STRIDE, bool COUNTERS, bool FIX, typename StackT>
-BRT_DEV void walk_interior_step(f3 o, f3 inv, const char* px, const char* py, const char* pz, float below,
+BRT_DEV void walk_interior_step(const char* pairs, f3 o, f3 inv, const char* px, const char* py, const char* pz, float below,
                                 uint32_t& cur, StackT*& sp, uint32_t& n, HitCounters& hc) {
     if (COUNTERS) { hc.node_pops++; hc.interior++; }
     if (STRIDE == 64) prof_section<COUNTERS>(hc, SEC_INTERIOR, true);
-    const uint32_t ro = cur << 3;           // interior descriptor = record offset in 8-byte units
-    float2 nx = *reinterpret_cast<const float2*>(px + ro), fx = *reinterpret_cast<const float2*>(px + ro + 8);
-    const uint2 D = *reinterpret_cast<const uint2*>(px + ro + PAIR_DESC);
-    float2 ny = *reinterpret_cast<const float2*>(py + ro), fy = *reinterpret_cast<const float2*>(py + ro + 8);
-    float2 nz = *reinterpret_cast<const float2*>(pz + ro), fz = *reinterpret_cast<const float2*>(pz + ro + 8);
+    const uint32_t ro = cur << 4;           // interior descriptor = record offset in 16-byte units
+    const float4 gx = *reinterpret_cast<const float4*>(px + ro);   // { near L, near R, far L, far R } on x
+    const float4 gy = *reinterpret_cast<const float4*>(py + ro);
+    const float4 gz = *reinterpret_cast<const float4*>(pz + ro);
+    const uint2 D = *reinterpret_cast<const uint2*>(pairs + ro + PAIR_DESC);
     // the would-be pop, issued with the node reads so that its LDS latency hides behind the slab
     // arithmetic; the store below goes to the entry above it, never to it
     const uint32_t popped = (uint32_t)(int32_t)*sp;
     // .x = child L (`index`), .y = child R (`index + 1`); (b - o) * (1/d) as in raytrace.wgsl:388-390
-    float nLx = (nx.x - o.x) * inv.x, fLx = (fx.x - o.x) * inv.x, nRx = (nx.y - o.x) * inv.x, fRx = (fx.y - o.x) * inv.x;
-    float nLy = (ny.x - o.y) * inv.y, fLy = (fy.x - o.y) * inv.y, nRy = (ny.y - o.y) * inv.y, fRy = (fy.y - o.y) * inv.y;
-    float nLz = (nz.x - o.z) * inv.z, fLz = (fz.x - o.z) * inv.z, nRz = (nz.y - o.z) * inv.z, fRz = (fz.y - o.z) * inv.z;
+    float nLx = (gx.x - o.x) * inv.x, nRx = (gx.y - o.x) * inv.x, fLx = (gx.z - o.x) * inv.x, fRx = (gx.w - o.x) * inv.x;
+    float nLy = (gy.x - o.y) * inv.y, nRy = (gy.y - o.y) * inv.y, fLy = (gy.z - o.y) * inv.y, fRy = (gy.w - o.y) * inv.y;
+    float nLz = (gz.x - o.z) * inv.z, nRz = (gz.y - o.z) * inv.z, fLz = (gz.z - o.z) * inv.z, fRz = (gz.w - o.z) * inv.z;
     if (FIX) {
         float t;
         t = min_f(nLx, fLx); fLx = max_f(nLx, fLx); nLx = t;
@@ -313,7 +313,7 @@ BRT_DEV void walk_loop_wave(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, co
         for (;;) {
             const bool interior = DS::is_interior(cur) && (SIMPLE_TREE || n < 31u);
             if (__ballot(interior) == 0ull) break;
-            if (interior) walk_interior_step<64, COUNTERS, FIX>(o, inv, px, py, pz, below, cur, sp, n, hc);
+            if (interior) walk_interior_step<64, COUNTERS, FIX>(sc.pairs, o, inv, px, py, pz, below, cur, sp, n, hc);
             const uint32_t want_leaf = (uint32_t)__popcll(__ballot(DS::is_leaf(cur) && (SIMPLE_TREE || n < 31u)));
             if (want_leaf >= vote) break;
         }
@@ -372,9 +372,9 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, f3
             if (DS::is_leaf(cur))
                 walk_leaf_step<STRIDE, COUNTERS, D16, SIMPLE_TREE>(sc, o, d, a, closest, closest_idx, cur, sp, n, hc);
             else if (unsafe)
-                walk_interior_step<STRIDE, COUNTERS, true>(o, inv, px, py, pz, float_below(closest), cur, sp, n, hc);
+                walk_interior_step<STRIDE, COUNTERS, true>(sc.pairs, o, inv, px, py, pz, float_below(closest), cur, sp, n, hc);
             else
-                walk_interior_step<STRIDE, COUNTERS, false>(o, inv, px, py, pz, float_below(closest), cur, sp, n, hc);
+                walk_interior_step<STRIDE, COUNTERS, false>(sc.pairs, o, inv, px, py, pz, float_below(closest), cur, sp, n, hc);
         }
     }
     w.closest = closest;

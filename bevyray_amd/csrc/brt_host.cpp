@@ -100,7 +100,7 @@ int32_t validate_and_encode(const Model* models, uint32_t n_models, const Materi
     const uint32_t LEAF1 = e.desc16 ? Desc<true>::LEAF1 : Desc<false>::LEAF1;
     auto desc_of = [&](uint32_t n) -> uint32_t {
         const BVHNode& nd = nodes[n];
-        if (nd.model_count == 0) return pair_id[n] * PAIR_UNITS;   // record offset in 8-byte units
+        if (nd.model_count == 0) return pair_id[n] * PAIR_UNITS;   // record offset in 16-byte units
         if (nd.model_count == 1) return LEAF | LEAF1 | nd.index;
         uint32_t id = (uint32_t)(e.leaf_table.size() / 2);
         e.leaf_table.push_back(nd.index);
@@ -118,17 +118,15 @@ int32_t validate_and_encode(const Model* models, uint32_t n_models, const Materi
         float* rec = &e.pairs[(size_t)PAIR_WORDS * i];
         const uint32_t block[3] = {PAIR_X / 4, PAIR_Y / 4, PAIR_Z / 4};
         for (int k = 0; k < 3; k++) {
-            float* a = rec + block[k];
-            a[0] = L.bounds_max[k]; a[1] = R.bounds_max[k];
-            a[2] = L.bounds_min[k]; a[3] = R.bounds_min[k];
-            a[4] = L.bounds_max[k]; a[5] = R.bounds_max[k];
+            float* g = rec + block[k];
+            g[0] = L.bounds_min[k]; g[1] = R.bounds_min[k]; g[2] = L.bounds_max[k]; g[3] = R.bounds_max[k];   // G0
+            g[4] = L.bounds_max[k]; g[5] = R.bounds_max[k]; g[6] = L.bounds_min[k]; g[7] = R.bounds_min[k];   // G1
             for (const BVHNode* c : {&L, &R})
                 if (!(std::isfinite(c->bounds_min[k]) && std::isfinite(c->bounds_max[k]) && c->bounds_min[k] <= c->bounds_max[k]))
                     e.boxes_ordered = false;
         }
-        const uint32_t dl = desc_of(nd.index), dr = desc_of(nd.index + 1);
-        const uint32_t dd[4] = {dl, dr, dl, dr};
-        std::memcpy(rec + 6, dd, sizeof dd);
+        const uint32_t dd[2] = {desc_of(nd.index), desc_of(nd.index + 1)};
+        std::memcpy(rec + PAIR_DESC / 4, dd, sizeof dd);
     }
 
     e.n_models = n_models;

@@ -14,7 +14,7 @@ int32_t fail(int32_t code, const std::string& msg);
 
 // Scene in the device encoding (brt_layout.h), still in host vectors.
 struct EncodedScene {
-    std::vector<float> pairs;            // PAIR_WORDS per pair record, padded to 16 bytes (brt_layout.h)
+    std::vector<float> pairs;            // PAIR_WORDS per pair record (brt_layout.h)
     std::vector<float> spheres;          // 4 per model
     std::vector<uint32_t> sphere_material;
     std::vector<float> materials;        // 8 per material

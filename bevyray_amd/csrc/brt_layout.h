@@ -74,8 +74,8 @@ static_assert(sizeof(Window) == 16 && offsetof(Window, height) == 4, "Window");
 // The push/pop ORDER is the reference's, so results (ties, stack-overflow rule) are the same.
 //
 // Descriptor (32-bit form; scenes too large for LDS):
-//   bit31 = 0                 interior: bits[30:0] = offset of the pair record in 8-byte units (index * 11), so that
-//                             a record address is one shift-add per axis
+//   bit31 = 0                 interior: bits[30:0] = offset of the pair record in 16-byte units (index * 7), so that
+//                             a granule address is one shift-add
 //   bit31 = 1, bit30 = 1      leaf with exactly one sphere: bits[29:0] = model index
 //   bit31 = 1, bit30 = 0      general leaf: bits[29:0] = index into the leaf table {first, count}
 // 16-bit form (every index < 16384, always the case for an LDS-resident scene): the same three
@@ -98,32 +98,35 @@ struct Desc {
 constexpr uint32_t DESC32_MAX_INDEX = 0x3FFFFFFEu;   // largest encodable index (all-ones is DONE)
 constexpr uint32_t DESC16_MAX_INDEX = 0x3FFEu;
 
-// Pair record: 88 bytes (22 words) per interior node, children L = node `index`, R = `index + 1`.
+// Pair record: 112 bytes (28 words) per interior node, children L = node `index`, R = `index + 1`.
 // The slab test needs, per axis, the plane the ray ENTERS through and the plane it LEAVES through;
 // which of {min, max} that is depends only on the sign of the ray direction on that axis.  Each axis
-// block therefore holds   max L R | min L R | max L R   (8 bytes per pair), and a lane reads 16 bytes
-// at offset 8 (direction >= 0: {min, max} = {near, far}) or at offset 0 (direction < 0: {max, min}):
-// the reference's min()/max() per axis (raytrace.wgsl:391-392) become an address chosen once per ray.
-//   word  0.. 5   x block: max.x L R, min.x L R, max.x L R
-//   word  6.. 9   descL descR descL descR  (register form) -- 24 bytes after EITHER read offset of the x block
-//   word 10..15   y block
-//   word 16..21   z block
+// block therefore holds the four bounds twice, as two 16-byte granules
+//   G0 = { min L, min R, max L, max R }      G1 = { max L, max R, min L, min R }
+// and a lane reads ONE granule -- G0 for a direction >= 0, G1 for a direction < 0 -- as
+// { near L, near R, far L, far R }: the reference's min()/max() per axis (raytrace.wgsl:391-392)
+// become an address chosen once per ray, and the read is an aligned ds_read_b128 (4 LDS cycles per
+// wave; two 8-byte reads at an unaligned offset would go through ds_read2_b64 at half the LDS rate).
+//   bytes   0.. 31   x block (G0, G1)
+//   bytes  32.. 63   y block
+//   bytes  64.. 95   z block
+//   bytes  96..103   descL, descR (register form); 104..111 padding
+// The stride of 28 words spreads the granules of different records over 16 bank positions.
 // That choice is exact when the ray is "safe" (origin finite, 1/direction finite and non-zero) and the
 // boxes are finite with min <= max (checked at upload, `boxes_ordered`): then (b - o) * inv is monotone in b
 // and no NaN can arise.  Otherwise the kernels apply min/max to the two values they read, which is the
-// reference's expression whatever the read offset was.
-// The array is padded to a multiple of 16 bytes.
-constexpr uint32_t PAIR_WORDS = 22;
-constexpr uint32_t PAIR_BYTES = 88;
-constexpr uint32_t PAIR_UNITS = PAIR_BYTES / 8;   // an interior descriptor counts records in these units
-constexpr uint32_t PAIR_X = 0, PAIR_DESC = 24, PAIR_Y = 40, PAIR_Z = 64;   // byte offsets (PAIR_DESC relative to the x read address)
-constexpr size_t pair_array_bytes(uint32_t n_pairs) { return ((size_t)n_pairs * PAIR_BYTES + 15) & ~(size_t)15; }
+// reference's expression whichever granule was read.
+constexpr uint32_t PAIR_WORDS = 28;
+constexpr uint32_t PAIR_BYTES = 112;
+constexpr uint32_t PAIR_UNITS = PAIR_BYTES / 16;   // an interior descriptor counts records in 16-byte units
+constexpr uint32_t PAIR_X = 0, PAIR_Y = 32, PAIR_Z = 64, PAIR_DESC = 96;   // byte offsets in a record
+constexpr size_t pair_array_bytes(uint32_t n_pairs) { return (size_t)n_pairs * PAIR_BYTES; }
 // Spheres: { center.x, center.y, center.z, radius*radius } (hit_sphere only uses r*r,
 // raytrace.wgsl:375), material ids in a parallel u32 array.
 // Materials: two float4 per material, as on the wire.
 
 struct DeviceSceneView {
-    const float* pairs;      // n_pairs records of PAIR_BYTES, array padded to 16 bytes
+    const float* pairs;      // n_pairs records of PAIR_BYTES
     const float* spheres;    // float4[n_models]
     const uint32_t* sphere_material;  // u32[n_models]
     const float* materials;  // float4[2*n_materials]
