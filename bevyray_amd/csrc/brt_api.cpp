@@ -163,8 +163,8 @@ int32_t make_frame_params(brt_ctx* ctx, const void* camera80, const void* window
     if (fp.walk_exit_lanes > 63u) fp.walk_exit_lanes = 63u;
     fp.leaf_vote = env_u32("BRT_LEAF_VOTE", 8);
     if (fp.leaf_vote > 64u) fp.leaf_vote = 64u;
-    fp.drain_donate = env_u32("BRT_DRAIN_DONATE", 24);
-    if (fp.drain_donate > 48u) fp.drain_donate = 48u;
+    fp.drain_donate = env_u32("BRT_DRAIN_DONATE", 40);
+    if (fp.drain_donate > 56u) fp.drain_donate = 56u;
     fp.pool_cap = 0;               // set by launch_part from the launch plan
     *out = fp;
     return BRT_OK;
@@ -190,8 +190,14 @@ LaunchPlan plan_launch(const DeviceCtx& dc, const FrameParams& fp) {
     const uint32_t wg_env = env_u32("BRT_WG_PER_CU", 0);
     const uint32_t max_waves_cu = 32;
     lp.lds_scene = false;
-    // drain pool: every wave but one may hand over up to drain_donate paths
-    auto pool_of = [&](uint32_t block) { return fp.drain_donate * (block / 64u - 1u); };
+    // drain pool: every wave but one may hand over up to drain_donate paths, but the takers empty the pool
+    // while the donors fill it: 384 records (36 KB) are enough in practice, and a donation that does not
+    // fit is simply retried a round later
+    const uint32_t pool_max = env_u32("BRT_POOL_CAP", 384);
+    auto pool_of = [&](uint32_t block) {
+        const uint32_t want = fp.drain_donate * (block / 64u - 1u);
+        return want < pool_max ? want : pool_max;
+    };
     if (!force_global && dc.view.desc16) {
         struct Cand { uint32_t block, per_cu; };
         const Cand cands[] = {{1024, 1}, {512, 2}, {512, 3}, {1024, 2}, {512, 1}, {256, 1}};
@@ -246,8 +252,9 @@ bool is_pinned(const brt_ctx* ctx, const void* p, size_t bytes) {
 // view) and the next frames hand out
 //   first   the sky tiles, in raster order: whole waves of them, each done in 64 short rounds
 //           (cover frame 18.9 -> 18.4 ms);
-//   then    the most expensive tenth of the other tiles, by cost (one rank's share of the frame:
-//           1/2 16.2 -> 14.2 ms, 1/4 11.9 -> 10.3 ms);
+//   then    the tenth of the other tiles that hold the longest pixel chains (one rank's share of the
+//           frame: 1/2 16.2 -> 14.2 ms, 1/4 11.9 -> 10.3 ms; ranking by the longest pixel instead of the
+//           tile's ray sum: cover frame 18.2 -> 17.9 ms);
 //   then    the rest in raster order.
 // Measured and rejected: a FULLY sorted order -- the waves of a SIMD then run the same phase at the same
 // time (all in the walk, then all in the shading code) and compete for the same issue ports: +6..11 %
@@ -276,9 +283,9 @@ int32_t attach_tile_order(brt_ctx* ctx, DeviceCtx& dc, FrameParams& fp, hipStrea
     const bool match = dc.order_valid && std::memcmp(key, dc.order_key, sizeof key) == 0;
     if (match) fp.tile_order = dc.d_tile_order;
     if (may_measure && (!match || ++dc.order_age >= kLptRefresh)) {
-        int32_t rc = ensure(ctx, &dc.d_tile_cost, &dc.tile_cost_cap, (size_t)n_tiles * 4);
+        int32_t rc = ensure(ctx, &dc.d_tile_cost, &dc.tile_cost_cap, (size_t)n_tiles * 8);   // sums, then maxima
         if (rc != BRT_OK) return rc;
-        HIP_TRY(ctx, hipMemsetAsync(dc.d_tile_cost, 0, (size_t)n_tiles * 4, stream));
+        HIP_TRY(ctx, hipMemsetAsync(dc.d_tile_cost, 0, (size_t)n_tiles * 8, stream));
         fp.tile_cost = dc.d_tile_cost;
     }
     return BRT_OK;
@@ -288,9 +295,11 @@ int32_t attach_tile_order(brt_ctx* ctx, DeviceCtx& dc, FrameParams& fp, hipStrea
 int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hipStream_t stream) {
     if (!fp.tile_cost) return BRT_OK;
     const uint32_t n_tiles = fp.local_strips * fp.tiles_x;
-    dc.h_cost.resize(n_tiles);
-    HIP_TRY(ctx, hipMemcpyAsync(dc.h_cost.data(), dc.d_tile_cost, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, stream));
+    dc.h_cost.resize(2 * (size_t)n_tiles);
+    HIP_TRY(ctx, hipMemcpyAsync(dc.h_cost.data(), dc.d_tile_cost, (size_t)n_tiles * 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));
+    const uint32_t* h_max = dc.h_cost.data() + n_tiles;            // longest pixel chain of each tile
+    const uint32_t key_kind = env_u32("BRT_LPT_KEY", 1);            // 1: longest pixel of the tile, 0: sum of its rays
     // order: "sky" tiles (at most ~one ray per sample: every path left the scene at once) in raster order,
     // then the most expensive tenth of the others by cost, then the rest in raster order
     const uint32_t sky_first = env_u32("BRT_LPT_SKY_FIRST", 1);
@@ -303,7 +312,7 @@ int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hi
             if (dc.h_cost[tile] <= sky_cost) { where[tile] = 2; dc.h_order[k++] = tile; }
     dc.h_keys.clear();
     for (uint32_t i = 0; i < n_tiles; i++)
-        if (where[i] == 0) dc.h_keys.push_back(((uint64_t)(~dc.h_cost[i]) << 32) | i);   // cost descending, index ascending
+        if (where[i] == 0) dc.h_keys.push_back(((uint64_t)(~(key_kind ? h_max[i] : dc.h_cost[i])) << 32) | i);   // cost descending, index ascending
     uint32_t head = (uint32_t)((uint64_t)dc.h_keys.size() * env_u32("BRT_LPT_HEAD_PERMILLE", 100) / 1000u);
     if (head > dc.h_keys.size()) head = (uint32_t)dc.h_keys.size();
     std::nth_element(dc.h_keys.begin(), dc.h_keys.begin() + head, dc.h_keys.end());

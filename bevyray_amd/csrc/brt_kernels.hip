@@ -358,7 +358,10 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                 bounce = 0;
                 if (ps.sample == fp.sample_count) {
                     pixel_finish(fp, ps, out_tile, raster_rgba, raster_depth);
-                    if (fp.tile_cost) atomicAdd(&fp.tile_cost[ps.tile], n_rays - ps.rays_begin);
+                    if (fp.tile_cost) {
+                        atomicAdd(&fp.tile_cost[ps.tile], n_rays - ps.rays_begin);
+                        atomicMax(&fp.tile_cost[fp.local_strips * fp.tiles_x + ps.tile], n_rays - ps.rays_begin);
+                    }
                     active = false;
                 }
             }

@@ -167,9 +167,9 @@ struct FrameParams {
     // Drain (pixel queue empty): a wave with <= drain_donate live paths hands them to the workgroup's LDS pool
     // (pool_cap records) and ends; waves with idle lanes take them over.  pool_cap == 0: off.
     uint32_t drain_donate, pool_cap;
-    // Longest-first dispatch: tile_order[k] = k-th tile to hand out (tiles sorted by the ray count
-    // they needed in the previous frame of the same view), tile_cost[tile] += rays of each finished
-    // pixel (this frame's measurement for the next one).  Either may be null.
+    // Dispatch order: tile_order[k] = k-th tile to hand out (from the ray counts of the previous frame
+    // of the same view, brt_api.cpp); this frame's measurement for the next one: tile_cost[tile] += rays
+    // of each finished pixel, tile_cost[n_tiles + tile] = max of them.  Either may be null.
     const uint32_t* tile_order;
     uint32_t* tile_cost;
 };
