@@ -46,6 +46,7 @@ struct DeviceCtx {
     uint32_t* d_tile_cost = nullptr;
     size_t tile_cost_cap = 0;
     uint32_t* d_tile_order = nullptr;
+    uint32_t order_first_ranked = 0, order_crit = 0;   // d_tile_order[first_ranked .. +crit) are the CRITICAL tiles
     size_t tile_order_cap = 0;
     bool order_valid = false;
     uint32_t order_age = 0;                       // frames since the costs were last measured
@@ -166,6 +167,7 @@ int32_t make_frame_params(brt_ctx* ctx, const void* camera80, const void* window
     fp.drain_donate = env_u32("BRT_DRAIN_DONATE", 40);
     if (fp.drain_donate > 56u) fp.drain_donate = 56u;
     fp.pool_cap = 0;               // set by launch_part from the launch plan
+    fp.crit_begin = fp.crit_end = 0;   // set by attach_tile_order
     *out = fp;
     return BRT_OK;
 }
@@ -281,7 +283,11 @@ int32_t attach_tile_order(brt_ctx* ctx, DeviceCtx& dc, FrameParams& fp, hipStrea
     uint32_t key[6];
     order_key_of(ctx, fp, key);
     const bool match = dc.order_valid && std::memcmp(key, dc.order_key, sizeof key) == 0;
-    if (match) fp.tile_order = dc.d_tile_order;
+    if (match) {
+        fp.tile_order = dc.d_tile_order;
+        fp.crit_begin = dc.order_first_ranked * 64u;
+        fp.crit_end = fp.crit_begin + dc.order_crit * 64u;
+    }
     if (may_measure && (!match || ++dc.order_age >= kLptRefresh)) {
         int32_t rc = ensure(ctx, &dc.d_tile_cost, &dc.tile_cost_cap, (size_t)n_tiles * 8);   // sums, then maxima
         if (rc != BRT_OK) return rc;
@@ -317,6 +323,21 @@ int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hi
     if (head > dc.h_keys.size()) head = (uint32_t)dc.h_keys.size();
     std::nth_element(dc.h_keys.begin(), dc.h_keys.begin() + head, dc.h_keys.end());
     std::sort(dc.h_keys.begin(), dc.h_keys.begin() + head);                    // head: most expensive first
+    // CRITICAL tiles: a pixel whose chain alone takes half of what a lane works through in the whole frame
+    // (sum of rays / lanes of the grid) bounds the frame time by itself -- RTIOW at 256 spp and 50 bounces has
+    // pixels of > 10 000 sequential rays in a frame of ~5 000 rays per lane.  Waves holding such pixels run at
+    // raised priority and are not refilled (k_trace_persistent).  The cover frame has none (576 < 595).
+    dc.order_first_ranked = k;
+    dc.order_crit = 0;
+    if (key_kind == 1 && env_u32("BRT_CRIT", 1) != 0) {
+        uint64_t sum = 0;
+        uint32_t cmax = 0;
+        for (uint32_t i = 0; i < n_tiles; i++) { sum += dc.h_cost[i]; cmax = h_max[i] > cmax ? h_max[i] : cmax; }
+        const uint64_t per_lane = sum / ((uint64_t)dc.num_cus * BRT_BLOCK);
+        const uint64_t thr = per_lane / 2 > cmax / 2 ? per_lane / 2 : cmax / 2;
+        if (cmax >= per_lane / 2)
+            for (uint32_t i = 0; i < head && h_max[(uint32_t)(dc.h_keys[i] & 0xffffffffu)] >= thr; i++) dc.order_crit++;
+    }
     for (uint32_t i = 0; i < head; i++) {
         const uint32_t t = (uint32_t)(dc.h_keys[i] & 0xffffffffu);
         dc.h_order[k++] = t;

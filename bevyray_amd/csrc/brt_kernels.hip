@@ -227,6 +227,8 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     float first_depth = kInf;
     bool active = false, exhausted = false;
     bool in_flight = false;           // this lane's walk was suspended by walk_run's early exit
+    bool crit = false;                // this lane's pixel is one of the frame's longest chains (FrameParams::crit_*)
+    bool wave_crit = false;
     WalkState<StackT> walk;
     walk.a = 0.0f; walk.inv = mk3(0.0f, 0.0f, 0.0f); walk.closest = kInf; walk.closest_idx = 0xffffffffu;
     walk.cur = Desc<D16>::DONE; walk.sp = stk; walk.n = 0;
@@ -239,9 +241,19 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     if (COUNTERS) t_start = wall_clock64();
 
     for (;;) {
+        // A wave that carries one of the frame's CRITICAL pixels (FrameParams::crit_*) issues ahead of its SIMD
+        // mates and takes no new pixels: its rounds get shorter as its other pixels end, and the frame cannot
+        // end before that chain has.
+        if (fp.crit_end != 0u) {
+            const bool wc = __ballot(active && crit) != 0ull;
+            if (wc != wave_crit) {
+                wave_crit = wc;
+                if (wc) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+            }
+        }
         // ---- refill empty lanes from the pixel queue (wave-aggregated) ----
         for (;;) {
-            const bool need = !active && !exhausted;
+            const bool need = !active && !exhausted && !wave_crit;
             const uint64_t m = __ballot(need);
             if (m == 0) break;
             // keep a wave's pixels of one cost class: take new ones only in batches of refill_min
@@ -260,6 +272,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                     const PixelCoord c = slot_to_pixel(fp, q);
                     if (c.inside) {
                         pixel_begin(fp, c, ps);
+                        crit = q >= fp.crit_begin && q < fp.crit_end;
                         ps.rays_begin = n_rays;
                         if (fp.sample_count == 0) {
                             // 0/0 per channel.  The sums are compile-time zeros here; keep them opaque: hipcc 7.2
@@ -274,7 +287,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         }
         // ---- drain: hand the paths over / take paths over / leave (see "drain pool" above) ----
         bool finish_walks = false;    // this round runs every walk to its end so that the wave can hand over next round
-        if (fp.pool_cap != 0u && __ballot(exhausted) != 0ull) {
+        if (fp.pool_cap != 0u && __ballot(exhausted) != 0ull && !wave_crit) {
             const uint64_t am = __ballot(active);
             const uint32_t live = (uint32_t)__popcll(am);
             const bool quiet = __ballot(in_flight) == 0ull;              // no suspended walk: every live path is between two rays
@@ -293,7 +306,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                                              __uint_as_float(n_rays - ps.rays_begin));
                         rec[3] = make_float4(o.x, o.y, o.z, d.x);
                         rec[4] = make_float4(d.y, d.z, tput.x, tput.y);
-                        rec[5] = make_float4(tput.z, __uint_as_float(bounce), first_depth, 0.0f);
+                        rec[5] = make_float4(tput.z, __uint_as_float(bounce), first_depth, __uint_as_float(crit ? 1u : 0u));
                         active = false;
                     }
                     if (lane == 0) { pool_ctl[1] = count + live; pool_ctl[2] = alive - 1u; }
@@ -312,7 +325,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                         ps.out_index = __float_as_uint(r2.x); ps.frame_index = __float_as_uint(r2.y); ps.tile = __float_as_uint(r2.z);
                         ps.rays_begin = n_rays - __float_as_uint(r2.w);
                         o = mk3(r3.x, r3.y, r3.z); d = mk3(r3.w, r4.x, r4.y); tput = mk3(r4.z, r4.w, r5.x);
-                        bounce = __float_as_uint(r5.y); first_depth = r5.z;
+                        bounce = __float_as_uint(r5.y); first_depth = r5.z; crit = __float_as_uint(r5.w) != 0u;
                         active = true; in_flight = false; exhausted = true;
                     }
                     if (lane == 0) pool_ctl[1] = count - k;

@@ -167,6 +167,10 @@ struct FrameParams {
     // Drain (pixel queue empty): a wave with <= drain_donate live paths hands them to the workgroup's LDS pool
     // (pool_cap records) and ends; waves with idle lanes take them over.  pool_cap == 0: off.
     uint32_t drain_donate, pool_cap;
+    // Queue slots [crit_begin, crit_end) (the tiles with the longest pixel chains, when tile_order is set) are
+    // CRITICAL: a wave that holds one of their pixels raises its issue priority (s_setprio), because the
+    // frame cannot end before its longest sequential chain has.
+    uint32_t crit_begin, crit_end;
     // Dispatch order: tile_order[k] = k-th tile to hand out (from the ray counts of the previous frame
     // of the same view, brt_api.cpp); this frame's measurement for the next one: tile_cost[tile] += rays
     // of each finished pixel, tile_cost[n_tiles + tile] = max of them.  Either may be null.
