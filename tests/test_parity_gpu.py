@@ -429,6 +429,10 @@ def test_sample_count_zero_is_zero_over_zero(plugin, oracle, level):
     {"BRT_WALK_EXIT": "63", "BRT_REFILL_MIN": "9"}, {"BRT_WALK_EXIT": "40", "BRT_FORCE_GLOBAL_SCENE": "1"},
     {"BRT_LEAF_VOTE": "0"}, {"BRT_LEAF_VOTE": "64"}, {"BRT_LEAF_VOTE": "20", "BRT_WALK_EXIT": "0"},
     {"BRT_LEAF_VOTE": "3", "BRT_WALK_EXIT": "30", "BRT_BLOCK_THREADS": "256"},
+    # drain pool: off, eager, tiny pool (donations that do not fit), other workgroup shapes
+    {"BRT_DRAIN_DONATE": "0"}, {"BRT_DRAIN_DONATE": "56"}, {"BRT_DRAIN_DONATE": "8", "BRT_POOL_CAP": "16"},
+    {"BRT_DRAIN_DONATE": "40", "BRT_BLOCK_THREADS": "256"}, {"BRT_DRAIN_DONATE": "33", "BRT_FORCE_GLOBAL_SCENE": "1"},
+    {"BRT_DRAIN_DONATE": "48", "BRT_WALK_EXIT": "0", "BRT_BLOCK_THREADS": "512", "BRT_WG_PER_CU": "2"},
 ])
 def test_tuning_knobs_do_not_change_results(plugin, oracle, env):
     b = brt.generate_scene(brt.SCENE_COVER, 1)
@@ -551,6 +555,21 @@ def test_expensive_first_dispatch_never_changes_pixels(plugin, oracle):
         assert_frames_equal(plugin.node.run(lvl, cam, win, w, h), want)
     finally:
         del os.environ["BRT_LPT"]
+    # the ingredients of the order one by one: ranking key, sky tiles first, critical pixels (waves at raised
+    # priority that stop taking pixels -- on a frame this small nearly every ranked tile is critical)
+    for env in ({"BRT_LPT_KEY": "0"}, {"BRT_LPT_SKY_FIRST": "0"}, {"BRT_CRIT": "0"}, {"BRT_LPT_HEAD_PERMILLE": "1000"},
+                {"BRT_LPT_HEAD_PERMILLE": "1000", "BRT_DRAIN_DONATE": "56"}):
+        os.environ.update(env)
+        try:
+            plugin.node.write_buffers(brt.generate_scene(brt.SCENE_COVER, 5))    # forget the history ...
+            plugin.node.write_buffers(b)
+            for frame_no in range(3):                                              # ... measure, then use the order
+                got = plugin.node.run(lvl, cam, win, w, h, flags=brt.FLAG_COUNTERS)
+                assert_frames_equal(got, want)
+                assert {k: plugin.node.last_stats[k] for k in COUNTER_KEYS} == cnt, (env, frame_no)
+        finally:
+            for k in env:
+                del os.environ[k]
     # another view of the same scene reuses nothing wrongly (different size -> history key mismatch)
     lvl2, cam2, win2 = brt.cover_camera(96, 54, 2, 4)
     want2, _ = oracle.render(b, lvl2, cam2, win2, 96, 54)
