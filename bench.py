@@ -132,6 +132,23 @@ def main():
                     traffic = pmc.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # what actually bounds the kernel: wave-level instruction issue.  Instruction counts per launch from the
+        # committed rocprofv3 --pmc summary of this workload (they do not depend on the clock), time measured live.
+        issue = None
+        sq_path = os.path.join(ROOT, "profiles", "r01", "final_pmc_summary.json")
+        if world == 1 and os.path.exists(sq_path):
+            try:
+                sq = json.load(open(sq_path))["k_trace_persistent (timing build)"]
+                n_inst = sum(sq[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH"))
+                simd_cycles = mean_kernel_ms * 1e-3 * 2.4e9 * 256 * 4
+                issue = {"instructions_per_launch": n_inst, "valu_per_launch": sq["SQ_INSTS_VALU"],
+                         "instructions_per_simd_cycle": n_inst / simd_cycles,
+                         "peak_valu_per_simd_cycle": 0.5,
+                         "active_lanes_per_valu": sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"]
+                         if sq.get("SQ_ACTIVE_INST_VALU") else None,
+                         "source": "profiles/r01/final_pmc_summary.json (rocprofv3 --pmc, separate passes), 2.4 GHz, 1024 SIMDs"}
+            except Exception:
+                issue = None
         out = {
             "metric": "Mrays/s at 1920x1080, 64 spp, 8 bounces", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -148,7 +165,8 @@ def main():
                          "kernel": "k_trace_persistent", "kernel_ms": mean_kernel_ms, "algorithmic_bytes_per_launch": alg,
                          "note": "scene is LDS resident and ray state lives in registers: HBM traffic is the scene load "
                                  "per workgroup + one 16-B store per pixel, the kernel is bound by VALU/scalar issue "
-                                 "under divergence (DESIGN.md section 5), so achieved algorithmic bytes exceed the HBM peak"},
+                                 "under divergence (DESIGN.md section 5), so achieved algorithmic bytes exceed the HBM peak",
+                         "issue": issue},
             "kernel": {"lds_bytes": counted["lds_bytes"], "scene_in_lds": counted["scene_in_lds"],
                        "workgroups": counted["n_workgroups"], "threads": counted["threads_per_workgroup"]},
         }
