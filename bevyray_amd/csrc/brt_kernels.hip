@@ -4,9 +4,9 @@
 // k_trace_persistent  the production kernel: persistent threads, one path per lane.
 //     * One 1024-thread workgroup per CU (16 waves, 4 per SIMD) stays resident for the whole
 //       frame.  When the encoded scene fits, the workgroup first copies pair records, spheres
-//       and material ids into LDS (cover scene: 38 KB; the 32-byte materials stay in global
+//       and material ids into LDS (cover scene: 66 KB; the 32-byte materials stay in global
 //       memory, one read per hit); the per-lane traversal stacks also live in LDS as
-//       [entry][lane] arrays of u16 descriptors (conflict-free: bank = lane).
+//       [entry][lane] arrays of 16-bit descriptors.
 //     * Each lane owns one pixel at a time and walks that pixel's samples and bounces as a
 //       flat state machine, one ray segment per outer iteration ("round"), because the
 //       reference threads ONE RNG state through all samples of a pixel
@@ -14,7 +14,11 @@
 //       pixels are not.
 //     * Finished lanes are refilled from a global pixel queue: __ballot of the empty lanes,
 //       one wave-aggregated atomicAdd, mbcnt prefix sum to hand out consecutive queue slots.
-//       Queue slots map to 8x8 pixel tiles so that a wave starts on coherent primary rays.
+//       Queue slots map to 8x8 pixel tiles so that a wave starts on coherent primary rays; the
+//       ORDER of the tiles comes from the previous frame's ray counts (brt_api.cpp).
+//     * When the queue is empty the thinning waves of a workgroup hand their paths to the
+//       others through an LDS pool ("drain pool" below); waves that hold one of the frame's
+//       longest pixel chains run at raised priority and take no new pixels.
 //     * No ray state ever goes to HBM; the only HBM traffic is the scene load per workgroup
 //       and one 16-byte store per pixel.
 //     * Bound by instruction issue under divergence, not by memory: the
