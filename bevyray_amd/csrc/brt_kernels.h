@@ -30,6 +30,7 @@ struct TraceLaunch {
 
 size_t trace_lds_bytes(const DeviceSceneView& sv, bool lds_scene, uint32_t block, uint32_t pool_cap);
 constexpr uint32_t POOL_RECORD_BYTES = 96;   // one path in the drain pool (k_trace_persistent)
+constexpr uint32_t WGQ_BYTES = 64;           // a workgroup's share of the pixel queue: 8 control words + 8 tile ids
 hipError_t launch_trace_persistent(const TraceLaunch& tl);
 hipError_t launch_trace_simple(const TraceLaunch& tl);
 hipError_t launch_passthrough(const FrameParams& fp, float* out_tile, const float* raster_rgba, hipStream_t stream);

@@ -46,9 +46,11 @@ struct PixelCoord {
     uint32_t tile;          // tile id (strip * tiles_x + tx)
     bool inside;
 };
-BRT_DEV PixelCoord slot_to_pixel(const FrameParams& fp, uint32_t q) {
+BRT_DEV uint32_t slot_tile(const FrameParams& fp, uint32_t slot_tile_index) {
+    return fp.tile_order ? fp.tile_order[slot_tile_index] : slot_tile_index;   // dispatch order, if known
+}
+BRT_DEV PixelCoord slot_to_pixel(const FrameParams& fp, uint32_t q, uint32_t tile) {
     const uint32_t t = q & 63u;
-    const uint32_t tile = fp.tile_order ? fp.tile_order[q >> 6] : (q >> 6);   // longest-first order, if known
     const uint32_t sq = tile / fp.tiles_x, tx = tile - sq * fp.tiles_x;
     // queue order: bottom strips first when fp.bottom_up (longest-pixels-first heuristic)
     const uint32_t strip = fp.bottom_up ? (fp.local_strips - 1u - sq) : sq;
@@ -210,18 +212,24 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t n_waves = blockDim.x >> 6;
     StackT* stk = stacks + wave * ((sv.stack_entries + 2u) * 64u) + lane;   // + 2: DONE sentinel (entry 0) and one spare entry
-    // drain pool behind the stacks (same sum as trace_lds_bytes): 4 control words, then the records
+    // behind the stacks (same sums as trace_lds_bytes): the workgroup's share of the pixel queue, then the
+    // drain pool (4 control words, then the records)
+    char* const lds = reinterpret_cast<char*>(smem);
+    uint32_t off = (uint32_t)(reinterpret_cast<char*>(stacks + n_waves * ((sv.stack_entries + 2u) * 64u)) - lds);
+    off = (off + 15u) & ~15u;
+    uint32_t* const wgq = reinterpret_cast<uint32_t*>(lds + off);
+    off += WGQ_BYTES;
     uint32_t* pool_ctl = nullptr;
     float4* pool = nullptr;
     if (fp.pool_cap != 0u) {
-        char* const lds = reinterpret_cast<char*>(smem);
-        uint32_t off = (uint32_t)(reinterpret_cast<char*>(stacks + n_waves * ((sv.stack_entries + 2u) * 64u)) - lds);
-        off = (off + 15u) & ~15u;
         pool_ctl = reinterpret_cast<uint32_t*>(lds + off);
         pool = reinterpret_cast<float4*>(lds + off + 16u);
         if (threadIdx.x == 0) { pool_ctl[0] = 0u; pool_ctl[1] = 0u; pool_ctl[2] = n_waves; pool_ctl[3] = 0u; }
     }
-    if (LDS_SCENE || fp.pool_cap != 0u) __syncthreads();
+    if (threadIdx.x < WGQ_BYTES / 4u) wgq[threadIdx.x] = 0u;
+    __syncthreads();
+    // slots a workgroup takes from the global queue at a time: a quarter of a pixel per lane
+    const uint32_t wgq_batch = (blockDim.x >> 2) < 64u ? 64u : ((blockDim.x >> 2) & ~63u);
 
     PixelState ps;
     ps.sample = 0; ps.rng = 0; ps.out_index = 0; ps.frame_index = 0; ps.tile = 0; ps.rays_begin = 0;
@@ -242,7 +250,8 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     // COUNTERS build: when this wave started, when it first found the pixel queue empty, when it ended
     // (100 MHz wall clock; read by brt_debug_profile as words 24..29)
     unsigned long long t_start = 0, t_empty = 0, drain_lane_rounds = 0;
-    if (COUNTERS) t_start = wall_clock64();
+    unsigned long long t_mark = 0, ticks_refill = 0, ticks_walk = 0, ticks_shade = 0;   // phase times of this wave
+    if (COUNTERS) t_start = t_mark = wall_clock64();
 
     for (;;) {
         // A wave that carries one of the frame's CRITICAL pixels (FrameParams::crit_*) issues ahead of its SIMD
@@ -255,6 +264,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                 if (wc) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
             }
         }
+        if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_shade += now - t_mark; t_mark = now; }
         // ---- refill empty lanes from the pixel queue (wave-aggregated) ----
         for (;;) {
             const bool need = !active && !exhausted && !wave_crit;
@@ -264,16 +274,47 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             // (a round costs the max over its lanes, so a cheap pixel dropped among expensive ones
             // pays their price for each of its samples); always refill when nothing else runs
             if ((uint32_t)__popcll(m) < fp.refill_min && __ballot(active) != 0ull) break;
-            uint32_t base = 0;
-            if (need && mbcnt64(m) == 0) base = atomicAdd(queue_counter, (uint32_t)__popcll(m));
-            base = __shfl(base, (int)(__ffsll((long long)m) - 1), 64);
+            // The workgroup takes slots from the global queue a batch at a time (one atomic on the hot address
+            // and one read of the order table per batch instead of per refill) and its waves share the batch
+            // through LDS: {lock, lo, hi, batch base, queue empty} + the batch's tile ids.
+            const uint32_t n_need = (uint32_t)__popcll(m);
+            const uint32_t rank = mbcnt64(m);
+            uint32_t q = 0xffffffffu, tile = 0;
+            bool none_left;
+            {
+                pool_lock(wgq, lane);
+                uint32_t lo = pool_peek(wgq, 1), hi = pool_peek(wgq, 2), bbase = pool_peek(wgq, 3);
+                bool done = pool_peek(wgq, 4) != 0u;
+                if (lo == hi && !done) {
+                    const uint32_t batch = wgq_batch;
+                    uint32_t b = 0;
+                    if (lane == 0) b = atomicAdd(queue_counter, batch);
+                    b = (uint32_t)__shfl((int)b, 0, 64);
+                    bbase = b;
+                    lo = b < fp.queue_size ? b : fp.queue_size;
+                    hi = b + batch < fp.queue_size ? b + batch : fp.queue_size;
+                    if (hi < lo) hi = lo;
+                    done = lo == hi;
+                    const uint32_t ti = (b >> 6) + lane;
+                    if (lane < (batch >> 6) && ti < (fp.queue_size >> 6)) wgq[8u + lane] = slot_tile(fp, ti);
+                    if (lane == 0) { wgq[2] = hi; wgq[3] = bbase; wgq[4] = done ? 1u : 0u; }
+                }
+                const uint32_t avail = hi - lo;
+                const uint32_t take = n_need < avail ? n_need : avail;
+                if (need && rank < take) {
+                    q = lo + rank;
+                    tile = wgq[8u + ((q - bbase) >> 6)];
+                }
+                if (lane == 0) wgq[1] = lo + take;
+                none_left = done && take == 0u;
+                pool_unlock(wgq, lane);
+            }
             if (need) {
-                const uint32_t q = base + mbcnt64(m);
-                if (q >= fp.queue_size) {
+                if (none_left) {
                     exhausted = true;
                     if (COUNTERS && t_empty == 0) t_empty = wall_clock64();
-                } else {
-                    const PixelCoord c = slot_to_pixel(fp, q);
+                } else if (q != 0xffffffffu) {
+                    const PixelCoord c = slot_to_pixel(fp, q, tile);
                     if (c.inside) {
                         pixel_begin(fp, c, ps);
                         crit = q >= fp.crit_begin && q < fp.crit_end;
@@ -289,6 +330,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                 }
             }
         }
+        if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_refill += now - t_mark; t_mark = now; }
         // ---- drain: hand the paths over / take paths over / leave (see "drain pool" above) ----
         bool finish_walks = false;    // this round runs every walk to its end so that the wave can hand over next round
         if (fp.pool_cap != 0u && __ballot(exhausted) != 0ull && !wave_crit) {
@@ -358,8 +400,10 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             first_depth = kInf;
         }
         if (fresh) walk_begin<D16>(walk, sc, sv.root_desc, stk, d);
+        if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_shade += now - t_mark; t_mark = now; }
         if (active) walk_run<64, COUNTERS, D16, SIMPLE>(sc, walk, stk, o, d, finish_walks ? 0u : fp.walk_exit_lanes, fp.leaf_vote, hc);
         in_flight = active && walk_pending<D16, SIMPLE>(walk);
+        if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_walk += now - t_mark; t_mark = now; }
         const bool landed = active && !in_flight;      // walk finished: shade this segment now
         const float t = walk.closest;
         const uint32_t idx = walk.closest_idx;
@@ -410,6 +454,9 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             atomicAdd(&counters[29], 1ull);
             atomicAdd(&counters[30], drain_lane_rounds & 0xffffffffull);   // live lanes summed over the rounds after "empty"
             atomicAdd(&counters[31], drain_lane_rounds >> 32);              // those rounds
+            atomicAdd(&counters[5], ticks_refill);    // wave time in: the pixel refill loop (queue atomic, tile order, pixel_begin)
+            atomicAdd(&counters[6], ticks_walk);      //               the walk loop
+            atomicAdd(&counters[7], ticks_shade + (t_end - t_mark));   // drain logic, camera ray, walk_begin, shading
         }
     }
     if (COUNTERS) {
@@ -443,7 +490,7 @@ __global__ __launch_bounds__(256) void k_trace_simple(DeviceSceneView sv, FrameP
     uint32_t n_rays = 0;
     HitCounters hc = {};
     if (q < fp.queue_size) {
-        const PixelCoord c = slot_to_pixel(fp, q);
+        const PixelCoord c = slot_to_pixel(fp, q, slot_tile(fp, q >> 6));
         if (c.inside) {
             PixelState ps;
             pixel_begin(fp, c, ps);
@@ -488,7 +535,7 @@ __global__ __launch_bounds__(256) void k_trace_simple(DeviceSceneView sv, FrameP
 __global__ void k_passthrough(FrameParams fp, float4* __restrict__ out_tile, const float4* __restrict__ raster_rgba) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= fp.queue_size) return;
-    const PixelCoord c = slot_to_pixel(fp, q);
+    const PixelCoord c = slot_to_pixel(fp, q, slot_tile(fp, q >> 6));
     if (!c.inside) return;
     out_tile[c.local_row * fp.width + c.px] =
         raster_rgba ? raster_rgba[c.py * fp.width + c.px] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -560,6 +607,7 @@ size_t trace_lds_bytes(const DeviceSceneView& sv, bool lds_scene, uint32_t block
     }
     bytes += (size_t)(block / 64) * (sv.stack_entries + 2) * 64 * (sv.desc16 ? 2 : 4);   // + 2: DONE sentinel, one spare entry
     bytes = (bytes + 15) & ~(size_t)15;
+    bytes += WGQ_BYTES;                                                                  // workgroup share of the pixel queue
     if (pool_cap) bytes += 16 + (size_t)pool_cap * POOL_RECORD_BYTES;                    // drain pool: control words + records
     return bytes;
 }

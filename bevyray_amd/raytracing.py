@@ -299,6 +299,8 @@ class RaytracePlugin:
                 "mean_wave_drain_ms": int(raw[28]) / 1e5 / int(raw[29]),
                 "drain_rounds": int(raw[31]),
                 "drain_live_lanes_per_round": int(raw[30]) / max(1, int(raw[31])),
+                "wave_ms_refill_walk_other": [int(raw[5]) / 1e5 / int(raw[29]), int(raw[6]) / 1e5 / int(raw[29]),
+                                              int(raw[7]) / 1e5 / int(raw[29])],
             }
         return prof
 
