@@ -228,8 +228,8 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     }
     if (threadIdx.x < WGQ_BYTES / 4u) wgq[threadIdx.x] = 0u;
     __syncthreads();
-    // slots a workgroup takes from the global queue at a time: a quarter of a pixel per lane
-    const uint32_t wgq_batch = (blockDim.x >> 2) < 64u ? 64u : ((blockDim.x >> 2) & ~63u);
+    // slots a workgroup takes from the global queue at a time: half a pixel per lane (at most 8 tiles)
+    const uint32_t wgq_batch = fp.wgq_batch ? fp.wgq_batch : ((blockDim.x >> 1) < 64u ? 64u : ((blockDim.x >> 1) & ~63u));
 
     PixelState ps;
     ps.sample = 0; ps.rng = 0; ps.out_index = 0; ps.frame_index = 0; ps.tile = 0; ps.rays_begin = 0;

@@ -433,6 +433,9 @@ def test_sample_count_zero_is_zero_over_zero(plugin, oracle, level):
     {"BRT_DRAIN_DONATE": "0"}, {"BRT_DRAIN_DONATE": "56"}, {"BRT_DRAIN_DONATE": "8", "BRT_POOL_CAP": "16"},
     {"BRT_DRAIN_DONATE": "40", "BRT_BLOCK_THREADS": "256"}, {"BRT_DRAIN_DONATE": "33", "BRT_FORCE_GLOBAL_SCENE": "1"},
     {"BRT_DRAIN_DONATE": "48", "BRT_WALK_EXIT": "0", "BRT_BLOCK_THREADS": "512", "BRT_WG_PER_CU": "2"},
+    # workgroup share of the pixel queue: one tile at a time, the maximum, with other workgroup shapes
+    {"BRT_WGQ_BATCH": "64"}, {"BRT_WGQ_BATCH": "512"}, {"BRT_WGQ_BATCH": "192", "BRT_BLOCK_THREADS": "256"},
+    {"BRT_WGQ_BATCH": "512", "BRT_FORCE_GLOBAL_SCENE": "1", "BRT_REFILL_MIN": "5"},
 ])
 def test_tuning_knobs_do_not_change_results(plugin, oracle, env):
     b = brt.generate_scene(brt.SCENE_COVER, 1)
