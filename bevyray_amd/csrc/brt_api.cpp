@@ -388,6 +388,17 @@ int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const fl
             tl.block = lp.block;
             tl.lds_bytes = lp.lds_bytes;
             tl.frame.pool_cap = lp.pool_cap;
+            if (tl.frame.wgq_batch == 0u) {
+                // queue slots a workgroup takes at a time: at most half a pixel per lane, and small enough that every
+                // workgroup comes back for at least 8 batches -- a rank that renders 1/8 of the frame has one tile
+                // per wave and must hand them out one by one
+                uint32_t b = (fp.queue_size / (lp.grid * 8u)) & ~63u;
+                const uint32_t cap = (lp.block / 2u) & ~63u;
+                if (b > cap) b = cap;
+                if (b > 512u) b = 512u;
+                if (b < 64u) b = 64u;
+                tl.frame.wgq_batch = b;
+            }
             HIP_TRY(ctx, launch_trace_persistent(tl));
         }
     }

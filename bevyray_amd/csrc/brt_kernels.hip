@@ -228,8 +228,8 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     }
     if (threadIdx.x < WGQ_BYTES / 4u) wgq[threadIdx.x] = 0u;
     __syncthreads();
-    // slots a workgroup takes from the global queue at a time: half a pixel per lane (at most 8 tiles)
-    const uint32_t wgq_batch = fp.wgq_batch ? fp.wgq_batch : ((blockDim.x >> 1) < 64u ? 64u : ((blockDim.x >> 1) & ~63u));
+    // slots a workgroup takes from the global queue at a time (chosen by the host, brt_api.cpp launch_part)
+    const uint32_t wgq_batch = fp.wgq_batch >= 64u ? fp.wgq_batch : 64u;
 
     PixelState ps;
     ps.sample = 0; ps.rng = 0; ps.out_index = 0; ps.frame_index = 0; ps.tile = 0; ps.rays_begin = 0;
@@ -286,7 +286,11 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                 uint32_t lo = pool_peek(wgq, 1), hi = pool_peek(wgq, 2), bbase = pool_peek(wgq, 3);
                 bool done = pool_peek(wgq, 4) != 0u;
                 if (lo == hi && !done) {
-                    const uint32_t batch = wgq_batch;
+                    // guided: the batches shrink with what is left of the queue (judged from this workgroup's last
+                    // batch), down to single tiles, so that no workgroup sits on a big share when the queue runs dry
+                    const uint32_t left = fp.queue_size > bbase ? fp.queue_size - bbase : 0u;
+                    uint32_t batch = (left / (gridDim.x * 4u)) & ~63u;
+                    batch = batch > wgq_batch ? wgq_batch : (batch < 64u ? 64u : batch);
                     uint32_t b = 0;
                     if (lane == 0) b = atomicAdd(queue_counter, batch);
                     b = (uint32_t)__shfl((int)b, 0, 64);

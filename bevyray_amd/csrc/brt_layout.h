@@ -171,7 +171,7 @@ struct FrameParams {
     // CRITICAL: a wave that holds one of their pixels raises its issue priority (s_setprio), because the
     // frame cannot end before its longest sequential chain has.
     uint32_t crit_begin, crit_end;
-    uint32_t wgq_batch;              // queue slots a workgroup takes at a time (multiple of 64, <= 512; 0: half its lanes)
+    uint32_t wgq_batch;              // queue slots a workgroup takes at a time (multiple of 64, <= 512; chosen by launch_part)
     // Dispatch order: tile_order[k] = k-th tile to hand out (from the ray counts of the previous frame
     // of the same view, brt_api.cpp); this frame's measurement for the next one: tile_cost[tile] += rays
     // of each finished pixel, tile_cost[n_tiles + tile] = max of them.  Either may be null.
