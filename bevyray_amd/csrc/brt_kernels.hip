@@ -291,6 +291,9 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                     const uint32_t left = fp.queue_size > bbase ? fp.queue_size - bbase : 0u;
                     uint32_t batch = (left / (gridDim.x * 4u)) & ~63u;
                     batch = batch > wgq_batch ? wgq_batch : (batch < 64u ? 64u : batch);
+                    // single tiles until the queue is past the CRITICAL tiles: the waves that carry them run at raised
+                    // priority and should sit on different CUs, not eight to a workgroup
+                    if (bbase < fp.crit_end) batch = 64u;
                     uint32_t b = 0;
                     if (lane == 0) b = atomicAdd(queue_counter, batch);
                     b = (uint32_t)__shfl((int)b, 0, 64);
