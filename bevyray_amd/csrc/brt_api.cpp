@@ -46,6 +46,7 @@ struct DeviceCtx {
     uint32_t* d_tile_cost = nullptr;
     size_t tile_cost_cap = 0;
     uint32_t* d_tile_order = nullptr;
+    uint32_t order_main = 0;                             // tiles of the main queue; the rest of d_tile_order is the drain queue
     uint32_t order_first_ranked = 0, order_crit = 0;   // d_tile_order[first_ranked .. +crit) are the CRITICAL tiles
     size_t tile_order_cap = 0;
     bool order_valid = false;
@@ -156,6 +157,7 @@ int32_t make_frame_params(brt_ctx* ctx, const void* camera80, const void* window
     const uint32_t strips = (height + BRT_STRIP_ROWS - 1u) / BRT_STRIP_ROWS;
     fp.local_strips = (strips + n_parts - 1u) / n_parts;
     fp.queue_size = fp.local_strips * fp.tiles_x * 64u;
+    fp.queue_main = fp.queue_size;   // attach_tile_order may split off the sky tiles
     fp.bottom_up = env_u32("BRT_BOTTOM_UP", 0);
     fp.refill_min = env_u32("BRT_REFILL_MIN", 1);
     if (fp.refill_min < 1u) fp.refill_min = 1u;
@@ -287,6 +289,7 @@ int32_t attach_tile_order(brt_ctx* ctx, DeviceCtx& dc, FrameParams& fp, hipStrea
     const bool match = dc.order_valid && std::memcmp(key, dc.order_key, sizeof key) == 0;
     if (match) {
         fp.tile_order = dc.d_tile_order;
+        fp.queue_main = dc.order_main * 64u;
         fp.crit_begin = dc.order_first_ranked * 64u;
         fp.crit_end = fp.crit_begin + dc.order_crit * 64u;
     }
@@ -310,7 +313,8 @@ int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hi
     const uint32_t key_kind = env_u32("BRT_LPT_KEY", 1);            // 1: longest pixel of the tile, 0: sum of its rays
     // order: "sky" tiles (at most ~one ray per sample: every path left the scene at once) in raster order,
     // then the most expensive tenth of the others by cost, then the rest in raster order
-    const uint32_t sky_first = env_u32("BRT_LPT_SKY_FIRST", 1);
+    const uint32_t sky_mode = env_u32("BRT_LPT_SKY", 2);            // 0: in the raster part, 1: first, 2: last, as the drain queue
+    const uint32_t sky_first = sky_mode == 1u;
     const uint64_t sky_cost = (uint64_t)64 * fp.sample_count * (1000 + env_u32("BRT_LPT_SKY_SLACK", 20)) / 1000;
     dc.h_order.resize(n_tiles);
     std::vector<uint8_t> where(n_tiles, 0);                                    // 0 middle, 1 head, 2 sky
@@ -318,6 +322,9 @@ int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hi
     if (sky_first)
         for (uint32_t tile = 0; tile < n_tiles; tile++)
             if (dc.h_cost[tile] <= sky_cost) { where[tile] = 2; dc.h_order[k++] = tile; }
+    if (sky_mode == 2u)
+        for (uint32_t tile = 0; tile < n_tiles; tile++)
+            if (dc.h_cost[tile] <= sky_cost) where[tile] = 3;
     dc.h_keys.clear();
     for (uint32_t i = 0; i < n_tiles; i++)
         if (where[i] == 0) dc.h_keys.push_back(((uint64_t)(~(key_kind ? h_max[i] : dc.h_cost[i])) << 32) | i);   // cost descending, index ascending
@@ -347,6 +354,12 @@ int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hi
     }
     for (uint32_t tile = 0; tile < n_tiles; tile++)                            // the rest: raster order
         if (where[tile] == 0) dc.h_order[k++] = tile;
+    dc.order_main = n_tiles;
+    if (sky_mode == 2u) {                                                      // sky tiles: the drain queue
+        dc.order_main = k;
+        for (uint32_t tile = 0; tile < n_tiles; tile++)
+            if (where[tile] == 3) dc.h_order[k++] = tile;
+    }
     int32_t rc = ensure(ctx, &dc.d_tile_order, &dc.tile_order_cap, (size_t)n_tiles * 4);
     if (rc != BRT_OK) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(dc.d_tile_order, dc.h_order.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, stream));

@@ -253,6 +253,24 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     unsigned long long t_mark = 0, ticks_refill = 0, ticks_walk = 0, ticks_shade = 0;   // phase times of this wave
     if (COUNTERS) t_start = t_mark = wall_clock64();
 
+    bool sky_done = false;            // the drain queue (FrameParams::queue_main..queue_size) is empty
+    // lane takes queue slot q of `tile`
+    auto begin_pixel = [&](uint32_t q, uint32_t tile) {
+        const PixelCoord c = slot_to_pixel(fp, q, tile);
+        if (c.inside) {
+            pixel_begin(fp, c, ps);
+            crit = q >= fp.crit_begin && q < fp.crit_end;
+            ps.rays_begin = n_rays;
+            if (fp.sample_count == 0) {
+                // 0/0 per channel.  The sums are compile-time zeros here; keep them opaque: hipcc 7.2
+                // otherwise folds the four divisions into one and then drops two channels of the
+                // level-1/2 result (found by scripts/fuzz_parity.py; tests: sample_count 0).
+                asm volatile("" : "+v"(ps.sum.x), "+v"(ps.sum.y), "+v"(ps.sum.z), "+v"(ps.dsum));
+                pixel_finish(fp, ps, out_tile, raster_rgba, raster_depth);
+            } else { active = true; bounce = 0; }
+        }
+    };
+
     for (;;) {
         // A wave that carries one of the frame's CRITICAL pixels (FrameParams::crit_*) issues ahead of its SIMD
         // mates and takes no new pixels: its rounds get shorter as its other pixels end, and the frame cannot
@@ -288,7 +306,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                 if (lo == hi && !done) {
                     // guided: the batches shrink with what is left of the queue (judged from this workgroup's last
                     // batch), down to single tiles, so that no workgroup sits on a big share when the queue runs dry
-                    const uint32_t left = fp.queue_size > bbase ? fp.queue_size - bbase : 0u;
+                    const uint32_t left = fp.queue_main > bbase ? fp.queue_main - bbase : 0u;
                     uint32_t batch = (left / (gridDim.x * 4u)) & ~63u;
                     batch = batch > wgq_batch ? wgq_batch : (batch < 64u ? 64u : batch);
                     // single tiles until the queue is past the CRITICAL tiles: the waves that carry them run at raised
@@ -298,12 +316,12 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                     if (lane == 0) b = atomicAdd(queue_counter, batch);
                     b = (uint32_t)__shfl((int)b, 0, 64);
                     bbase = b;
-                    lo = b < fp.queue_size ? b : fp.queue_size;
-                    hi = b + batch < fp.queue_size ? b + batch : fp.queue_size;
+                    lo = b < fp.queue_main ? b : fp.queue_main;
+                    hi = b + batch < fp.queue_main ? b + batch : fp.queue_main;
                     if (hi < lo) hi = lo;
                     done = lo == hi;
                     const uint32_t ti = (b >> 6) + lane;
-                    if (lane < (batch >> 6) && ti < (fp.queue_size >> 6)) wgq[8u + lane] = slot_tile(fp, ti);
+                    if (lane < (batch >> 6) && ti < (fp.queue_main >> 6)) wgq[8u + lane] = slot_tile(fp, ti);
                     if (lane == 0) { wgq[2] = hi; wgq[3] = bbase; wgq[4] = done ? 1u : 0u; }
                 }
                 const uint32_t avail = hi - lo;
@@ -321,21 +339,18 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                     exhausted = true;
                     if (COUNTERS && t_empty == 0) t_empty = wall_clock64();
                 } else if (q != 0xffffffffu) {
-                    const PixelCoord c = slot_to_pixel(fp, q, tile);
-                    if (c.inside) {
-                        pixel_begin(fp, c, ps);
-                        crit = q >= fp.crit_begin && q < fp.crit_end;
-                        ps.rays_begin = n_rays;
-                        if (fp.sample_count == 0) {
-                            // 0/0 per channel.  The sums are compile-time zeros here; keep them opaque: hipcc 7.2
-                            // otherwise folds the four divisions into one and then drops two channels of the
-                            // level-1/2 result (found by scripts/fuzz_parity.py; tests: sample_count 0).
-                            asm volatile("" : "+v"(ps.sum.x), "+v"(ps.sum.y), "+v"(ps.sum.z), "+v"(ps.dsum));
-                            pixel_finish(fp, ps, out_tile, raster_rgba, raster_depth);
-                        } else { active = true; bounce = 0; }
-                    }
+                    begin_pixel(q, tile);
                 }
             }
+        }
+        // ---- nothing left to do and the main queue is empty: a whole tile of the drain queue (sky pixels) ----
+        if (fp.queue_main != fp.queue_size && !sky_done && !wave_crit && __ballot(active) == 0ull &&
+            __ballot(!exhausted) == 0ull) {
+            uint32_t b = 0;
+            if (lane == 0) b = atomicAdd(queue_counter + 1, 64u);
+            b = fp.queue_main + (uint32_t)__shfl((int)b, 0, 64);
+            if (b < fp.queue_size) begin_pixel(b + lane, slot_tile(fp, b >> 6));
+            else sky_done = true;
         }
         if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_refill += now - t_mark; t_mark = now; }
         // ---- drain: hand the paths over / take paths over / leave (see "drain pool" above) ----
@@ -362,8 +377,10 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                         rec[5] = make_float4(tput.z, __uint_as_float(bounce), first_depth, __uint_as_float(crit ? 1u : 0u));
                         active = false;
                     }
-                    if (lane == 0) { pool_ctl[1] = count + live; pool_ctl[2] = alive - 1u; }
-                    leave = true;
+                    // (while the drain queue has tiles the wave stays: it takes one next round)
+                    const bool stay = fp.queue_main != fp.queue_size && !sky_done;
+                    if (lane == 0) { pool_ctl[1] = count + live; if (!stay) pool_ctl[2] = alive - 1u; }
+                    leave = !stay;
                 } else if (count != 0u && live < 64u) {
                     // take over: idle lane r of k takes record count - k + r
                     const uint64_t im = ~am;
@@ -382,7 +399,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                         active = true; in_flight = false; exhausted = true;
                     }
                     if (lane == 0) pool_ctl[1] = count - k;
-                } else if (live == 0u && count == 0u) {
+                } else if (live == 0u && count == 0u && (fp.queue_main == fp.queue_size || sky_done)) {
                     if (lane == 0) pool_ctl[2] = alive - 1u;
                     leave = true;
                 }
@@ -390,7 +407,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             }
             if (leave) break;
             finish_walks = (uint32_t)__popcll(__ballot(active)) <= fp.drain_donate;
-        } else if (__ballot(active) == 0) {
+        } else if (__ballot(active) == 0 && (fp.queue_main == fp.queue_size || sky_done || __ballot(!exhausted) != 0ull)) {
             break;
         }
         if (__ballot(active) == 0) continue;      // (pool on) nothing live but paths may still arrive
