@@ -162,9 +162,9 @@ int32_t make_frame_params(brt_ctx* ctx, const void* camera80, const void* window
     fp.refill_min = env_u32("BRT_REFILL_MIN", 1);
     if (fp.refill_min < 1u) fp.refill_min = 1u;
     if (fp.refill_min > 64u) fp.refill_min = 64u;
-    fp.walk_exit_lanes = env_u32("BRT_WALK_EXIT", 8);
+    fp.walk_exit_lanes = env_u32("BRT_WALK_EXIT", 12);
     if (fp.walk_exit_lanes > 63u) fp.walk_exit_lanes = 63u;
-    fp.leaf_vote = env_u32("BRT_LEAF_VOTE", 8);
+    fp.leaf_vote = env_u32("BRT_LEAF_VOTE", 12);
     if (fp.leaf_vote > 64u) fp.leaf_vote = 64u;
     fp.drain_donate = env_u32("BRT_DRAIN_DONATE", 40);
     if (fp.drain_donate > 56u) fp.drain_donate = 56u;
