@@ -837,11 +837,11 @@ int32_t brt_build_bvh_device(brt_ctx* ctx, const void* models, uint32_t n_models
     return BRT_OK;
 }
 
-int32_t brt_debug_profile(brt_ctx* ctx, uint64_t* out32) {
-    if (!ctx || !out32) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
+int32_t brt_debug_profile(brt_ctx* ctx, uint64_t* out64) {
+    if (!ctx || !out64) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
     DeviceCtx& dc = ctx->devs[0];
     HIP_TRY(ctx, hipSetDevice(dc.device));
-    HIP_TRY(ctx, hipMemcpy(out32, dc.d_ctrl, 256, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out64, dc.d_ctrl, 512, hipMemcpyDeviceToHost));
     return BRT_OK;
 }
 

@@ -130,6 +130,7 @@ struct HitCounters {
     // COUNTERS builds only: per code section, how often the wave executed it and with how many
     // lanes (lane-utilisation profile; read by brt_debug_profile)
     uint32_t sec_exec[8], sec_lanes[8];
+    unsigned long long ticks_ball;   // COUNTERS builds: wave time in the rejection-sampler loop (100 MHz ticks)
 };
 enum { SEC_INTERIOR = 0, SEC_LEAF, SEC_CAMERA, SEC_SCATTER, SEC_SKY, SEC_BALL, SEC_REFILL, SEC_ROUND };
 
@@ -442,6 +443,8 @@ BRT_DEV bool scatter(const ScenePtrs& sc, f3& o, f3& d, float t, uint32_t idx, u
     // included.  Each accepted candidate is the shader's own expression.
     f3 acc = diffuse ? nrm : mk3(-0.0f, -0.0f, -0.0f);
     float scale = diffuse ? 1.0f : m1.x;
+    unsigned long long t_ball = 0;
+    if (COUNTERS) t_ball = wall_clock64();
     while (need != 0u) {                                                      // random.wgsl:19-24
         if (COUNTERS) prof_section<COUNTERS>(hc, SEC_BALL, true);
         const float px = rng_ball_coord(rng);
@@ -453,6 +456,11 @@ BRT_DEV bool scatter(const ScenePtrs& sc, f3& o, f3& d, float t, uint32_t idx, u
         acc = mk3(ok ? cand.x : acc.x, ok ? cand.y : acc.y, ok ? cand.z : acc.z);
         scale = ok ? m1.x : scale;
         need -= ok ? 1u : 0u;
+    }
+    if (COUNTERS) {   // booked by the first lane of the section, like prof_section
+        const uint64_t m = __ballot(true);
+        if (__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0u)
+            hc.ticks_ball += wall_clock64() - t_ball;
     }
 
     bool absorbed = false;

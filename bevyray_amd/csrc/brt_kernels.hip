@@ -250,7 +250,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     // COUNTERS build: when this wave started, when it first found the pixel queue empty, when it ended
     // (100 MHz wall clock; read by brt_debug_profile as words 24..29)
     unsigned long long t_start = 0, t_empty = 0, drain_lane_rounds = 0;
-    unsigned long long t_mark = 0, ticks_refill = 0, ticks_walk = 0, ticks_shade = 0;   // phase times of this wave
+    unsigned long long t_mark = 0, ticks_refill = 0, ticks_walk = 0, ticks_shade = 0, ticks_pre = 0;   // phase times of this wave
     if (COUNTERS) t_start = t_mark = wall_clock64();
 
     bool sky_done = false;            // the drain queue (FrameParams::queue_main..queue_size) is empty
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             first_depth = kInf;
         }
         if (fresh) walk_begin<D16>(walk, sc, sv.root_desc, stk, d);
-        if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_shade += now - t_mark; t_mark = now; }
+        if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_pre += now - t_mark; t_mark = now; }
         if (active) walk_run<64, COUNTERS, D16, SIMPLE>(sc, walk, stk, o, d, finish_walks ? 0u : fp.walk_exit_lanes, fp.leaf_vote, hc);
         in_flight = active && walk_pending<D16, SIMPLE>(walk);
         if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_walk += now - t_mark; t_mark = now; }
@@ -480,8 +480,14 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             atomicAdd(&counters[31], drain_lane_rounds >> 32);              // those rounds
             atomicAdd(&counters[5], ticks_refill);    // wave time in: the pixel refill loop (queue atomic, tile order, pixel_begin)
             atomicAdd(&counters[6], ticks_walk);      //               the walk loop
-            atomicAdd(&counters[7], ticks_shade + (t_end - t_mark));   // drain logic, camera ray, walk_begin, shading
+            atomicAdd(&counters[7], ticks_shade + (t_end - t_mark));   // shading of the landed rays, pixel finish
+            atomicAdd(&counters[43], ticks_pre);                       // drain logic, camera ray, walk_begin
         }
+    }
+    if (COUNTERS) {
+        unsigned long long tb = hc.ticks_ball;   // sum over the lanes that booked it
+        for (int off = 32; off > 0; off >>= 1) tb += __shfl_down(tb, off, 64);
+        if (lane == 0) atomicAdd(&counters[44], tb);
     }
     if (COUNTERS) {
         const uint32_t h = wave_sum(hc.hits);

@@ -283,7 +283,7 @@ class RaytracePlugin:
 
     def debug_profile(self) -> dict:
         """Lane-utilisation profile of the last FLAG_COUNTERS launch: section -> (executions, lanes)."""
-        raw = (C.c_uint64 * 32)()
+        raw = (C.c_uint64 * 64)()
         _lib.check(self._lib.brt_debug_profile(self._ctx, raw), self._ctx)
         names = ["interior", "leaf", "camera", "scatter", "sky", "ball", "sec6", "round"]
         prof = {n: (int(raw[8 + 2 * k]), int(raw[9 + 2 * k])) for k, n in enumerate(names)}
@@ -299,8 +299,11 @@ class RaytracePlugin:
                 "mean_wave_drain_ms": int(raw[28]) / 1e5 / int(raw[29]),
                 "drain_rounds": int(raw[31]),
                 "drain_live_lanes_per_round": int(raw[30]) / max(1, int(raw[31])),
-                "wave_ms_refill_walk_other": [int(raw[5]) / 1e5 / int(raw[29]), int(raw[6]) / 1e5 / int(raw[29]),
-                                              int(raw[7]) / 1e5 / int(raw[29])],
+                # mean per wave, ms: pixel refill | walk loop | shading (of which the rejection-sampler loop) | drain
+                # logic + camera ray + walk begin
+                "wave_ms_refill_walk_shade_ball_pre": [int(raw[5]) / 1e5 / int(raw[29]), int(raw[6]) / 1e5 / int(raw[29]),
+                                                       int(raw[7]) / 1e5 / int(raw[29]), int(raw[44]) / 1e5 / int(raw[29]),
+                                                       int(raw[43]) / 1e5 / int(raw[29])],
             }
         return prof
 
