@@ -77,6 +77,7 @@ _PROTOTYPES = {
     "brt_host_camera_extract": (_I32, [C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _F, _F, _F, _F, _U32, _U32, _VP]),
     "brt_host_window_extract": (_I32, [_F, _U32, _VP]),
     "brt_host_material": (_I32, [C.POINTER(_F), _F, _F, _F, _F, _F, _VP]),
+    "brt_host_tile_order": (_I32, [_VP, _VP, _U32, _U32, C.c_uint64, _U32, _U32, _VP, _VP]),
 }
 EXPORTS = tuple(_PROTOTYPES)
 

@@ -53,7 +53,6 @@ struct DeviceCtx {
     uint32_t order_age = 0;                       // frames since the costs were last measured
     uint32_t order_key[6] = {0, 0, 0, 0, 0, 0};   // width, height, part, n_parts, scene epoch, n_tiles
     std::vector<uint32_t> h_cost;
-    std::vector<uint64_t> h_keys;
     std::vector<uint32_t> h_order;
     // GPU BVH build
     char* d_bvh_scratch = nullptr;
@@ -309,57 +308,20 @@ int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hi
     dc.h_cost.resize(2 * (size_t)n_tiles);
     HIP_TRY(ctx, hipMemcpyAsync(dc.h_cost.data(), dc.d_tile_cost, (size_t)n_tiles * 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));
-    const uint32_t* h_max = dc.h_cost.data() + n_tiles;            // longest pixel chain of each tile
-    const uint32_t key_kind = env_u32("BRT_LPT_KEY", 1);            // 1: longest pixel of the tile, 0: sum of its rays
-    // order: "sky" tiles (at most ~one ray per sample: every path left the scene at once) in raster order,
-    // then the most expensive tenth of the others by cost, then the rest in raster order
-    const uint32_t sky_mode = env_u32("BRT_LPT_SKY", 2);            // 0: in the raster part, 1: first, 2: last, as the drain queue
-    const uint32_t sky_first = sky_mode == 1u;
-    const uint64_t sky_cost = (uint64_t)64 * fp.sample_count * (1000 + env_u32("BRT_LPT_SKY_SLACK", 20)) / 1000;
-    dc.h_order.resize(n_tiles);
-    std::vector<uint8_t> where(n_tiles, 0);                                    // 0 middle, 1 head, 2 sky
-    uint32_t k = 0;
-    if (sky_first)
-        for (uint32_t tile = 0; tile < n_tiles; tile++)
-            if (dc.h_cost[tile] <= sky_cost) { where[tile] = 2; dc.h_order[k++] = tile; }
-    if (sky_mode == 2u)
-        for (uint32_t tile = 0; tile < n_tiles; tile++)
-            if (dc.h_cost[tile] <= sky_cost) where[tile] = 3;
-    dc.h_keys.clear();
-    for (uint32_t i = 0; i < n_tiles; i++)
-        if (where[i] == 0) dc.h_keys.push_back(((uint64_t)(~(key_kind ? h_max[i] : dc.h_cost[i])) << 32) | i);   // cost descending, index ascending
-    uint32_t head = (uint32_t)((uint64_t)dc.h_keys.size() * env_u32("BRT_LPT_HEAD_PERMILLE", 100) / 1000u);
-    if (head > dc.h_keys.size()) head = (uint32_t)dc.h_keys.size();
-    std::nth_element(dc.h_keys.begin(), dc.h_keys.begin() + head, dc.h_keys.end());
-    std::sort(dc.h_keys.begin(), dc.h_keys.begin() + head);                    // head: most expensive first
-    // CRITICAL tiles: a pixel whose chain alone takes half of what a lane works through in the whole frame
-    // (sum of rays / lanes of the grid) bounds the frame time by itself -- RTIOW at 256 spp and 50 bounces has
-    // pixels of > 10 000 sequential rays in a frame of ~5 000 rays per lane.  Waves holding such pixels run at
-    // raised priority and are not refilled (k_trace_persistent).  The cover frame has none (576 < 595).
-    dc.order_first_ranked = k;
-    dc.order_crit = 0;
-    if (key_kind == 1 && env_u32("BRT_CRIT", 1) != 0) {
-        uint64_t sum = 0;
-        uint32_t cmax = 0;
-        for (uint32_t i = 0; i < n_tiles; i++) { sum += dc.h_cost[i]; cmax = h_max[i] > cmax ? h_max[i] : cmax; }
-        const uint64_t per_lane = sum / ((uint64_t)dc.num_cus * BRT_BLOCK);
-        const uint64_t thr = per_lane / 2 > cmax / 2 ? per_lane / 2 : cmax / 2;
-        if (cmax >= per_lane / 2)
-            for (uint32_t i = 0; i < head && h_max[(uint32_t)(dc.h_keys[i] & 0xffffffffu)] >= thr; i++) dc.order_crit++;
-    }
-    for (uint32_t i = 0; i < head; i++) {
-        const uint32_t t = (uint32_t)(dc.h_keys[i] & 0xffffffffu);
-        dc.h_order[k++] = t;
-        where[t] = 1;
-    }
-    for (uint32_t tile = 0; tile < n_tiles; tile++)                            // the rest: raster order
-        if (where[tile] == 0) dc.h_order[k++] = tile;
-    dc.order_main = n_tiles;
-    if (sky_mode == 2u) {                                                      // sky tiles: the drain queue
-        dc.order_main = k;
-        for (uint32_t tile = 0; tile < n_tiles; tile++)
-            if (where[tile] == 3) dc.h_order[k++] = tile;
-    }
+    TileOrderParams tp{};
+    tp.sample_count = fp.sample_count;
+    tp.grid_lanes = (uint64_t)dc.num_cus * BRT_BLOCK;
+    tp.key_longest_pixel = env_u32("BRT_LPT_KEY", 1);
+    tp.sky_mode = env_u32("BRT_LPT_SKY", 2);
+    tp.sky_slack_permille = env_u32("BRT_LPT_SKY_SLACK", 20);
+    tp.head_permille = env_u32("BRT_LPT_HEAD_PERMILLE", 100);
+    tp.critical = env_u32("BRT_CRIT", 1);
+    TileOrder to;
+    build_tile_order(dc.h_cost.data(), dc.h_cost.data() + n_tiles, n_tiles, tp, &to);   // sums, then longest pixels (brt_host.cpp)
+    dc.h_order.swap(to.order);
+    dc.order_main = to.n_main;
+    dc.order_first_ranked = to.first_ranked;
+    dc.order_crit = to.n_critical;
     int32_t rc = ensure(ctx, &dc.d_tile_order, &dc.tile_order_cap, (size_t)n_tiles * 4);
     if (rc != BRT_OK) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(dc.d_tile_order, dc.h_order.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, stream));
