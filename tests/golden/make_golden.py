@@ -96,13 +96,9 @@ def main():
             ((-0.4, 0.6, -1.6), 0.35, M(base_color=(0.9, 0.9, 0.9), metallic=1.0, perceptual_roughness=0.0))]
     cases = {}
     rng = np.random.default_rng(7)
-    for name, bvh_fn, w, h, spp, bounces, level, rseed in [
-            ("ploc_pure", None, 16, 12, 3, 6, brt.Raytracing.Pure, 0.37),
-            ("leaf2_blend", lambda m: median_split_bvh(m, 2), 12, 9, 2, 4, brt.Raytracing.FallbackRaytraced, 0.81),
-            ("leaf3_raster", lambda m: median_split_bvh(m, 3), 10, 8, 2, 3, brt.Raytracing.FallbackRaster, 0.12)]:
-        b = make_buffers(data, bvh_fn)
-        lvl, cam, win = uniforms(w, h, spp=spp, bounces=bounces, pos=(0.2, 0.4, 1.6), target=(0.0, 0.0, -1.0), fov=0.9, seed=rseed,
-                                 level=level, window_height=h * 3)
+    from helpers import chain_bvh
+
+    def add_case(name, b, lvl, cam, win, w, h, level):
         raster = rng.random((h, w, 4), dtype=np.float32) if level != brt.Raytracing.Pure else None
         depth = (rng.random((h, w), dtype=np.float32) * np.float32(0.2)) if level != brt.Raytracing.Pure else None
         frame, rays = npr.render(b.models, b.materials, b.bvh, cam[0], win[0], int(level), w, h, raster, depth)
@@ -113,7 +109,35 @@ def main():
         if raster is not None:
             cases[f"{name}.raster"] = raster
             cases[f"{name}.depth"] = depth
-        print("numpy restatement:", name, frame.shape, rays, "rays, mean", frame[..., :3].mean())
+        with np.errstate(all="ignore"):
+            print("numpy restatement:", name, frame.shape, rays, "rays, mean", np.nanmean(frame[..., :3]))
+
+    for name, bvh_fn, w, h, spp, bounces, level, rseed in [
+            ("ploc_pure", None, 16, 12, 3, 6, brt.Raytracing.Pure, 0.37),
+            ("leaf2_blend", lambda m: median_split_bvh(m, 2), 12, 9, 2, 4, brt.Raytracing.FallbackRaytraced, 0.81),
+            ("leaf3_raster", lambda m: median_split_bvh(m, 3), 10, 8, 2, 3, brt.Raytracing.FallbackRaster, 0.12)]:
+        b = make_buffers(data, bvh_fn)
+        lvl, cam, win = uniforms(w, h, spp=spp, bounces=bounces, pos=(0.2, 0.4, 1.6), target=(0.0, 0.0, -1.0), fov=0.9, seed=rseed,
+                                 level=level, window_height=h * 3)
+        add_case(name, b, lvl, cam, win, w, h, level)
+
+    # (added later; the three cases above keep their bytes)
+    # a piece of the 506-sphere cover scene through its PLOC tree, cover camera
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    lvl, cam, win = brt.cover_camera(12, 7, 2, 5, brt.Raytracing.Pure, 0.5)
+    add_case("cover_ploc", b, lvl, cam, win, 12, 7, brt.Raytracing.Pure)
+    # a 36-deep caterpillar tree: the 32-entry stack overflows and drops subtrees (raytrace.wgsl:320)
+    deep = make_buffers([((0.0, 0.0, -5.0 - i), 0.5, M(base_color=(0.8, 0.3, 0.3))) for i in range(36)], chain_bvh)
+    lvl, cam, win = uniforms(8, 8, spp=2, bounces=3, pos=(0, 0, 0), target=(0, 0, -1), fov=0.3, seed=0.5)
+    add_case("deep_chain", deep, lvl, cam, win, 8, 8, brt.Raytracing.Pure)
+    # every primary ray parallel to -Z (up parallel to the view direction: right = 0) from an origin ON a padded
+    # slab plane: 1/d = inf, 0 * inf = NaN in the slab test (raytrace.wgsl:387-398 with minNum/maxNum)
+    b = make_buffers(data[:4], lambda m: median_split_bvh(m, 1))
+    lvl, cam, win = uniforms(6, 6, spp=2, bounces=3, pos=(0.0, 0.0, 0.5), target=(0.0, 0.0, -1.0), fov=0.6, seed=0.25)
+    cam = cam.copy()
+    cam["up"] = (0.0, 0.0, -1.0)
+    cam["position"] = (float(np.float32(0.0) - (np.float32(0.5) + np.float32(0.1))), 0.0, 0.5)
+    add_case("axis_parallel", b, lvl, cam, win, 6, 6, brt.Raytracing.Pure)
     np.savez_compressed(os.path.join(HERE, "tiny_frames.npz"), **cases)
     print("wrote tiny_frames.npz")
 

@@ -237,7 +237,7 @@ def test_oracle_matches_numpy_restatement_frames(oracle):
         assert np.array_equal(got.view(np.uint32), frame.view(np.uint32)), name
         assert cnt["rays"] == rays, name
         n += 1
-    assert n == 3
+    assert n == 6
 
 
 # ---- (4) regression fixture ----------------------------------------------------------------------------
