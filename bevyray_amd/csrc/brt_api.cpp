@@ -46,8 +46,8 @@ struct DeviceCtx {
     uint32_t* d_tile_cost = nullptr;
     size_t tile_cost_cap = 0;
     uint32_t* d_tile_order = nullptr;
-    uint32_t order_main = 0;                             // tiles of the main queue; the rest of d_tile_order is the drain queue
-    uint32_t order_first_ranked = 0, order_crit = 0;   // d_tile_order[first_ranked .. +crit) are the CRITICAL tiles
+    uint32_t order_lane = 0;                             // tiles of the lane queue; the rest of d_tile_order is the tile queue
+    uint32_t order_crit = 0;                             // d_tile_order[0 .. crit) are the CRITICAL tiles
     size_t tile_order_cap = 0;
     bool order_valid = false;
     uint32_t order_age = 0;                       // frames since the costs were last measured
@@ -156,7 +156,7 @@ int32_t make_frame_params(brt_ctx* ctx, const void* camera80, const void* window
     const uint32_t strips = (height + BRT_STRIP_ROWS - 1u) / BRT_STRIP_ROWS;
     fp.local_strips = (strips + n_parts - 1u) / n_parts;
     fp.queue_size = fp.local_strips * fp.tiles_x * 64u;
-    fp.queue_main = fp.queue_size;   // attach_tile_order may split off the sky tiles
+    fp.queue_main = 0u;              // whole tiles for idle waves; attach_tile_order may give the front of the order to the lane queue
     fp.bottom_up = env_u32("BRT_BOTTOM_UP", 0);
     fp.refill_min = env_u32("BRT_REFILL_MIN", 1);
     if (fp.refill_min < 1u) fp.refill_min = 1u;
@@ -288,9 +288,9 @@ int32_t attach_tile_order(brt_ctx* ctx, DeviceCtx& dc, FrameParams& fp, hipStrea
     const bool match = dc.order_valid && std::memcmp(key, dc.order_key, sizeof key) == 0;
     if (match) {
         fp.tile_order = dc.d_tile_order;
-        fp.queue_main = dc.order_main * 64u;
-        fp.crit_begin = dc.order_first_ranked * 64u;
-        fp.crit_end = fp.crit_begin + dc.order_crit * 64u;
+        fp.queue_main = dc.order_lane * 64u;
+        fp.crit_begin = 0u;
+        fp.crit_end = dc.order_crit * 64u;
     }
     if (may_measure && (!match || ++dc.order_age >= kLptRefresh)) {
         int32_t rc = ensure(ctx, &dc.d_tile_cost, &dc.tile_cost_cap, (size_t)n_tiles * 8);   // sums, then maxima
@@ -311,16 +311,14 @@ int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hi
     TileOrderParams tp{};
     tp.sample_count = fp.sample_count;
     tp.grid_lanes = (uint64_t)dc.num_cus * BRT_BLOCK;
-    tp.key_longest_pixel = env_u32("BRT_LPT_KEY", 1);
-    tp.sky_mode = env_u32("BRT_LPT_SKY", 2);
+    tp.sorted = env_u32("BRT_LPT_SORT", 1);
     tp.sky_slack_permille = env_u32("BRT_LPT_SKY_SLACK", 20);
-    tp.head_permille = env_u32("BRT_LPT_HEAD_PERMILLE", 100);
+    tp.lane_permille = env_u32("BRT_LPT_LANE_PERMILLE", 0);
     tp.critical = env_u32("BRT_CRIT", 1);
     TileOrder to;
     build_tile_order(dc.h_cost.data(), dc.h_cost.data() + n_tiles, n_tiles, tp, &to);   // sums, then longest pixels (brt_host.cpp)
     dc.h_order.swap(to.order);
-    dc.order_main = to.n_main;
-    dc.order_first_ranked = to.first_ranked;
+    dc.order_lane = to.n_lane;
     dc.order_crit = to.n_critical;
     int32_t rc = ensure(ctx, &dc.d_tile_order, &dc.tile_order_cap, (size_t)n_tiles * 4);
     if (rc != BRT_OK) return rc;

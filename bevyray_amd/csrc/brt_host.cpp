@@ -377,62 +377,45 @@ int32_t scene_generate(uint32_t kind, uint64_t seed, std::vector<Model>* models,
 float tan_half_fov(float fov) { return (float)std::tan((double)(fov * 0.5f)); }
 
 // ---------------------------------------------------------------------------------------
-// Dispatch order of the 8x8 tiles (used by brt_api.cpp for k_trace_persistent's pixel queue).
+// Dispatch order of the 8x8 tiles (used by brt_api.cpp for k_trace_persistent's queues).
 //
-// A pixel is one sequential chain of samples (the reference threads one RNG state through them), so
-// (1) a frame ends when its slowest pixels end -- a tile with a long pixel must not be handed out late --
-// and (2) a lane that takes a one-ray-per-sample "sky" pixel while its wave-mates walk the scene pays their
-// round time for each of its samples.  From the rays each tile needed in a measured frame (sum and longest
-// pixel):
-//   first   the `head_permille` of the non-sky tiles with the longest pixels, longest first;
-//   then    the other non-sky tiles in raster order (a FULLY sorted order makes the waves of a SIMD run the
-//           same phase at the same time: +6..11 % time at equal instruction counts);
-//   last    the sky tiles as a separate DRAIN queue (sky_mode 2): whole tiles for waves that have nothing
-//           else left.  (sky_mode 1: first; 0: left in the raster part.)
+// A pixel is one sequential chain of samples (the reference threads one RNG state through them), so a frame
+// ends when its slowest pixels end: a tile with a long pixel must not be handed out late.  From the rays each
+// tile needed in a measured frame (sum and longest pixel):
+//   first   the non-sky tiles by their longest pixel, longest first (`sorted`; raster order otherwise);
+//   last    the "sky" tiles (one ray per sample: every path leaves the scene at once), in raster order.
+// The kernel hands out WHOLE tiles to waves that have nothing left (the tile queue); `lane_permille` of the
+// non-sky tiles, from the front, can instead be handed out pixel by pixel to single free lanes (the lane queue).
 // CRITICAL tiles: a pixel whose chain alone takes half of what a lane works through in the whole frame
 // (sum of rays / lanes of the grid) bounds the frame time by itself -- RTIOW at 256 spp and 50 bounces has
 // pixels of > 10 000 sequential rays in a frame of ~5 000 rays per lane.  Tiles holding such a pixel (and at
-// least half the frame's longest pixel) are flagged; they are the front of the ranked head.
+// least half the frame's longest pixel) are flagged; in the sorted order they are its front.
 // ---------------------------------------------------------------------------------------
 void build_tile_order(const uint32_t* ray_sum, const uint32_t* longest, uint32_t n_tiles, const TileOrderParams& p, TileOrder* out) {
     TileOrder& o = *out;
     o = TileOrder();
     o.order.resize(n_tiles);
     const uint64_t sky_cost = (uint64_t)64 * p.sample_count * (1000 + p.sky_slack_permille) / 1000;
-    std::vector<uint8_t> where(n_tiles, 0);                                    // 0 raster part, 1 head, 2 sky first, 3 sky last
-    uint32_t k = 0;
-    if (p.sky_mode == 1u)
-        for (uint32_t tile = 0; tile < n_tiles; tile++)
-            if (ray_sum[tile] <= sky_cost) { where[tile] = 2; o.order[k++] = tile; }
-    if (p.sky_mode == 2u)
-        for (uint32_t tile = 0; tile < n_tiles; tile++)
-            if (ray_sum[tile] <= sky_cost) where[tile] = 3;
-    std::vector<uint64_t> keys;
-    for (uint32_t i = 0; i < n_tiles; i++)
-        if (where[i] == 0) keys.push_back(((uint64_t)(~(p.key_longest_pixel ? longest[i] : ray_sum[i])) << 32) | i);   // cost descending, index ascending
-    uint32_t head = (uint32_t)((uint64_t)keys.size() * p.head_permille / 1000u);
-    if (head > keys.size()) head = (uint32_t)keys.size();
-    std::nth_element(keys.begin(), keys.begin() + head, keys.end());
-    std::sort(keys.begin(), keys.begin() + head);                              // head: longest first
+    std::vector<uint64_t> keys;                                                // non-sky tiles: (~longest pixel, index)
     uint64_t sum = 0;
-    for (uint32_t i = 0; i < n_tiles; i++) { sum += ray_sum[i]; o.longest_pixel = longest[i] > o.longest_pixel ? longest[i] : o.longest_pixel; }
-    o.first_ranked = k;
-    if (p.key_longest_pixel && p.critical && p.grid_lanes != 0) {
+    for (uint32_t i = 0; i < n_tiles; i++) {
+        sum += ray_sum[i];
+        o.longest_pixel = longest[i] > o.longest_pixel ? longest[i] : o.longest_pixel;
+        if (ray_sum[i] > sky_cost) keys.push_back(((uint64_t)(~longest[i]) << 32) | i);
+    }
+    if (p.sorted) std::sort(keys.begin(), keys.end());                         // longest first, then by index
+    uint32_t k = 0;
+    for (uint64_t key : keys) o.order[k++] = (uint32_t)(key & 0xffffffffu);
+    for (uint32_t tile = 0; tile < n_tiles; tile++)                            // sky tiles: raster order
+        if (ray_sum[tile] <= sky_cost) o.order[k++] = tile;
+    o.n_lane = (uint32_t)((uint64_t)keys.size() * p.lane_permille / 1000u);
+    if (o.n_lane > keys.size()) o.n_lane = (uint32_t)keys.size();
+    if (p.sorted && p.critical && p.grid_lanes != 0) {
         const uint64_t per_lane = sum / p.grid_lanes;
         const uint64_t thr = per_lane / 2 > o.longest_pixel / 2 ? per_lane / 2 : o.longest_pixel / 2;
         if (o.longest_pixel >= per_lane / 2)
-            for (uint32_t i = 0; i < head && longest[(uint32_t)(keys[i] & 0xffffffffu)] >= thr; i++) o.n_critical++;
+            while (o.n_critical < keys.size() && longest[o.order[o.n_critical]] >= thr) o.n_critical++;
     }
-    for (uint32_t i = 0; i < head; i++) {
-        const uint32_t t = (uint32_t)(keys[i] & 0xffffffffu);
-        o.order[k++] = t;
-        where[t] = 1;
-    }
-    for (uint32_t tile = 0; tile < n_tiles; tile++)                            // the rest: raster order
-        if (where[tile] == 0) o.order[k++] = tile;
-    o.n_main = k;
-    for (uint32_t tile = 0; tile < n_tiles; tile++)                            // sky tiles: the drain queue
-        if (where[tile] == 3) o.order[k++] = tile;
 }
 
 }  // namespace brt
@@ -527,15 +510,15 @@ int32_t brt_host_material(const float* base_color_srgb3, float metallic, float p
 }
 
 int32_t brt_host_tile_order(const uint32_t* ray_sum, const uint32_t* longest_pixel, uint32_t n_tiles, uint32_t sample_count,
-                            uint64_t grid_lanes, uint32_t sky_mode, uint32_t head_permille, uint32_t* out_order, uint32_t* out_info4) {
-    if (!ray_sum || !longest_pixel || !out_order || !out_info4) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
+                            uint64_t grid_lanes, uint32_t sorted, uint32_t lane_permille, uint32_t* out_order, uint32_t* out_info3) {
+    if (!ray_sum || !longest_pixel || !out_order || !out_info3) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
     TileOrderParams tp{};
-    tp.sample_count = sample_count; tp.grid_lanes = grid_lanes; tp.key_longest_pixel = 1; tp.sky_mode = sky_mode;
-    tp.sky_slack_permille = 20; tp.head_permille = head_permille; tp.critical = 1;
+    tp.sample_count = sample_count; tp.grid_lanes = grid_lanes; tp.sorted = sorted; tp.sky_slack_permille = 20;
+    tp.lane_permille = lane_permille; tp.critical = 1;
     TileOrder to;
     build_tile_order(ray_sum, longest_pixel, n_tiles, tp, &to);
     std::memcpy(out_order, to.order.data(), (size_t)n_tiles * 4);
-    out_info4[0] = to.n_main; out_info4[1] = to.first_ranked; out_info4[2] = to.n_critical; out_info4[3] = to.longest_pixel;
+    out_info3[0] = to.n_lane; out_info3[1] = to.n_critical; out_info3[2] = to.longest_pixel;
     return BRT_OK;
 }
 

@@ -38,17 +38,15 @@ float tan_half_fov(float fov);
 struct TileOrderParams {
     uint32_t sample_count;       // samples per pixel of the measured frame
     uint64_t grid_lanes;         // lanes of the launch grid (CUs x threads per workgroup)
-    uint32_t key_longest_pixel;  // 1: rank tiles by their longest pixel, 0: by their ray sum
-    uint32_t sky_mode;           // 0: sky tiles stay in the raster part, 1: first, 2: last, as the drain queue
+    uint32_t sorted;             // 1: non-sky tiles by their longest pixel, longest first; 0: raster order
     uint32_t sky_slack_permille; // a tile is "sky" when it needed <= 64 * spp * (1 + slack) rays
-    uint32_t head_permille;      // share of the non-sky tiles that is ranked and goes first
+    uint32_t lane_permille;      // share of the non-sky tiles (the front of the order) that goes to the lane queue
     uint32_t critical;           // 1: mark critical tiles
 };
 struct TileOrder {
     std::vector<uint32_t> order; // order[k] = k-th tile to hand out
-    uint32_t n_main = 0;         // order[0 .. n_main) is the main queue, the rest the drain queue (sky tiles)
-    uint32_t first_ranked = 0;   // order[first_ranked .. first_ranked + n_critical) are the critical tiles
-    uint32_t n_critical = 0;
+    uint32_t n_lane = 0;         // order[0 .. n_lane) is the lane queue, the rest the tile queue
+    uint32_t n_critical = 0;     // order[0 .. n_critical) are the critical tiles
     uint32_t longest_pixel = 0;
 };
 void build_tile_order(const uint32_t* ray_sum, const uint32_t* longest, uint32_t n_tiles, const TileOrderParams& p, TileOrder* out);

@@ -181,13 +181,14 @@ int32_t brt_debug_profile(brt_ctx* ctx, uint64_t* out64);
 /* ---- host-only helpers (no GPU needed) --------------------------------------------- */
 
 /* The dispatch order brt_render derives from one frame's per-tile ray counts (sum and longest pixel of each
- * 8x8 tile): out_order[k] = k-th tile to hand out; out_info4 = {tiles of the main queue
- * (the rest, one-ray-per-sample "sky" tiles, form the drain queue when sky_mode is 2), index of the first
- * ranked tile, number of critical tiles from there, longest pixel}.  grid_lanes = CUs x threads per
- * workgroup.  No reference counterpart: the reference draws one fullscreen triangle (pipeline.rs:206-215). */
+ * 8x8 tile): out_order[k] = k-th tile to hand out -- the non-sky tiles (longest pixel
+ * first when `sorted`), then the one-ray-per-sample "sky" tiles; out_info3 = {tiles at the front that go to the
+ * lane queue (pixel by pixel to single lanes; the rest are handed out as whole tiles), critical tiles at the
+ * front, longest pixel}.  grid_lanes = CUs x threads per workgroup.  No reference counterpart: the reference
+ * draws one fullscreen triangle (pipeline.rs:206-215). */
 int32_t brt_host_tile_order(const uint32_t* ray_sum, const uint32_t* longest_pixel, uint32_t n_tiles, uint32_t sample_count,
-                            uint64_t grid_lanes, uint32_t sky_mode, uint32_t head_permille, uint32_t* out_order,
-                            uint32_t* out_info4);
+                            uint64_t grid_lanes, uint32_t sorted, uint32_t lane_permille, uint32_t* out_order,
+                            uint32_t* out_info3);
 
 /* Replaces: obvhs::ploc::build_ploc::<24>(aabbs, identity, SortPrecision::U64, 0) and the
  * flatten into BVHNode (extract.rs:315-332), including Model::aabb's 0.1 pad

@@ -225,18 +225,19 @@ def test_create_fails_loudly_without_a_gpu():
     assert e.value.code == -2 and "no CPU path" in e.value.text
 
 
-def _tile_order(ray_sum, longest, spp, grid_lanes, sky_mode=2, head_permille=100):
+def _tile_order(ray_sum, longest, spp, grid_lanes, sorted_=1, lane_permille=0):
     ray_sum = np.ascontiguousarray(ray_sum, np.uint32)
     longest = np.ascontiguousarray(longest, np.uint32)
     order = np.zeros(len(ray_sum), np.uint32)
-    info = np.zeros(4, np.uint32)
-    _lib.check(_lib.load().brt_host_tile_order(ray_sum.ctypes.data, longest.ctypes.data, len(ray_sum), spp, grid_lanes, sky_mode,
-                                               head_permille, order.ctypes.data, info.ctypes.data))
-    return order, dict(zip(("n_main", "first_ranked", "n_critical", "longest_pixel"), (int(x) for x in info)))
+    info = np.zeros(3, np.uint32)
+    _lib.check(_lib.load().brt_host_tile_order(ray_sum.ctypes.data, longest.ctypes.data, len(ray_sum), spp, grid_lanes, sorted_,
+                                               lane_permille, order.ctypes.data, info.ctypes.data))
+    return order, dict(zip(("n_lane", "n_critical", "longest_pixel"), (int(x) for x in info)))
 
 
 def test_dispatch_order_from_tile_costs():
-    """brt_host.cpp build_tile_order: longest chains first, the rest in raster order, sky tiles as the drain queue."""
+    """brt_host.cpp build_tile_order: non-sky tiles by their longest pixel (longest first), sky tiles last in raster
+    order; the front of the order can go to the lane queue; critical tiles are a prefix."""
     spp, n = 64, 200
     rng = np.random.default_rng(3)
     longest = rng.integers(64, 577, n).astype(np.uint32)           # rays of a tile's longest pixel (<= spp * 9)
@@ -247,27 +248,23 @@ def test_dispatch_order_from_tile_costs():
     order, info = _tile_order(ray_sum, longest, spp, lanes)
     assert sorted(order.tolist()) == list(range(n))                # a permutation
     n_sky = int(sky.sum())
-    assert info["n_main"] == n - n_sky and set(order[info["n_main"]:].tolist()) == set(np.flatnonzero(sky).tolist())
-    assert list(order[info["n_main"]:]) == sorted(order[info["n_main"]:])          # drain queue in raster order
-    head = (n - n_sky) * 100 // 1000
-    ranked = order[:head]
-    assert info["first_ranked"] == 0
-    assert list(longest[ranked]) == sorted(longest[ranked], reverse=True)           # longest pixel first
-    assert longest[ranked].min() >= np.sort(longest[~sky])[::-1][head - 1]          # ... and they are the top `head`
-    rest = order[head:info["n_main"]]
-    assert list(rest) == sorted(rest)                                               # raster order
-    assert info["longest_pixel"] == int(longest.max())
+    front, back = order[:n - n_sky], order[n - n_sky:]
+    assert set(back.tolist()) == set(np.flatnonzero(sky).tolist()) and list(back) == sorted(back)   # sky last, raster order
+    assert list(longest[front]) == sorted(longest[front], reverse=True)             # longest pixel first
+    assert info["n_lane"] == 0 and info["longest_pixel"] == int(longest.max())
+    # ties keep raster order
+    same = np.flatnonzero(longest[front][1:] == longest[front][:-1])
+    assert all(front[i] < front[i + 1] for i in same)
     # this frame is far longer than any pixel (sum / lanes >> longest): nothing is critical ...
     big = np.full(n, 4_000_000, np.uint32)
     assert _tile_order(big, longest, spp, 1000)[1]["n_critical"] == 0
-    # ... a frame whose lanes work through ~200 rays each while pixels need up to 576 has critical tiles:
-    # those of the ranked head with a pixel of at least half the longest one
-    order2, info2 = _tile_order(ray_sum, longest, spp, int(ray_sum.sum()) // 200, head_permille=500)
-    assert info2["n_critical"] > 0
-    crit = order2[info2["first_ranked"]:info2["first_ranked"] + info2["n_critical"]]
-    assert longest[crit].min() >= info2["longest_pixel"] // 2
-    # sky_mode 1: sky tiles first (raster order), then the ranked head; sky_mode 0: sky tiles stay in the raster part
-    order3, info3 = _tile_order(ray_sum, longest, spp, lanes, sky_mode=1)
-    assert info3["n_main"] == n and info3["first_ranked"] == n_sky and set(order3[:n_sky].tolist()) == set(np.flatnonzero(sky).tolist())
-    order4, info4 = _tile_order(ray_sum, longest, spp, lanes, sky_mode=0)
-    assert info4["n_main"] == n and info4["first_ranked"] == 0 and sorted(order4.tolist()) == list(range(n))
+    # ... a frame whose lanes work through ~200 rays each while pixels need up to 576 has critical tiles: the front
+    # of the order down to half the longest pixel
+    order2, info2 = _tile_order(ray_sum, longest, spp, int(ray_sum.sum()) // 200)
+    assert info2["n_critical"] > 0 and np.array_equal(order2, order)
+    assert longest[order2[:info2["n_critical"]]].min() >= info2["longest_pixel"] // 2
+    assert info2["n_critical"] == n - n_sky or longest[order2[info2["n_critical"]]] < info2["longest_pixel"] // 2
+    # a tenth of the non-sky tiles to the lane queue; raster order instead of the ranking
+    assert _tile_order(ray_sum, longest, spp, lanes, lane_permille=100)[1]["n_lane"] == (n - n_sky) // 10
+    order3, info3 = _tile_order(ray_sum, longest, spp, lanes, sorted_=0)
+    assert list(order3[:n - n_sky]) == sorted(order3[:n - n_sky]) and info3["n_critical"] == 0

@@ -560,8 +560,9 @@ def test_expensive_first_dispatch_never_changes_pixels(plugin, oracle):
         del os.environ["BRT_LPT"]
     # the ingredients of the order one by one: ranking key, sky tiles first, critical pixels (waves at raised
     # priority that stop taking pixels -- on a frame this small nearly every ranked tile is critical)
-    for env in ({"BRT_LPT_KEY": "0"}, {"BRT_LPT_SKY": "0"}, {"BRT_LPT_SKY": "1"}, {"BRT_LPT_SKY": "2", "BRT_DRAIN_DONATE": "0"}, {"BRT_CRIT": "0"}, {"BRT_LPT_HEAD_PERMILLE": "1000"},
-                {"BRT_LPT_HEAD_PERMILLE": "1000", "BRT_DRAIN_DONATE": "56"}):
+    for env in ({"BRT_LPT_SORT": "0"}, {"BRT_LPT_LANE_PERMILLE": "100"}, {"BRT_LPT_LANE_PERMILLE": "1000"},
+                {"BRT_LPT_LANE_PERMILLE": "500", "BRT_DRAIN_DONATE": "0"}, {"BRT_CRIT": "0"}, {"BRT_DRAIN_DONATE": "0"},
+                {"BRT_LPT_LANE_PERMILLE": "1000", "BRT_DRAIN_DONATE": "56"}):
         os.environ.update(env)
         try:
             plugin.node.write_buffers(brt.generate_scene(brt.SCENE_COVER, 5))    # forget the history ...
