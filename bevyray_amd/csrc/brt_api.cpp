@@ -156,7 +156,7 @@ int32_t make_frame_params(brt_ctx* ctx, const void* camera80, const void* window
     const uint32_t strips = (height + BRT_STRIP_ROWS - 1u) / BRT_STRIP_ROWS;
     fp.local_strips = (strips + n_parts - 1u) / n_parts;
     fp.queue_size = fp.local_strips * fp.tiles_x * 64u;
-    fp.queue_main = 0u;              // whole tiles for idle waves; attach_tile_order may give the front of the order to the lane queue
+    fp.queue_lane = 0u;              // whole tiles for idle waves; attach_tile_order may give the front of the order to the lane queue
     fp.bottom_up = env_u32("BRT_BOTTOM_UP", 0);
     fp.refill_min = env_u32("BRT_REFILL_MIN", 1);
     if (fp.refill_min < 1u) fp.refill_min = 1u;
@@ -248,26 +248,12 @@ bool is_pinned(const brt_ctx* ctx, const void* p, size_t bytes) {
     return false;
 }
 
-// Dispatch order of the 8x8 tiles.  A pixel is one sequential chain of samples (the reference threads
-// one RNG state through them), so (1) a frame ends when its slowest pixels end -- a tile that needs
-// many rays must not be handed out late -- and (2) a lane that takes a one-ray-per-sample "sky" pixel
-// while its wave-mates walk the scene pays their round time for each of its samples.  The cost of a
-// tile is not known in advance, but a renderer draws nearly the same frame again and again: the kernel
-// measures the rays each tile needed (one atomic per finished pixel, every kLptRefresh-th frame of a
-// view) and the next frames hand out
-//   first   the sky tiles, in raster order: whole waves of them, each done in 64 short rounds
-//           (cover frame 18.9 -> 18.4 ms);
-//   then    the tenth of the other tiles that hold the longest pixel chains (one rank's share of the
-//           frame: 1/2 16.2 -> 14.2 ms, 1/4 11.9 -> 10.3 ms; ranking by the longest pixel instead of the
-//           tile's ray sum: cover frame 18.2 -> 17.9 ms);
-//   then    the rest in raster order.
-// Measured and rejected: a FULLY sorted order -- the waves of a SIMD then run the same phase at the same
-// time (all in the walk, then all in the shading code) and compete for the same issue ports: +6..11 %
-// time at equal instruction counts; raster order lets them drift apart.  The cheapest tiles LAST: they
-// are dropped into waves that still carry expensive pixels (+1..3 ms).
-// Pixels never change, only the queue order does.
-// BRT_LPT=0 disables; BRT_LPT_HEAD_PERMILLE sets the head size (default 100); BRT_LPT_SKY_FIRST=0
-// keeps the sky tiles in the raster part.
+// Dispatch order of the 8x8 tiles (brt_host.cpp build_tile_order has the rule).  The cost of a tile is not
+// known in advance, but a renderer draws nearly the same frame again and again: the kernel measures the rays
+// each tile needed (sum and longest pixel: two atomics per finished pixel, every kLptRefresh-th frame of a
+// view) and the next frames use the order built from that.  Pixels never change, only the queue order does.
+// BRT_LPT=0 disables (raster order); BRT_LPT_SORT, BRT_LPT_LANE_PERMILLE, BRT_LPT_SKY_SLACK, BRT_CRIT: see
+// update_tile_order.
 constexpr uint32_t kLptRefresh = 16;
 bool lpt_enabled() { return env_u32("BRT_LPT", 1) != 0; }
 
@@ -288,7 +274,7 @@ int32_t attach_tile_order(brt_ctx* ctx, DeviceCtx& dc, FrameParams& fp, hipStrea
     const bool match = dc.order_valid && std::memcmp(key, dc.order_key, sizeof key) == 0;
     if (match) {
         fp.tile_order = dc.d_tile_order;
-        fp.queue_main = dc.order_lane * 64u;
+        fp.queue_lane = dc.order_lane * 64u;
         fp.crit_begin = 0u;
         fp.crit_end = dc.order_crit * 64u;
     }

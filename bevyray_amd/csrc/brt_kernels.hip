@@ -12,13 +12,14 @@
 //       reference threads ONE RNG state through all samples of a pixel
 //       (raytrace.wgsl:161-163): the samples of a pixel are sequentially dependent, the
 //       pixels are not.
-//     * Finished lanes are refilled from a global pixel queue: __ballot of the empty lanes,
-//       one wave-aggregated atomicAdd, mbcnt prefix sum to hand out consecutive queue slots.
-//       Queue slots map to 8x8 pixel tiles so that a wave starts on coherent primary rays; the
-//       ORDER of the tiles comes from the previous frame's ray counts (brt_api.cpp).
-//     * When the queue is empty the thinning waves of a workgroup hand their paths to the
-//       others through an LDS pool ("drain pool" below); waves that hold one of the frame's
-//       longest pixel chains run at raised priority and take no new pixels.
+//     * A wave that has nothing left takes the next 8x8 tile of the tile queue (one atomicAdd per
+//       tile): 64 neighbouring pixels, coherent primary rays.  The ORDER of the tiles comes from the
+//       previous frame's ray counts (brt_host.cpp build_tile_order).  Optionally the front of the
+//       order is handed out pixel by pixel to single free lanes instead (the lane queue: __ballot of
+//       the free lanes, mbcnt ranks, slots taken from a per-workgroup batch in LDS).
+//     * A wave that has thinned to `drain_donate` live paths hands them to the other waves of its
+//       workgroup through an LDS pool ("drain pool" below) and takes its next tile; waves that hold
+//       one of the frame's longest pixel chains run at raised priority and take nothing new.
 //     * No ray state ever goes to HBM; the only HBM traffic is the scene load per workgroup
 //       and one 16-byte store per pixel.
 //     * Bound by instruction issue under divergence, not by memory: the
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     unsigned long long t_mark = 0, ticks_refill = 0, ticks_walk = 0, ticks_shade = 0, ticks_pre = 0;   // phase times of this wave
     if (COUNTERS) t_start = t_mark = wall_clock64();
 
-    bool sky_done = false;            // the drain queue (FrameParams::queue_main..queue_size) is empty
+    bool tiles_done = false;          // the tile queue (slots FrameParams::queue_lane .. queue_size) is empty
     // lane takes queue slot q of `tile`
     auto begin_pixel = [&](uint32_t q, uint32_t tile) {
         const PixelCoord c = slot_to_pixel(fp, q, tile);
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                 if (lo == hi && !done) {
                     // guided: the batches shrink with what is left of the queue (judged from this workgroup's last
                     // batch), down to single tiles, so that no workgroup sits on a big share when the queue runs dry
-                    const uint32_t left = fp.queue_main > bbase ? fp.queue_main - bbase : 0u;
+                    const uint32_t left = fp.queue_lane > bbase ? fp.queue_lane - bbase : 0u;
                     uint32_t batch = (left / (gridDim.x * 4u)) & ~63u;
                     batch = batch > wgq_batch ? wgq_batch : (batch < 64u ? 64u : batch);
                     // single tiles until the queue is past the CRITICAL tiles: the waves that carry them run at raised
@@ -316,12 +317,12 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                     if (lane == 0) b = atomicAdd(queue_counter, batch);
                     b = (uint32_t)__shfl((int)b, 0, 64);
                     bbase = b;
-                    lo = b < fp.queue_main ? b : fp.queue_main;
-                    hi = b + batch < fp.queue_main ? b + batch : fp.queue_main;
+                    lo = b < fp.queue_lane ? b : fp.queue_lane;
+                    hi = b + batch < fp.queue_lane ? b + batch : fp.queue_lane;
                     if (hi < lo) hi = lo;
                     done = lo == hi;
                     const uint32_t ti = (b >> 6) + lane;
-                    if (lane < (batch >> 6) && ti < (fp.queue_main >> 6)) wgq[8u + lane] = slot_tile(fp, ti);
+                    if (lane < (batch >> 6) && ti < (fp.queue_lane >> 6)) wgq[8u + lane] = slot_tile(fp, ti);
                     if (lane == 0) { wgq[2] = hi; wgq[3] = bbase; wgq[4] = done ? 1u : 0u; }
                 }
                 const uint32_t avail = hi - lo;
@@ -343,14 +344,14 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                 }
             }
         }
-        // ---- nothing left to do and the main queue is empty: a whole tile of the drain queue (sky pixels) ----
-        if (fp.queue_main != fp.queue_size && !sky_done && !wave_crit && __ballot(active) == 0ull &&
+        // ---- nothing left to do (and the lane queue, if any, is empty): the next whole tile ----
+        if (fp.queue_lane != fp.queue_size && !tiles_done && !wave_crit && __ballot(active) == 0ull &&
             __ballot(!exhausted) == 0ull) {
             uint32_t b = 0;
             if (lane == 0) b = atomicAdd(queue_counter + 1, 64u);
-            b = fp.queue_main + (uint32_t)__shfl((int)b, 0, 64);
+            b = fp.queue_lane + (uint32_t)__shfl((int)b, 0, 64);
             if (b < fp.queue_size) begin_pixel(b + lane, slot_tile(fp, b >> 6));
-            else sky_done = true;
+            else tiles_done = true;
         }
         if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_refill += now - t_mark; t_mark = now; }
         // ---- drain: hand the paths over / take paths over / leave (see "drain pool" above) ----
@@ -377,8 +378,8 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                         rec[5] = make_float4(tput.z, __uint_as_float(bounce), first_depth, __uint_as_float(crit ? 1u : 0u));
                         active = false;
                     }
-                    // (while the drain queue has tiles the wave stays: it takes one next round)
-                    const bool stay = fp.queue_main != fp.queue_size && !sky_done;
+                    // (while the tile queue has tiles the wave stays: it takes one next round)
+                    const bool stay = fp.queue_lane != fp.queue_size && !tiles_done;
                     if (lane == 0) { pool_ctl[1] = count + live; if (!stay) pool_ctl[2] = alive - 1u; }
                     leave = !stay;
                 } else if (count != 0u && live < 64u) {
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                         active = true; in_flight = false; exhausted = true;
                     }
                     if (lane == 0) pool_ctl[1] = count - k;
-                } else if (live == 0u && count == 0u && (fp.queue_main == fp.queue_size || sky_done)) {
+                } else if (live == 0u && count == 0u && (fp.queue_lane == fp.queue_size || tiles_done)) {
                     if (lane == 0) pool_ctl[2] = alive - 1u;
                     leave = true;
                 }
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             }
             if (leave) break;
             finish_walks = (uint32_t)__popcll(__ballot(active)) <= fp.drain_donate;
-        } else if (__ballot(active) == 0 && (fp.queue_main == fp.queue_size || sky_done || __ballot(!exhausted) != 0ull)) {
+        } else if (__ballot(active) == 0 && (fp.queue_lane == fp.queue_size || tiles_done || __ballot(!exhausted) != 0ull)) {
             break;
         }
         if (__ballot(active) == 0) continue;      // (pool on) nothing live but paths may still arrive

@@ -156,10 +156,10 @@ struct FrameParams {
     uint32_t tiles_x;                // ceil(width / 8)
     uint32_t local_strips;           // strips owned by this part (padded count)
     uint32_t queue_size;             // local_strips * tiles_x * 64
-    // Slots [0, queue_main) are the main queue (any free lane takes the next one); slots [queue_main, queue_size)
-    // are whole tiles of one-ray-per-sample ("sky") pixels, taken one tile at a time by a wave that has nothing
-    // else left -- they fill the drain instead of delaying the start.  queue_main == queue_size: no such tiles.
-    uint32_t queue_main;
+    // Slots [0, queue_lane) are the lane queue (any free lane takes the next pixel); slots [queue_lane, queue_size)
+    // are the tile queue: whole 8x8 tiles, taken one at a time by a wave that has nothing left.  Default:
+    // queue_lane == 0, every tile goes through the tile queue.
+    uint32_t queue_lane;
     // Pixels are independent but each is ONE sequential chain of sample_count paths (the
     // reference threads one RNG state through them), so the frame ends when the slowest pixels
     // end: hand out the (usually) expensive ones first.  With the usual "up = +Y" camera the
