@@ -168,6 +168,8 @@ int32_t make_frame_params(brt_ctx* ctx, const void* camera80, const void* window
     fp.drain_donate = env_u32("BRT_DRAIN_DONATE", 40);
     if (fp.drain_donate > 56u) fp.drain_donate = 56u;
     fp.pool_cap = 0;               // set by launch_part from the launch plan
+    fp.pool_adopt = env_u32("BRT_POOL_ADOPT", 56);
+    if (fp.pool_adopt > 63u) fp.pool_adopt = 63u;
     fp.crit_begin = fp.crit_end = 0;   // set by attach_tile_order
     fp.wgq_batch = env_u32("BRT_WGQ_BATCH", 0) & ~63u;
     if (fp.wgq_batch > 512u) fp.wgq_batch = 512u;

@@ -362,7 +362,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             const bool quiet = __ballot(in_flight) == 0ull;              // no suspended walk: every live path is between two rays
             const bool thin = live != 0u && live <= fp.drain_donate;
             bool leave = false;
-            if (live == 0u || (thin && quiet && pool_peek(pool_ctl, 2) > 1u) || (live <= 56u && pool_peek(pool_ctl, 1) != 0u)) {
+            if (live == 0u || (thin && quiet && pool_peek(pool_ctl, 2) > 1u) || (live <= fp.pool_adopt && pool_peek(pool_ctl, 1) != 0u)) {
                 pool_lock(pool_ctl, lane);
                 const uint32_t count = pool_peek(pool_ctl, 1), alive = pool_peek(pool_ctl, 2);
                 if (thin && quiet && alive > 1u && count + live <= fp.pool_cap) {

@@ -171,6 +171,7 @@ struct FrameParams {
     // Drain (pixel queue empty): a wave with <= drain_donate live paths hands them to the workgroup's LDS pool
     // (pool_cap records) and ends; waves with idle lanes take them over.  pool_cap == 0: off.
     uint32_t drain_donate, pool_cap;
+    uint32_t pool_adopt;             // a wave takes paths from the pool when it has at most this many live ones
     // Queue slots [crit_begin, crit_end) (the tiles with the longest pixel chains, when tile_order is set) are
     // CRITICAL: a wave that holds one of their pixels raises its issue priority (s_setprio), because the
     // frame cannot end before its longest sequential chain has.

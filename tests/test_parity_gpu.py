@@ -436,6 +436,8 @@ def test_sample_count_zero_is_zero_over_zero(plugin, oracle, level):
     # workgroup share of the pixel queue: one tile at a time, the maximum, with other workgroup shapes
     {"BRT_WGQ_BATCH": "64"}, {"BRT_WGQ_BATCH": "512"}, {"BRT_WGQ_BATCH": "192", "BRT_BLOCK_THREADS": "256"},
     {"BRT_WGQ_BATCH": "512", "BRT_FORCE_GLOBAL_SCENE": "1", "BRT_REFILL_MIN": "5"},
+    # who takes pooled paths over: nearly full waves too, only thin ones (thinner than the donors: paths wait in the pool)
+    {"BRT_POOL_ADOPT": "62"}, {"BRT_POOL_ADOPT": "20", "BRT_DRAIN_DONATE": "40"}, {"BRT_POOL_ADOPT": "0"},
 ])
 def test_tuning_knobs_do_not_change_results(plugin, oracle, env):
     b = brt.generate_scene(brt.SCENE_COVER, 1)
