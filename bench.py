@@ -2,7 +2,7 @@
 """Headline benchmark: Mrays/s on the README cover scene at 1920x1080, 64 spp, 8 bounces
 (BASELINE.json metric, configs[1]).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -10,24 +10,37 @@ A step = one full frame: every rank traces its interleaved row strips with the p
 kernel (scene already resident in HBM), the tiles meet on rank 0 in ONE gather over RCCL, and
 rank 0 de-interleaves.  The frame is fixed while N grows, so scaling is "strong".
 Rank 0 prints one JSON line.  `value` = rays of all ranks / max-over-ranks wall time of the K
-timed steps.  `roofline.achieved` = algorithmic bytes of one launch (SURVEY.md 8(d) formula,
-from exact device counters collected OUTSIDE the timed region) / the trace kernel's mean
-launch duration, measured with HIP events on the kernel's own stream inside the timed steps.
+timed steps.
+
+`roofline` names the resource that binds the trace kernel: the f32 vector pipes (VALU
+lane-cycles).  achieved = VALU instructions x average active lanes / kernel time, peak = 256 CUs
+x 4 SIMDs x 32 lanes x 2.4 GHz; the instruction and lane counts come from a rocprofv3 --pmc
+pass over the same workload made by THIS run after the timed region (fallback: the committed
+profiles/pmc_summary.json, only if it was taken on the same device code), the kernel time from
+HIP events on the kernel's own stream inside the timed steps.  The SURVEY.md 8(d) algorithmic
+bytes and the measured HBM bytes are carried as secondary keys: the scene lives in LDS and ray
+state in registers, so HBM is idle and is not the bound.
 `cpu_baseline` = the C oracle (a port, not the reference: the reference cannot be built here)
 on this host's cores over a bounded, evenly spread row sample of the same frame.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+N_CUS, SIMDS_PER_CU, SIMD_LANES, CLOCK_HZ = 256, 4, 32, 2.4e9
+VALU_PEAK_TLANEOPS = N_CUS * SIMDS_PER_CU * SIMD_LANES * CLOCK_HZ / 1e12   # 78.6: one f32 lane-op per lane per cycle
 
 WORKLOAD = dict(width=1920, height=1080, spp=64, bounces=8, scene_seed=1, random_seed=0.5)
+WORKLOAD4 = dict(width=3840, height=2160, spp=1024, bounces=8, scene_seed=1, random_seed=0.5)   # BASELINE.json configs[3]
+PMC_WORKLOAD_TAG = "cover_1920x1080_64spp_8b"
 
 
 def bytes_alg(stats, width, rows):
@@ -36,147 +49,339 @@ def bytes_alg(stats, width, rows):
             stats["sphere_tests"] * 32 + stats["hits"] * 32 + width * rows * 16)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)   # the first ~7 frames after idle run 4 % slower (clock ramp)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time target of the CPU baseline sample")
-    args = ap.parse_args()
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc pass (N = 1 only)")
+    ap.add_argument("--no-extras", action="store_true", help="skip first-frame / reseeded / config-4 measurements")
+    return ap.parse_args(argv)
 
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks as CHILD processes (this parent has not
+    imported torch or touched HIP, and never execs), relay rank 0's JSON line, exit with their code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL (see the environment notes)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    if proc.returncode == 0 and line is None:
+        print("bench.py: the ranks ended without a JSON line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
+def load_tracer():
+    """(plugin, node, device, backend).  The product tracer needs an MI355X; BRT_BENCH_TRACER=module:factory
+    swaps in a stand-in (tests/stub_tracer.py: CPU tensors over gloo) so that the launch / gather / reporting
+    logic of this file can be tested without a GPU.  A stub run says so in its JSON line (`data`)."""
+    hook = os.environ.get("BRT_BENCH_TRACER")
+    if hook:
+        mod, fn = hook.split(":")
+        return getattr(__import__(mod), fn)
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
-    import numpy as np
     import bevyray_amd as brt
-    from bevyray_amd.parallel import frame_rows_of_part, gather_frame
+    from bevyray_amd.parallel import end_of_frame, frame_rows_of_part, gather_frame
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device (there is no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    stub = load_tracer()
+    if stub is None:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: no HIP device (there is no CPU path)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        backend = "nccl"
+    else:
+        dev = torch.device("cpu")
+        backend = "gloo"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    W, H, spp, bounces = WORKLOAD["width"], WORKLOAD["height"], WORKLOAD["spp"], WORKLOAD["bounces"]
-    buffers = brt.generate_scene(brt.SCENE_COVER, WORKLOAD["scene_seed"])
-    lvl, cam, win = brt.cover_camera(W, H, spp, bounces, brt.Raytracing.Pure, WORKLOAD["random_seed"])
-
-    plugin = brt.RaytracePlugin([local_rank])
+    plugin = brt.RaytracePlugin([local_rank]) if stub is None else stub(rank, world)
     node = plugin.node
-    node.write_buffers(buffers)             # scene resident in HBM before anything is timed
-    rows = brt.tile_rows(H, world)
-    tile = torch.zeros((rows, W, 4), dtype=torch.float32, device=dev)
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
-    gather_events = []
+    def all_max(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    def step(flags=0, timed=False):
-        st = node.render_part_device(lvl, cam, win, W, H, rank, world, tile.data_ptr(), flags=flags)  # synchronous
-        if timed:   # gather + de-interleave run on torch's current stream: time them there
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        frame = gather_frame(tile, H, rank, world, node=node)
-        if timed:
-            e1.record()
-            gather_events.append((e0, e1))
-        return st, frame
+    def all_sum(x):
+        t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
 
-    # exact counters for the algorithmic-bytes figure (deterministic; outside the timed region)
-    counted, frame = step(brt.FLAG_COUNTERS)
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    kernel_ms = []
-    rays = 0
-    for _ in range(args.steps):
-        st, frame = step(timed=True)
-        kernel_ms.append(st["kernel_ms"])
-        rays += st["rays"]
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def all_list(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        if world == 1:
+            return [float(x)]
+        out = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    r = torch.tensor([float(rays)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-    elapsed, total_rays = float(t.item()), float(r.item())
+    def run_workload(wl, scene_kind, steps, warmup, counters=True):
+        """Times `steps` frames of one workload; returns a dict (meaningful on every rank after the reductions)."""
+        W, H, spp, bounces = wl["width"], wl["height"], wl["spp"], wl["bounces"]
+        buffers = brt.generate_scene(scene_kind, wl["scene_seed"])
+        lvl, cam, win = brt.cover_camera(W, H, spp, bounces, brt.Raytracing.Pure, wl["random_seed"])
+        node.write_buffers(buffers)             # scene resident in HBM before anything is timed
+        rows = brt.tile_rows(H, world)
+        tile = torch.zeros((rows, W, 4), dtype=torch.float32, device=dev)
+        sync()                                  # the zero fill ran on torch's stream, the trace kernel has its own
+        gather_events = []
 
-    gather_ms = float(np.mean([a.elapsed_time(b) for a, b in gather_events])) if gather_events else 0.0
+        def step(flags=0, timed=False, window=win):
+            # the trace kernel runs on the context's own stream and the call returns when it is done
+            st = node.render_part_device(lvl, cam, window, W, H, rank, world, tile.data_ptr(), flags=flags)
+            if timed and dev.type == "cuda":   # gather + de-interleave run on torch's current stream: time them there
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            frame = gather_frame(tile, H, rank, world, node=node)
+            if timed and dev.type == "cuda":
+                e1.record()
+                gather_events.append((e0, e1))
+            end_of_frame(tile)                  # the RCCL send / the copy kernel are done before `tile` is reused
+            return st, frame
+
+        counted, frame = step(brt.FLAG_COUNTERS) if counters else (None, None)
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        kernel_ms, rays = [], 0
+        for _ in range(steps):
+            st, frame = step(timed=True)
+            kernel_ms.append(st["kernel_ms"])
+            rays += st["rays"]
+        barrier()
+        elapsed = all_max(time.perf_counter() - t0)
+        total_rays = all_sum(rays)
+        res = {"W": W, "H": H, "spp": spp, "bounces": bounces, "buffers": buffers, "lvl": lvl, "cam": cam, "win": win,
+               "frame": frame, "counted": counted, "elapsed": elapsed, "total_rays": total_rays, "steps": steps,
+               "kernel_ms": float(np.mean(kernel_ms)), "kernel_ms_per_rank": all_list(float(np.mean(kernel_ms))),
+               "rays_per_rank": all_list(rays / steps),
+               "gather_ms": float(np.mean([a.elapsed_time(b) for a, b in gather_events])) if gather_events else 0.0,
+               "step": step, "tile": tile, "last_stats": st}
+        return res
+
+    head = run_workload(WORKLOAD, brt.SCENE_COVER, args.steps, args.warmup)
+    W, H, spp = head["W"], head["H"], head["spp"]
+
+    # ---- outside the timed region: what a frame costs when the view or the seed is new ----------------
+    extras = {}
+    if not args.no_extras and stub is None:
+        step = head["step"]
+        # (a) a new seed every frame, as the reference draws one (extract.rs:72-73); the dispatch order of the
+        #     view is reused (it does not depend on the seed)
+        ks = []
+        for i in range(8):
+            w2 = brt.WindowExtract.extract_component(H, 0.05 + 0.11 * i)
+            ks.append(step(window=w2)[0]["kernel_ms"])
+        extras["reseeded_ms"] = [round(all_max(k), 3) for k in ks]
+        # (b) the first frame of a view: new scene epoch -> no history
+        other = brt.generate_scene(brt.SCENE_COVER, 2)
+        node.write_buffers(other)
+        node.write_buffers(head["buffers"])
+        first = step()[0]["kernel_ms"]
+        second = step()[0]["kernel_ms"]
+        extras["first_frame_ms"] = round(all_max(first), 3)
+        extras["second_frame_ms"] = round(all_max(second), 3)
+    cfg4 = None
+    if not args.no_extras and world > 1:
+        # config 2's longest pixel chains take ~5 ms whatever N is (DESIGN.md section 7); BASELINE.json's own
+        # multi-GPU config is 4K x 1024 spp, reported here beside the headline
+        r4 = run_workload(WORKLOAD4, brt.SCENE_RTIOW_FINAL if stub is None else brt.SCENE_COVER, 2, 1, counters=False)
+        cfg4 = {"workload": "RTIOW random spheres 3840x2160, 1024 spp, 8 bounces (BASELINE.json configs[3])",
+                "value": r4["total_rays"] / r4["elapsed"] / 1e6, "unit": "Mrays/s", "ms_per_step": r4["elapsed"] / r4["steps"] * 1e3,
+                "steps": r4["steps"], "warmup": 1, "kernel_ms_per_rank": r4["kernel_ms_per_rank"], "gather_ms": r4["gather_ms"]}
+
     if rank == 0:
+        counted = head["counted"]
         my_rows = int((frame_rows_of_part(H, 0, world) >= 0).sum())
         alg = bytes_alg(counted, W, my_rows)
-        mean_kernel_ms = float(np.mean(kernel_ms))
-        achieved = alg / (mean_kernel_ms * 1e-3) / 1e9
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc_path):
-            try:
-                pmc = json.load(open(pmc_path))
-                if pmc.get("n_gpus") == world and pmc.get("workload") == "cover_1920x1080_64spp_8b":
-                    traffic = pmc.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # what actually bounds the kernel: wave-level instruction issue.  Instruction counts per launch from the
-        # committed rocprofv3 --pmc summary of this workload (they do not depend on the clock), time measured live.
-        issue = None
-        sq_path = os.path.join(ROOT, "profiles", "r01", "final_pmc_summary.json")
-        if world == 1 and os.path.exists(sq_path):
-            try:
-                sq = json.load(open(sq_path))["k_trace_persistent (timing build)"]
-                n_inst = sum(sq[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH"))
-                simd_cycles = mean_kernel_ms * 1e-3 * 2.4e9 * 256 * 4
-                issue = {"instructions_per_launch": n_inst, "valu_per_launch": sq["SQ_INSTS_VALU"],
-                         "instructions_per_simd_cycle": n_inst / simd_cycles,
-                         "peak_valu_per_simd_cycle": 0.5,
-                         "active_lanes_per_valu": sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"]
-                         if sq.get("SQ_ACTIVE_INST_VALU") else None,
-                         "source": "profiles/r01/final_pmc_summary.json (rocprofv3 --pmc, separate passes), 2.4 GHz, 1024 SIMDs"}
-            except Exception:
-                issue = None
+        kernel_ms = head["kernel_ms"]
+        roof = roofline_block(args, world, stub is not None, kernel_ms, alg)
         out = {
-            "metric": "Mrays/s at 1920x1080, 64 spp, 8 bounces", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "metric": "Mrays/s at 1920x1080, 64 spp, 8 bounces", "value": head["total_rays"] / head["elapsed"] / 1e6,
+            "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if stub is None else "synthetic (STUB tracer: no rays traced)",
             "config": {"workload": "README cover scene 1920x1080, 64 spp, 8 bounces (BASELINE.json configs[1])",
-                       "spheres": int(len(buffers.models)), "bvh_nodes": int(len(buffers.bvh)), "scene_seed": WORKLOAD["scene_seed"],
-                       "random_seed": WORKLOAD["random_seed"], "level": "Pure",
+                       "spheres": int(len(head["buffers"].models)), "bvh_nodes": int(len(head["buffers"].bvh)),
+                       "scene_seed": WORKLOAD["scene_seed"], "random_seed": WORKLOAD["random_seed"], "level": "Pure",
                        "parallelism": f"interleaved 8-row strips over {world} GPU(s), one RCCL gather per frame"},
-            "rays_per_frame": total_rays / args.steps, "paths_per_frame": W * H * spp,
-            "mpaths_per_s": W * H * spp * args.steps / elapsed / 1e6,
-            "gather_ms": gather_ms,   # rank 0: RCCL gather (N > 1) + de-interleave copy kernel, per frame
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_trace_persistent", "kernel_ms": mean_kernel_ms, "algorithmic_bytes_per_launch": alg,
-                         "note": "scene is LDS resident and ray state lives in registers: HBM traffic is the scene load "
-                                 "per workgroup + one 16-B store per pixel, the kernel is bound by VALU/scalar issue "
-                                 "under divergence (DESIGN.md section 5), so achieved algorithmic bytes exceed the HBM peak",
-                         "issue": issue},
+            "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
+            "rays_per_frame": head["total_rays"] / args.steps, "paths_per_frame": W * H * spp,
+            "mpaths_per_s": W * H * spp * args.steps / head["elapsed"] / 1e6,
+            "kernel_ms_per_rank": head["kernel_ms_per_rank"], "rays_per_frame_per_rank": head["rays_per_rank"],
+            "gather_ms": head["gather_ms"],   # rank 0: RCCL gather (N > 1) + de-interleave copy kernel, per frame
+            "roofline": roof,
             "kernel": {"lds_bytes": counted["lds_bytes"], "scene_in_lds": counted["scene_in_lds"],
                        "workgroups": counted["n_workgroups"], "threads": counted["threads_per_workgroup"]},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(buffers, lvl, cam, win, W, H, frame, args.cpu_seconds)
+        out.update(extras)
+        if cfg4 is not None:
+            out["config4"] = cfg4
+        if world == 1 and not args.no_cpu_baseline and stub is None:
+            out["cpu_baseline"] = cpu_baseline(head["buffers"], head["lvl"], head["cam"], head["win"], W, H, head["frame"],
+                                               args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     plugin.close()
+
+
+# ---- roofline ---------------------------------------------------------------------------------------------
+
+PMC_PASSES = [
+    "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES",
+    "FETCH_SIZE",
+    "WRITE_SIZE",
+]
+
+
+def live_pmc(timeout_s=150.0):
+    """rocprofv3 --pmc over scripts/pmc_frame.py (the headline workload, torch-free), one child process per
+    counter set (SQ: 8 slots; FETCH_SIZE and WRITE_SIZE do not fit one TCC pass).  Returns {counter: value of
+    the LAST dispatch of the production kernel} or None.  The program comes directly after `--` (no shell, no
+    env wrapper: the profiler has initialised the GPU by then)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="brt_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", BRT_NO_TORCH="1")
+    got = {}
+    t_end = time.time() + timeout_s
+    try:
+        for i, counters in enumerate(PMC_PASSES):
+            left = t_end - time.time()
+            if left < 10:
+                return (got or None), "time budget of the PMC passes used up"
+            out_dir = os.path.join(tmp, f"pass{i}")
+            cmd = [rocprof, "--pmc"] + counters.split() + ["--output-format", "csv", "-d", out_dir, "--",
+                                                           sys.executable, os.path.join(ROOT, "scripts", "pmc_frame.py")]
+            try:
+                proc = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                                      timeout=left)
+            except subprocess.TimeoutExpired:
+                return (got or None), f"pass {i} timed out"
+            if proc.returncode != 0:
+                return (got or None), f"pass {i}: rocprofv3 exit {proc.returncode}: {proc.stdout[-300:]}"
+            per = {}
+            for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "k_trace_persistent" not in r["Kernel_Name"]:
+                        continue
+                    d = per.setdefault(int(r["Dispatch_Id"]), {})
+                    d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            if not per:
+                return (got or None), f"pass {i}: no k_trace_persistent dispatch in the counter CSV"
+            got.update(per[max(per)])
+        return got, None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def roofline_block(args, world, is_stub, kernel_ms, alg):
+    from bevyray_amd import _lib
+    code_hash = None if is_stub else _lib.kernel_code_hash()
+    pmc, source, why = None, None, None
+    if world == 1 and not is_stub and not args.no_pmc:
+        pmc, why = live_pmc()
+        if pmc and "SQ_INSTS_VALU" in pmc:
+            source = "live: rocprofv3 --pmc passes made by this run after the timed region (scripts/pmc_frame.py, last dispatch)"
+        else:
+            pmc = None
+    if pmc is None and world == 1 and not is_stub:
+        path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        try:
+            rec = json.load(open(path))
+            if rec.get("workload") == PMC_WORKLOAD_TAG and rec.get("kernel_code_hash") == code_hash:
+                pmc = rec["counters"]
+                source = f"profiles/pmc_summary.json (same device code {code_hash})"
+            else:
+                why = (why + "; " if why else "") + f"profiles/pmc_summary.json was taken on device code {rec.get('kernel_code_hash')}, this is {code_hash}"
+        except Exception as e:   # noqa: BLE001
+            why = (why + "; " if why else "") + f"profiles/pmc_summary.json: {e}"
+    secs = kernel_ms * 1e-3
+    roof = {"bound": "valu", "achieved": None, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "frac": None, "traffic": None,
+            "kernel": "k_trace_persistent", "kernel_ms": kernel_ms, "kernel_code_hash": code_hash,
+            "algorithmic_bytes_per_launch": alg, "algorithmic_GBs": alg / secs / 1e9 if secs > 0 else None,
+            "hbm_peak_GBs": HBM_PEAK_GBS, "hbm_frac_measured": None,
+            "note": "bound = f32 vector pipes: achieved = VALU instructions x mean active lanes / kernel time; peak = 256 CUs x 4 SIMDs "
+                    "x 32 lanes x 2.4 GHz (a wave64 VALU instruction issues over 2 cycles; v_sqrt/v_rcp/v_mul_lo_u32 over 8). The "
+                    "scene is LDS resident and ray state lives in registers, so HBM only sees the scene load per workgroup and "
+                    "one 16-B store per pixel: `traffic` (measured HBM bytes) / kernel time is `hbm_frac_measured` of the 8 TB/s "
+                    "peak; the SURVEY 8(d) algorithmic bytes are informational (they are served from LDS/registers)",
+            "counter_source": source, "counter_note": why}
+    if pmc:
+        valu, act, thr = pmc.get("SQ_INSTS_VALU"), pmc.get("SQ_ACTIVE_INST_VALU"), pmc.get("SQ_THREAD_CYCLES_VALU")
+        lanes = thr / act if act else None
+        if valu and lanes and secs > 0:
+            roof["achieved"] = valu * lanes / secs / 1e12
+            roof["frac"] = roof["achieved"] / VALU_PEAK_TLANEOPS
+            simd_cycles = secs * CLOCK_HZ * N_CUS * SIMDS_PER_CU
+            n_inst = sum(pmc.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH"))
+            roof["issue"] = {"valu_instructions_per_launch": valu, "instructions_per_launch": n_inst,
+                             "active_lanes_per_valu": lanes, "valu_per_simd_cycle": valu / simd_cycles,
+                             "valu_issue_frac": valu / simd_cycles / 0.5, "instructions_per_simd_cycle": n_inst / simd_cycles}
+        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            # rocprofv3 reports KB; on gfx950 FETCH_SIZE counts 64 B per 128-B request: doubled (MI355X_MICROARCH.md, HBM)
+            roof["traffic"] = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+            roof["hbm_frac_measured"] = roof["traffic"] / secs / 1e9 / HBM_PEAK_GBS if secs > 0 else None
+    return roof
 
 
 def cpu_baseline(buffers, lvl, cam, win, W, H, gpu_frame, target_seconds):

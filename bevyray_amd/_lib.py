@@ -67,7 +67,7 @@ _PROTOTYPES = {
     "brt_render_part_device": (_I32, [_VP, _VP, _VP, _U32, _U32, _U32, _U32, _U32, _VP, _VP, _VP, _VP, _U32,
                                       C.POINTER(BrtStats)]),
     "brt_tile_rows": (_U32, [_U32, _U32]),
-    "brt_deinterleave_device": (_I32, [_VP, _VP, _U32, _U32, _U32, _VP, _VP]),
+    "brt_deinterleave_device": (_I32, [_VP, _VP, _U32, _U32, _U32, _VP, _VP, _U32]),
     "brt_debug_eval": (_I32, [_VP, _U32, _VP, _VP, _U32]),
     "brt_debug_profile": (_I32, [_VP, C.POINTER(C.c_uint64)]),
     "brt_build_bvh": (_I32, [_VP, _U32, _VP, _U32, C.POINTER(_U32)]),
@@ -109,10 +109,35 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.brt_abi_version() != 1:
+    if lib.brt_abi_version() != 2:
         raise RuntimeError("libbevyray_amd.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def kernel_code_hash(path: str = LIB_PATH) -> str:
+    """sha256 (first 16 hex digits) of the `.hip_fatbin` section of the shared library, i.e. of the gfx950
+    code objects only: changes iff the device code changes (the build is deterministic), not when host
+    code does.  profiles/*.json record it next to the PMC counters they were measured on, and bench.py
+    drops file-sourced counters whose hash differs from the library it is timing."""
+    import hashlib
+    import struct
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"\x7fELF" or data[4] != 2:
+        raise RuntimeError(f"{path}: not an ELF64 file")
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+    def sec(i):
+        name, _type, _flags, _addr, off, size = struct.unpack_from("<IIQQQQ", data, shoff + i * shentsize)
+        return name, off, size
+    _, stroff, strsize = sec(shstrndx)
+    strtab = data[stroff:stroff + strsize]
+    for i in range(shnum):
+        name, off, size = sec(i)
+        if strtab[name:strtab.index(b"\0", name)] == b".hip_fatbin":
+            return hashlib.sha256(data[off:off + size]).hexdigest()[:16]
+    raise RuntimeError(f"{path}: no .hip_fatbin section")
 
 
 class BrtError(RuntimeError):

@@ -24,6 +24,7 @@ struct DeviceCtx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_last = nullptr;   // end of the last launch that used the control block (any stream)
     int num_cus = 0;
     size_t max_lds = 0;
     // scene
@@ -322,6 +323,9 @@ int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hi
 int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const float* d_raster_rgba,
                     const float* d_raster_depth, float* d_out_tile, hipStream_t stream, uint32_t flags, bool timed,
                     LaunchPlan* plan_out) {
+    // the control block and the order table are per context: whatever stream the previous launch ran on, this
+    // one starts after it (include/bevyray_amd.h: one render per context in flight)
+    HIP_TRY(ctx, hipStreamWaitEvent(stream, dc.ev_last, 0));
     HIP_TRY(ctx, hipMemsetAsync(dc.d_ctrl, 0, 512, stream));
     if (timed) HIP_TRY(ctx, hipEventRecord(dc.ev0, stream));
     LaunchPlan lp{};
@@ -364,6 +368,7 @@ int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const fl
         }
     }
     if (timed) HIP_TRY(ctx, hipEventRecord(dc.ev1, stream));
+    HIP_TRY(ctx, hipEventRecord(dc.ev_last, stream));
     if (plan_out) *plan_out = lp;
     return BRT_OK;
 }
@@ -404,6 +409,7 @@ void free_device(DeviceCtx& dc) {
     if (dc.d_bvh_models) (void)hipFree(dc.d_bvh_models);
     if (dc.ev0) (void)hipEventDestroy(dc.ev0);
     if (dc.ev1) (void)hipEventDestroy(dc.ev1);
+    if (dc.ev_last) (void)hipEventDestroy(dc.ev_last);
     if (dc.stream) (void)hipStreamDestroy(dc.stream);
     dc = DeviceCtx();
 }
@@ -480,6 +486,8 @@ int32_t brt_create(const int32_t* device_ids, int32_t n_devices, brt_ctx** out_c
             HIP_TRY(ctx, hipStreamCreateWithFlags(&dc.stream, hipStreamNonBlocking));
             HIP_TRY(ctx, hipEventCreate(&dc.ev0));
             HIP_TRY(ctx, hipEventCreate(&dc.ev1));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&dc.ev_last, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventRecord(dc.ev_last, dc.stream));
             HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dc.d_ctrl), 512));
             return BRT_OK;
         };
@@ -621,7 +629,7 @@ int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* w
     if (rc != BRT_OK) return rc;
     DeviceCtx& dc = ctx->devs[0];
     HIP_TRY(ctx, hipSetDevice(dc.device));
-    const bool own_stream = (hip_stream == nullptr);
+    const bool own_stream = (hip_stream == nullptr) && !(flags & BRT_FLAG_CALLER_STREAM);
     hipStream_t stream = own_stream ? dc.stream : static_cast<hipStream_t>(hip_stream);
     rc = attach_tile_order(ctx, dc, fp, stream, own_stream);
     if (rc != BRT_OK) return rc;
@@ -654,11 +662,27 @@ int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* w
     return BRT_OK;
 }
 
-int32_t brt_render(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level, uint32_t width, uint32_t height,
-                   const float* raster_rgba, const float* raster_depth, float* out_rgba, uint32_t flags, brt_stats* stats) {
-    if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
-    if (!out_rgba) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "out_rgba is null");
-    if (!ctx->has_scene && level != 0u) return ctx_fail(ctx, BRT_ERR_NO_SCENE, "brt_upload_scene has not succeeded yet");
+}  // extern "C"
+
+namespace {
+
+// After a failure inside brt_render some devices may still be tracing, or copying into the caller's
+// (possibly page-locked) frame: wait for every stream of the context before the error is returned, so that
+// nothing of this call is in flight when the caller gets its buffers back.  The first error message stays.
+void drain_all_streams(brt_ctx* ctx) {
+    const std::string keep = ctx->last_error;
+    for (auto& dc : ctx->devs) {
+        if (!dc.stream) continue;
+        if (hipSetDevice(dc.device) != hipSuccess) continue;
+        (void)hipStreamSynchronize(dc.stream);
+    }
+    (void)hipGetLastError();
+    ctx->last_error = keep;
+    g_last_error = keep;
+}
+
+int32_t render_frame(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level, uint32_t width, uint32_t height,
+                     const float* raster_rgba, const float* raster_depth, float* out_rgba, uint32_t flags, brt_stats* stats) {
     const auto t0 = std::chrono::steady_clock::now();
     const uint32_t n_parts = (uint32_t)ctx->devs.size();
     std::vector<FrameParams> fps(n_parts);
@@ -756,15 +780,30 @@ int32_t brt_render(brt_ctx* ctx, const void* camera80, const void* window16, uin
     return BRT_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int32_t brt_render(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level, uint32_t width, uint32_t height,
+                   const float* raster_rgba, const float* raster_depth, float* out_rgba, uint32_t flags, brt_stats* stats) {
+    if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (!out_rgba) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "out_rgba is null");
+    if (!ctx->has_scene && level != 0u) return ctx_fail(ctx, BRT_ERR_NO_SCENE, "brt_upload_scene has not succeeded yet");
+    const int32_t rc = render_frame(ctx, camera80, window16, level, width, height, raster_rgba, raster_depth, out_rgba, flags, stats);
+    if (rc != BRT_OK) drain_all_streams(ctx);
+    return rc;
+}
+
 int32_t brt_deinterleave_device(brt_ctx* ctx, const float* d_tiles, uint32_t n_parts, uint32_t width, uint32_t height,
-                                float* d_frame, void* hip_stream) {
+                                float* d_frame, void* hip_stream, uint32_t flags) {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (!d_tiles || !d_frame || n_parts == 0) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "null buffer / n_parts == 0");
     DeviceCtx& dc = ctx->devs[0];
     HIP_TRY(ctx, hipSetDevice(dc.device));
-    hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : dc.stream;
+    const bool own_stream = (hip_stream == nullptr) && !(flags & BRT_FLAG_CALLER_STREAM);
+    hipStream_t stream = own_stream ? dc.stream : static_cast<hipStream_t>(hip_stream);
     HIP_TRY(ctx, launch_deinterleave(d_tiles, d_frame, width, height, n_parts, brt_tile_rows(height, n_parts), stream));
-    if (!hip_stream) HIP_TRY(ctx, hipStreamSynchronize(stream));
+    if (own_stream) HIP_TRY(ctx, hipStreamSynchronize(stream));
     return BRT_OK;
 }
 

@@ -36,7 +36,16 @@ def gather_frame(tile, height: int, rank: int, world: int, node=None, group=None
 
     CUDA tensors: one RCCL gather, then the de-interleave HIP kernel of `node`
     (brt_deinterleave_device).  CPU tensors (gloo, used by the world_size-2 tests): one gloo
-    gather, then an index copy -- the row mapping under test is the same."""
+    gather, then an index copy -- the row mapping under test is the same.
+
+    Stream ordering on the GPU path (everything is enqueued on torch's CURRENT stream):
+      * `tile` must be complete, or be produced by work already enqueued on the current stream
+        (render_part_device(stream=None) is synchronous; with stream=<current stream> it is ordered);
+      * dist.gather makes the current stream wait for RCCL's own stream, and the de-interleave kernel is
+        launched on that same current stream (FLAG_CALLER_STREAM: also when it is the default stream, handle
+        0), so it runs behind the gather;
+      * the host is NOT blocked: before `tile` is overwritten (next frame) or the returned frame is read
+        from another stream, synchronise the current stream -- `end_of_frame()` does that."""
     import torch
     import torch.distributed as dist
 
@@ -54,7 +63,9 @@ def gather_frame(tile, height: int, rank: int, world: int, node=None, group=None
             raise RuntimeError("gather_frame on CUDA tensors needs the RayTracingNode (de-interleave kernel)")
         frame = torch.empty((height, width, 4), dtype=torch.float32, device=tiles.device)
         node.deinterleave_device(tiles.data_ptr(), world, width, height, frame.data_ptr(),
-                                 torch.cuda.current_stream().cuda_stream)
+                                 stream=int(torch.cuda.current_stream().cuda_stream))
+        # `tiles` is freed by Python when this function returns; the caching allocator only hands the block to
+        # later work on the SAME stream, which is ordered behind the kernel that reads it
         return frame
     frame = torch.empty((height, width, 4), dtype=torch.float32)
     for p in range(world):
@@ -62,3 +73,13 @@ def gather_frame(tile, height: int, rank: int, world: int, node=None, group=None
         valid = rows >= 0
         frame[torch.from_numpy(rows[valid])] = tiles[p][torch.from_numpy(np.flatnonzero(valid))]
     return frame
+
+
+def end_of_frame(tile) -> None:
+    """Blocks the host until everything enqueued on torch's current stream has finished: rank 0's gather
+    + de-interleave, and on the other ranks the RCCL send that still reads `tile`.  Call it before the
+    next frame is rendered into the same `tile` (the trace kernel runs on the context's own stream, which
+    is not ordered with torch's)."""
+    if tile.is_cuda:
+        import torch
+        torch.cuda.current_stream().synchronize()

@@ -47,6 +47,7 @@ LEVEL_DTYPE = np.dtype({"names": ["level"], "formats": ["<u4"], "offsets": [0], 
 STRIP_ROWS = 8
 FLAG_COUNTERS = 1
 FLAG_KERNEL_SIMPLE = 2
+FLAG_CALLER_STREAM = 4   # device entry points: `stream` is the caller's stream even when its handle is 0
 
 SCENE_COVER, SCENE_RTIOW_FINAL, SCENE_STRESS_GRID = 0, 1, 2
 
@@ -226,6 +227,16 @@ def cover_camera(width: int, height: int, sample_count: int, bounces: int,
     return lvl, cex, WindowExtract.extract_component(height, seed)
 
 
+def rtiow_camera(width: int, height: int, sample_count: int, bounces: int,
+                 level: Raytracing = Raytracing.Pure, seed: float = 0.5):
+    """The book's final-scene view for BASELINE.json configs 3 and 4: lookfrom (13,2,3),
+    lookat the origin, vfov 20 degrees = 0.34906585 rad, no defocus (the shader has none)."""
+    cam = RaytracedCamera(level=level, sample_count=sample_count, bounces=bounces)
+    proj = PerspectiveProjection(fov=0.34906585, aspect_ratio=width / height, near=0.1, far=1000.0)
+    lvl, cex = CameraExtract.extract_component(cam, Transform((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)), proj)
+    return lvl, cex, WindowExtract.extract_component(height, seed)
+
+
 def tile_rows(height: int, n_parts: int) -> int:
     return int(_lib.load().brt_tile_rows(height, n_parts))
 
@@ -365,16 +376,24 @@ class RayTracingNode:
     # -- device-pointer entry points (used by bench.py with torch tensors) ------------------------
 
     def render_part_device(self, level, camera, window, width: int, height: int, part: int, n_parts: int,
-                           d_out_tile: int, d_raster_rgba: int = 0, d_raster_depth: int = 0, stream: int = 0,
+                           d_out_tile: int, d_raster_rgba: int = 0, d_raster_depth: int = 0, stream: Optional[int] = None,
                            flags: int = 0) -> dict:
+        """stream=None: the context's own stream, synchronous, full stats.  stream=<hipStream_t handle>
+        (0 = the default stream): asynchronous on that stream (FLAG_CALLER_STREAM is added)."""
         p = self._p
         stats = BrtStats()
+        if stream is not None:
+            flags |= FLAG_CALLER_STREAM
         _lib.check(p._lib.brt_render_part_device(p._ctx, camera.ctypes.data, window.ctypes.data, int(level["level"][0]),
                                                  width, height, part, n_parts, d_raster_rgba or None,
                                                  d_raster_depth or None, d_out_tile, stream or None, flags,
                                                  C.byref(stats)), p._ctx)
         return stats.as_dict()
 
-    def deinterleave_device(self, d_tiles: int, n_parts: int, width: int, height: int, d_frame: int, stream: int = 0):
+    def deinterleave_device(self, d_tiles: int, n_parts: int, width: int, height: int, d_frame: int,
+                            stream: Optional[int] = None):
+        """stream=None: own stream, synchronous.  stream=<handle> (0 = default stream): asynchronous there --
+        pass the stream the gather was enqueued on so that the copy kernel runs behind it."""
         p = self._p
-        _lib.check(p._lib.brt_deinterleave_device(p._ctx, d_tiles, n_parts, width, height, d_frame, stream or None), p._ctx)
+        _lib.check(p._lib.brt_deinterleave_device(p._ctx, d_tiles, n_parts, width, height, d_frame, stream or None,
+                                                  0 if stream is None else FLAG_CALLER_STREAM), p._ctx)

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define BRT_ABI_VERSION 1u
+#define BRT_ABI_VERSION 2u
 
 /* Rows per strip of the interleaved row tiling. */
 #define BRT_STRIP_ROWS 8u
@@ -71,7 +71,11 @@ enum {
 /* brt_render* flags */
 enum {
     BRT_FLAG_COUNTERS = 1u,        /* also count node pops / interior visits / sphere tests / hits */
-    BRT_FLAG_KERNEL_SIMPLE = 2u    /* one-thread-per-pixel bring-up kernel instead of the persistent one */
+    BRT_FLAG_KERNEL_SIMPLE = 2u,   /* one-thread-per-pixel bring-up kernel instead of the persistent one */
+    BRT_FLAG_CALLER_STREAM = 4u    /* device entry points: `hip_stream` is the caller's stream even when it is NULL
+                                      (NULL is then the legacy default stream, not "the context's own stream"):
+                                      the work is enqueued there, ordered with whatever the caller enqueued before
+                                      (e.g. an RCCL gather), and the call does not synchronise */
 };
 
 typedef struct brt_ctx brt_ctx;
@@ -137,8 +141,13 @@ int32_t brt_host_free(brt_ctx* ctx, void* ptr);
  * s % n_parts), written densely into a DEVICE tile buffer of brt_tile_rows() rows on the
  * context's first device: tile row (k*BRT_STRIP_ROWS + r) is frame row
  * ((k*n_parts + part)*BRT_STRIP_ROWS + r).  d_raster_* are optional DEVICE full-frame
- * buffers.  Asynchronous on `hip_stream` (a hipStream_t; NULL = the context's stream);
- * kernel_ms in stats is only filled when `hip_stream` is NULL (the call then synchronises). */
+ * buffers.  `hip_stream` is a hipStream_t.  NULL without BRT_FLAG_CALLER_STREAM = the context's own
+ * (non-blocking) stream: the call then SYNCHRONISES before it returns, fills every field of stats and
+ * refreshes the dispatch-order history.  A non-NULL stream, or BRT_FLAG_CALLER_STREAM: asynchronous on that
+ * stream; only the launch-shape fields and `paths` of stats are filled.
+ * One render per context is in flight at a time: the control block (counters, tile queue) is per context, so
+ * a call first makes its stream wait (hipStreamWaitEvent) for the previous call's kernel, whichever stream
+ * that ran on.  d_out_tile must not be read or overwritten by other streams before this call's work is done. */
 int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level,
                                uint32_t width, uint32_t height, uint32_t part, uint32_t n_parts,
                                const float* d_raster_rgba, const float* d_raster_depth,
@@ -150,9 +159,12 @@ uint32_t brt_tile_rows(uint32_t height, uint32_t n_parts);
 
 /* Root side of the gather: d_tiles holds n_parts tiles back to back (each
  * brt_tile_rows()*width*4 floats, i.e. the receive buffer of a gather); writes the
- * de-interleaved width x height frame to d_frame.  Asynchronous on hip_stream. */
+ * de-interleaved width x height frame to d_frame.  Stream rule as for brt_render_part_device: NULL without
+ * BRT_FLAG_CALLER_STREAM = the context's own stream, synchronous; otherwise asynchronous on `hip_stream` --
+ * pass the stream the gather was enqueued on (with BRT_FLAG_CALLER_STREAM if that is the default stream), or
+ * the copy kernel is not ordered behind the gather. */
 int32_t brt_deinterleave_device(brt_ctx* ctx, const float* d_tiles, uint32_t n_parts,
-                                uint32_t width, uint32_t height, float* d_frame, void* hip_stream);
+                                uint32_t width, uint32_t height, float* d_frame, void* hip_stream, uint32_t flags);
 
 /* Diagnostic: evaluates one device function of the ray loop on n inputs (16 floats in,
  * 8 floats out per element; op codes BRT_DBG_* below) so that tests can compare single

@@ -69,3 +69,45 @@ def test_single_rank_is_identity():
     tile = _pattern(rows, 8)
     frame = gather_frame(tile, 24, 0, 1)
     assert torch.equal(frame, _pattern(np.arange(24), 8))
+
+
+def _run_bench(extra_env, *argv):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BRT_BENCH_TRACER="stub_tracer:make",
+               PYTHONPATH=os.path.join(root, "tests") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env)
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], capture_output=True, text=True, env=env,
+                          timeout=600)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's command shape): the parent starts the
+    two ranks itself (gloo + a stub tracer here), relays ONE JSON line and the line describes both ranks."""
+    out = _run_bench({}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["steps"] == 2
+    assert out["scaling"] == "strong" and out["unit"] == "Mrays/s"
+    assert len(out["kernel_ms_per_rank"]) == 2 and out["kernel_ms_per_rank"] == [1.0, 2.0]
+    # 1080 rows = 135 strips: rank 0 gets 68 of them, rank 1 67; one "ray" per pixel sample in the stub
+    assert out["rays_per_frame_per_rank"] == [68 * 8 * 1920 * 64, 67 * 8 * 1920 * 64]
+    assert out["rays_per_frame"] == 1920 * 1080 * 64
+    assert "STUB" in out["data"] and out["roofline"]["frac"] is None
+    assert out["config4"]["steps"] == 2 and len(out["config4"]["kernel_ms_per_rank"]) == 2
+
+
+def test_bench_single_rank_line_has_the_contract_keys():
+    out = _run_bench({}, "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["n_ranks_seen"] == 1 and out["vs_baseline"] is None
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(out["roofline"])
+    assert out["roofline"]["bound"] == "valu" and "workload" in out["config"] and "model" not in out["config"]

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/bevyray_amd.h but not exported"
     assert declared == set(_lib.EXPORTS), "ctypes prototypes out of sync with the header"
-    assert _lib.load().brt_abi_version() == 1
+    assert _lib.load().brt_abi_version() == 2
 
 
 def test_wire_layouts_match_the_wgsl_structs():

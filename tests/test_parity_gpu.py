@@ -368,6 +368,73 @@ def test_config2_full_size_properties(plugin, oracle):
         assert_frames_equal(f1[r0:r0 + 3], want[r0:r0 + 3])
 
 
+def _frame_properties(f, stats, w, h, spp, bounces, n_px=None):
+    n_px = w * h if n_px is None else n_px
+    assert stats["paths"] == n_px * spp and n_px * spp <= stats["rays"] <= n_px * spp * (bounces + 1)
+    assert np.all(f[..., 3] == 1.0) and np.all(np.isfinite(f)) and f[..., :3].min() >= 0.0 and f[..., :3].max() <= 1.0
+
+
+def test_config3_rtiow_full_size(plugin, oracle):
+    """BASELINE.json configs[2]: RTIOW final scene 1920x1080, 256 spp, 50 bounces -- the WHOLE frame and its ray
+    count against the oracle (pixel chains of > 10 000 sequential rays, critical-pixel waves)."""
+    b = brt.generate_scene(brt.SCENE_RTIOW_FINAL, 1)
+    w, h, spp, bounces = 1920, 1080, 256, 50
+    lvl, cam, win = brt.rtiow_camera(w, h, spp, bounces)
+    f1 = plugin.node.run(lvl, cam, win, w, h, buffers=b)          # first frame of the view: raster order
+    s1 = dict(plugin.node.last_stats)
+    f2 = plugin.node.run(lvl, cam, win, w, h)                     # second: order learned from the first (critical tiles first)
+    assert np.array_equal(f1.view(np.uint32), f2.view(np.uint32)) and plugin.node.last_stats["rays"] == s1["rays"]
+    _frame_properties(f1, s1, w, h, spp, bounces)
+    # the oracle over EVERY row (about 1.3 G rays: ~20-30 s on the box's 16 CPUs): whole frame + ray count
+    want, cnt = oracle.render(b, lvl, cam, win, w, h)
+    assert s1["rays"] == cnt["rays"]
+    assert_frames_equal(f1, want)
+
+
+@pytest.mark.parametrize("part", [0, 7])
+def test_config4_4k_1024spp_one_rank_share(plugin, oracle, part):
+    """BASELINE.json configs[3]: 3840x2160, 1024 spp, 8 bounces, row-tiled over 8 ranks -- rank `part`'s share
+    (every 8th strip of 8 rows) rendered into a device tile as bench.py does it, 33+ of its rows against the oracle."""
+    import torch
+    from bevyray_amd.parallel import frame_rows_of_part
+    b = brt.generate_scene(brt.SCENE_RTIOW_FINAL, 1)
+    w, h, spp, bounces, n_parts = 3840, 2160, 1024, 8, 8
+    lvl, cam, win = brt.rtiow_camera(w, h, spp, bounces)
+    plugin.node.write_buffers(b)
+    fr = frame_rows_of_part(h, part, n_parts)
+    tile = torch.zeros((len(fr), w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    st = plugin.node.render_part_device(lvl, cam, win, w, h, part, n_parts, tile.data_ptr())
+    t = tile.cpu().numpy()
+    _frame_properties(t[fr >= 0], st, w, h, spp, bounces, n_px=int((fr >= 0).sum()) * w)
+    assert np.all(t[fr < 0] == 0.0)                               # padding rows of the last strip are never written
+    # rows part*8 + 3 + 64 j all lie in strips of this part (strip s -> part s % 8): one oracle call, a thread per row
+    r0 = part * 8 + 3
+    want, _ = oracle.render(b, lvl, cam, win, w, h, rows=(r0, h), row_step=64)
+    ys = np.arange(r0, h, 64)
+    assert len(ys) >= 12
+    tile_row_of = {int(y): k for k, y in enumerate(fr) if y >= 0}
+    assert_frames_equal(t[[tile_row_of[int(y)] for y in ys]], want[ys])
+
+
+def test_config5_10k_spheres_full_size(plugin, oracle):
+    """BASELINE.json configs[4]: 10 004 spheres, 1920x1080, 64 spp, 8 bounces -- the scene does not fit LDS
+    (pair records from L2); the WHOLE frame and its ray count against the oracle."""
+    b = brt.generate_scene(brt.SCENE_STRESS_GRID, 1)
+    assert len(b.models) == 10004
+    w, h, spp, bounces = 1920, 1080, 64, 8
+    lvl, cam, win = brt.cover_camera(w, h, spp, bounces)
+    f1 = plugin.node.run(lvl, cam, win, w, h, buffers=b)
+    s1 = dict(plugin.node.last_stats)
+    assert s1["scene_in_lds"] == 0
+    f2 = plugin.node.run(lvl, cam, win, w, h)
+    assert np.array_equal(f1.view(np.uint32), f2.view(np.uint32)) and plugin.node.last_stats["rays"] == s1["rays"]
+    _frame_properties(f1, s1, w, h, spp, bounces)
+    want, cnt = oracle.render(b, lvl, cam, win, w, h)
+    assert s1["rays"] == cnt["rays"]
+    assert_frames_equal(f1, want)
+
+
 # ---- GPU BVH build (SURVEY.md 8(f) rank 1) --------------------------------------------------------------------
 
 def test_gpu_ploc_build_is_byte_identical_to_cpu_build(plugin, oracle):
@@ -623,3 +690,76 @@ def test_unchanged_scene_is_not_reuploaded_and_changes_are(plugin, oracle):
         plugin.node.write_buffers(brt.Buffers(moved, b.materials, bad))
     f3 = plugin.node.run(lvl, cam, win, 64, 36, buffers=brt.Buffers(moved, b.materials, None))
     assert_frames_equal(f3, want2)
+
+
+# ---- the frame loop of bench.py: render on the context's stream, gather + de-interleave on torch's ------------------
+
+def test_frame_loop_with_a_new_seed_every_frame(plugin, oracle):
+    """world = 1 leg of bevyray_amd.parallel.gather_frame: the de-interleave kernel is enqueued on torch's current
+    stream (the default stream, handle 0, through BRT_FLAG_CALLER_STREAM) behind whatever produced the tiles; the
+    seed changes every frame so that a stale tile or frame would show."""
+    import torch
+    from bevyray_amd.parallel import end_of_frame, gather_frame
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    w, h = 200, 120
+    plugin.node.write_buffers(b)
+    tile = torch.zeros((brt.tile_rows(h, 1), w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for i in range(6):
+        lvl, cam, win = brt.cover_camera(w, h, 3, 5, seed=0.1 + 0.13 * i)
+        plugin.node.render_part_device(lvl, cam, win, w, h, 0, 1, tile.data_ptr())
+        frame = gather_frame(tile, h, 0, 1, node=plugin.node)
+        end_of_frame(tile)
+        want, _ = oracle.render(b, lvl, cam, win, w, h)
+        assert_frames_equal(frame.cpu().numpy(), want)
+
+
+def _nccl_rank(rank, world, port, w, h, seeds, out_path):
+    import torch
+    import torch.distributed as dist
+    from bevyray_amd.parallel import end_of_frame, gather_frame
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        b = brt.generate_scene(brt.SCENE_COVER, 1)
+        frames = []
+        with brt.RaytracePlugin([rank]) as p:
+            p.node.write_buffers(b)
+            tile = torch.zeros((brt.tile_rows(h, world), w, 4), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            for seed in seeds:
+                lvl, cam, win = brt.cover_camera(w, h, 3, 5, seed=seed)
+                p.node.render_part_device(lvl, cam, win, w, h, rank, world, tile.data_ptr())
+                frame = gather_frame(tile, h, rank, world, node=p.node)
+                end_of_frame(tile)
+                if rank == 0:
+                    frames.append(frame.cpu().numpy())
+            if rank == 0:
+                np.save(out_path, np.stack(frames))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_over_rccl_match_one_gpu(plugin, oracle, tmp_path):
+    """RCCL leg (needs two GPUs; skipped on the one-GPU boxes): two ranks, a new seed every frame, rank 0's
+    gathered frame against the oracle and against the one-GPU render."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    w, h, seeds = 200, 120, [0.1, 0.3, 0.55, 0.8]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_nccl_rank, args=(2, port, w, h, seeds, out), nprocs=2, join=True)
+    frames = np.load(out)
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    for seed, f in zip(seeds, frames):
+        lvl, cam, win = brt.cover_camera(w, h, 3, 5, seed=seed)
+        want, _ = oracle.render(b, lvl, cam, win, w, h)
+        assert_frames_equal(f, want)
+        assert_frames_equal(plugin.node.run(lvl, cam, win, w, h, buffers=b), want)
