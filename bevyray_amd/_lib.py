@@ -14,8 +14,8 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libbevyray_amd.so")
-_SOURCES = ["brt_api.cpp", "brt_host.cpp", "brt_kernels.hip", "brt_host.h", "brt_kernels.h", "brt_layout.h",
-            "brt_device.h", "brt_ploc.h", "brt_bvh.hip", "Makefile"]
+_SOURCES = ["brt_api.cpp", "brt_host.cpp", "brt_kernels.hip", "brt_trace_prod.hip", "brt_trace_tune.hip", "brt_trace.h",
+            "brt_host.h", "brt_kernels.h", "brt_layout.h", "brt_device.h", "brt_ploc.h", "brt_bvh.hip", "Makefile"]
 
 _lock = threading.Lock()
 _lib = None
@@ -46,7 +46,7 @@ def build(force: bool = False) -> str:
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     with _lock:
         if force or _stale():
-            cmd = ["make", "-C", _CSRC] + (["-B"] if force else [])
+            cmd = ["make", "-C", _CSRC, "-j", str(min(6, os.cpu_count() or 1))] + (["-B"] if force else [])
             proc = subprocess.run(cmd, capture_output=True, text=True)
             if proc.returncode != 0:
                 raise RuntimeError("building libbevyray_amd.so failed:\n" + proc.stdout + proc.stderr)

@@ -174,30 +174,40 @@ int32_t make_frame_params(brt_ctx* ctx, const void* camera80, const void* window
     fp.crit_begin = fp.crit_end = 0;   // set by attach_tile_order
     fp.wgq_batch = env_u32("BRT_WGQ_BATCH", 0) & ~63u;
     if (fp.wgq_batch > 512u) fp.wgq_batch = 512u;
+    // any knob off its default (or the lane queue asked for) -> the TUNABLE instantiation of the kernel
+    fp.tunable = (fp.bottom_up != 0u || fp.refill_min != kRefillMin || fp.walk_exit_lanes != kWalkExitLanes ||
+                  fp.leaf_vote != kLeafVote || fp.drain_donate != kDrainDonate || fp.pool_adopt != kPoolAdopt ||
+                  fp.wgq_batch != 0u || env_u32("BRT_LPT_LANE_PERMILLE", 0) != 0u || env_u32("BRT_TUNABLE", 0) != 0u)
+                     ? 1u : 0u;
     *out = fp;
     return BRT_OK;
 }
 
 struct LaunchPlan {
-    bool lds_scene;
+    int scene_mode;              // SceneMode (brt_layout.h)
+    uint32_t lds_pairs;          // SCENE_LDS_TOP: pair records staged in LDS
     uint32_t block, grid, wg_per_cu;
     uint32_t pool_cap;           // records of the drain pool per workgroup (0: none)
     size_t lds_bytes;
 };
 
-// Choose the kernel variant and grid.  The scene (pair records, spheres, material ids) goes to
-// LDS when it fits; the 32-byte materials stay in global memory (read once per hit; measured:
-// no difference).  Measured on the cover scene: the kernel is bound by VALU pipe
-// time, not by latency -- 4, 6 and 8 waves/SIMD run within 4 % of each other -- so the plan is
-// simply one 1024-thread workgroup per CU.  BRT_FORCE_GLOBAL_SCENE / BRT_BLOCK_THREADS /
-// BRT_WG_PER_CU override (tuning aids).
+// Choose the kernel variant and grid.
+//   SCENE_LDS      the whole encoded scene (pair records, spheres, material ids) fits a workgroup's LDS beside the
+//                  stacks and the drain pool: one 1024-thread workgroup per CU (measured on the cover scene,
+//                  bound by VALU pipe time; 4, 6 and 8 waves/SIMD run within 4 % of each other);
+//   SCENE_LDS_TOP  it does not fit, but descriptors are 16-bit (<= 16 382 spheres): the LDS left beside stacks and
+//                  pool holds the top of the tree (pair records are in breadth-first order), the rest comes from L2;
+//   SCENE_GLOBAL   larger scenes: 256-thread workgroups, as many per CU as their stacks allow.
+// The 32-byte materials always stay in global memory (read once per hit; measured: no difference).
+// BRT_FORCE_GLOBAL_SCENE / BRT_FORCE_LDS_TOP=<records> / BRT_BLOCK_THREADS / BRT_WG_PER_CU override (tests, tuning).
 LaunchPlan plan_launch(const DeviceCtx& dc, const FrameParams& fp) {
     LaunchPlan lp{};
     const bool force_global = env_u32("BRT_FORCE_GLOBAL_SCENE", 0) != 0;
+    const uint32_t force_top = env_u32("BRT_FORCE_LDS_TOP", 0);
     const uint32_t block_env = env_u32("BRT_BLOCK_THREADS", 0);
     const uint32_t wg_env = env_u32("BRT_WG_PER_CU", 0);
     const uint32_t max_waves_cu = 32;
-    lp.lds_scene = false;
+    lp.scene_mode = SCENE_GLOBAL;
     // drain pool: every wave but one may hand over up to drain_donate paths, but the takers empty the pool
     // while the donors fill it: 384 records (36 KB) are enough in practice, and a donation that does not
     // fit is simply retried a round later
@@ -206,17 +216,17 @@ LaunchPlan plan_launch(const DeviceCtx& dc, const FrameParams& fp) {
         const uint32_t want = fp.drain_donate * (block / 64u - 1u);
         return want < pool_max ? want : pool_max;
     };
-    if (!force_global && dc.view.desc16) {
+    if (!force_global && !force_top && dc.view.desc16) {
         struct Cand { uint32_t block, per_cu; };
         const Cand cands[] = {{1024, 1}, {512, 2}, {512, 3}, {1024, 2}, {512, 1}, {256, 1}};
-        for (int with_pool = 1; with_pool >= 0 && !lp.lds_scene; with_pool--) {
+        for (int with_pool = 1; with_pool >= 0 && lp.scene_mode != SCENE_LDS; with_pool--) {
             for (const Cand& c : cands) {
                 if (block_env && c.block != block_env) continue;
                 if (wg_env && c.per_cu != wg_env) continue;
                 const uint32_t pool = with_pool ? pool_of(c.block) : 0u;
-                const size_t need = trace_lds_bytes(dc.view, true, c.block, pool);
+                const size_t need = trace_lds_bytes(dc.view, SCENE_LDS, c.block, pool);
                 if (need * c.per_cu <= dc.max_lds && c.per_cu * (c.block / 64) <= max_waves_cu) {
-                    lp.lds_scene = true;
+                    lp.scene_mode = SCENE_LDS;
                     lp.block = c.block;
                     lp.wg_per_cu = c.per_cu;
                     lp.lds_bytes = need;
@@ -226,10 +236,30 @@ LaunchPlan plan_launch(const DeviceCtx& dc, const FrameParams& fp) {
             }
         }
     }
-    if (!lp.lds_scene) {
+    if (lp.scene_mode != SCENE_LDS && !force_global && dc.view.desc16) {
+        // top of the tree in LDS: one workgroup per CU, everything that is left of the LDS for pair records
+        DeviceSceneView v = dc.view;
+        v.lds_pairs = 0;
+        const uint32_t block = block_env ? block_env : BRT_BLOCK;
+        const uint32_t pool = pool_of(block) < 192u ? pool_of(block) : 192u;   // half the pool: the tile is worth more
+        const size_t fixed = trace_lds_bytes(v, SCENE_LDS_TOP, block, pool);
+        if (fixed + 64 * PAIR_BYTES <= dc.max_lds) {
+            uint32_t k = (uint32_t)((dc.max_lds - fixed) / PAIR_BYTES);
+            if (k > v.n_pairs) k = v.n_pairs;
+            if (force_top && force_top < k) k = force_top;
+            v.lds_pairs = k;
+            lp.scene_mode = SCENE_LDS_TOP;
+            lp.lds_pairs = k;
+            lp.block = block;
+            lp.wg_per_cu = 1;
+            lp.pool_cap = pool;
+            lp.lds_bytes = trace_lds_bytes(v, SCENE_LDS_TOP, block, pool);
+        }
+    }
+    if (lp.scene_mode == SCENE_GLOBAL) {
         lp.block = block_env ? block_env : 256u;
         lp.pool_cap = pool_of(lp.block);
-        lp.lds_bytes = trace_lds_bytes(dc.view, false, lp.block, lp.pool_cap);
+        lp.lds_bytes = trace_lds_bytes(dc.view, SCENE_GLOBAL, lp.block, lp.pool_cap);
         uint32_t per_cu = (uint32_t)(dc.max_lds / (lp.lds_bytes ? lp.lds_bytes : 1));
         const uint32_t by_waves = max_waves_cu / (lp.block / 64u);
         if (per_cu > by_waves) per_cu = by_waves;
@@ -348,7 +378,8 @@ int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const fl
             lp.grid = (fp.queue_size + 255u) / 256u;
         } else {
             lp = plan_launch(dc, fp);
-            tl.lds_scene = lp.lds_scene;
+            tl.scene_mode = lp.scene_mode;
+            tl.scene.lds_pairs = lp.lds_pairs;
             tl.grid = lp.grid;
             tl.block = lp.block;
             tl.lds_bytes = lp.lds_bytes;
@@ -640,7 +671,7 @@ int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* w
         std::memset(stats, 0, sizeof *stats);
         stats->paths = part_pixels(fp) * (uint64_t)fp.sample_count;
         stats->lds_bytes = (uint32_t)lp.lds_bytes;
-        stats->scene_in_lds = lp.lds_scene ? 1u : 0u;
+        stats->scene_in_lds = lp.scene_mode == SCENE_LDS ? 1u : (lp.scene_mode == SCENE_LDS_TOP ? 2u : 0u);
         stats->n_workgroups = lp.grid;
         stats->threads_per_workgroup = lp.block;
     }
@@ -773,7 +804,7 @@ int32_t render_frame(brt_ctx* ctx, const void* camera80, const void* window16, u
         stats->gather_ms = gather_ms;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         stats->lds_bytes = (uint32_t)lp.lds_bytes;
-        stats->scene_in_lds = lp.lds_scene ? 1u : 0u;
+        stats->scene_in_lds = lp.scene_mode == SCENE_LDS ? 1u : (lp.scene_mode == SCENE_LDS_TOP ? 2u : 0u);
         stats->n_workgroups = lp.grid;
         stats->threads_per_workgroup = lp.block;
     }

@@ -118,6 +118,10 @@ BRT_DEV float float_below(float closest) { return __uint_as_float(__float_as_uin
 // kernel and the large-scene variant with global pointers.
 struct ScenePtrs {
     const char* pairs;       // pair records of PAIR_BYTES (brt_layout.h): near/far planes by granule, descriptors
+    // SCENE_LDS_TOP: `pairs` is the LDS tile holding the records below byte offset `near_bytes` (the top of the
+    // tree in breadth-first order), `pairs_far` the whole array in global memory
+    const char* pairs_far;
+    uint32_t near_bytes;
     bool boxes_ordered;      // every child box finite with min <= max (decided at upload)
     const float4* spheres;
     const uint32_t* sphere_material;
@@ -179,18 +183,18 @@ struct WalkState {
     uint32_t cur;            // DONE when the walk has ended
     StackT* sp;
     uint32_t n;              // entries in use (overflow rule of general trees only)
-    // record base + the granule this ray's direction selects on each axis (brt_layout.h): G0 reads
-    // {min, max} = {near, far} for a direction >= 0, G1 reads {max, min} for a direction < 0
-    const char *px, *py, *pz;
+    // byte offset, inside a pair record, of the granule this ray's direction selects on each axis
+    // (brt_layout.h): G0 reads {min, max} = {near, far} for a direction >= 0, G1 {max, min} for a direction < 0
+    uint32_t ox, oy, oz;
 };
 
 template <bool D16, typename StackT>
 BRT_DEV void walk_begin(WalkState<StackT>& w, const ScenePtrs& sc, uint32_t root_desc, StackT* stk, f3 d) {
     w.a = dot3(d, d);
     w.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    w.px = sc.pairs + PAIR_X + (w.inv.x < 0.0f ? 16u : 0u);
-    w.py = sc.pairs + PAIR_Y + (w.inv.y < 0.0f ? 16u : 0u);
-    w.pz = sc.pairs + PAIR_Z + (w.inv.z < 0.0f ? 16u : 0u);
+    w.ox = PAIR_X + (w.inv.x < 0.0f ? 16u : 0u);
+    w.oy = PAIR_Y + (w.inv.y < 0.0f ? 16u : 0u);
+    w.oz = PAIR_Z + (w.inv.z < 0.0f ? 16u : 0u);
     w.closest = kInf;
     w.closest_idx = 0xffffffffu;
     w.cur = root_desc;
@@ -250,18 +254,30 @@ BRT_DEV bool ray_is_safe(f3 o, f3 inv) {
 // tests, push/pop as selects.  FIX: apply min/max to the {near, far} values read (needed when some ray
 // of the wave is not safe or the boxes are not ordered); without it the read offset has already made
 // that choice.
-template <int STRIDE, bool COUNTERS, bool FIX, typename StackT>
-BRT_DEV void walk_interior_step(const char* pairs, f3 o, f3 inv, const char* px, const char* py, const char* pz, float below,
+template <int STRIDE, bool COUNTERS, bool FIX, bool D16, int MODE, typename StackT>
+BRT_DEV void walk_interior_step(const ScenePtrs& sc, f3 o, f3 inv, uint32_t ox, uint32_t oy, uint32_t oz, float below,
                                 uint32_t& cur, StackT*& sp, uint32_t& n, HitCounters& hc) {
     if (COUNTERS) { hc.node_pops++; hc.interior++; }
     if (STRIDE == 64) prof_section<COUNTERS>(hc, SEC_INTERIOR, true);
-    const uint32_t ro = cur << 4;           // interior descriptor = record offset in 16-byte units
-    const float4 gx = *reinterpret_cast<const float4*>(px + ro);   // { near L, near R, far L, far R } on x
-    const float4 gy = *reinterpret_cast<const float4*>(py + ro);
-    const float4 gz = *reinterpret_cast<const float4*>(pz + ro);
-    const uint2 D = *reinterpret_cast<const uint2*>(pairs + ro + PAIR_DESC);
-    // the would-be pop, issued with the node reads so that its LDS latency hides behind the slab
-    // arithmetic; the store below goes to the entry above it, never to it
+    const uint32_t ro = Desc<D16>::record_offset(cur);   // byte offset of the pair record
+    float4 gx, gy, gz;                                   // per axis { near L, near R, far L, far R }
+    uint2 D;
+    if (MODE == SCENE_LDS_TOP && ro >= sc.near_bytes) {
+        // a record below the LDS tile: from global memory (L2).  Lanes of one wave take either side.
+        const char* rec = sc.pairs_far + ro;
+        gx = *reinterpret_cast<const float4*>(rec + ox);
+        gy = *reinterpret_cast<const float4*>(rec + oy);
+        gz = *reinterpret_cast<const float4*>(rec + oz);
+        D = *reinterpret_cast<const uint2*>(rec + PAIR_DESC);
+    } else {
+        const char* rec = sc.pairs + ro;
+        gx = *reinterpret_cast<const float4*>(rec + ox);
+        gy = *reinterpret_cast<const float4*>(rec + oy);
+        gz = *reinterpret_cast<const float4*>(rec + oz);
+        D = *reinterpret_cast<const uint2*>(rec + PAIR_DESC);
+    }
+    // the would-be pop: its LDS latency hides behind the slab arithmetic; the store below goes to the entry
+    // above it, never to it
     const uint32_t popped = (uint32_t)(int32_t)*sp;
     // .x = child L (`index`), .y = child R (`index + 1`); (b - o) * (1/d) as in raytrace.wgsl:388-390
     float nLx = (gx.x - o.x) * inv.x, nRx = (gx.y - o.x) * inv.x, fLx = (gx.z - o.x) * inv.x, fRx = (gx.w - o.x) * inv.x;
@@ -304,8 +320,8 @@ BRT_DEV void walk_interior_step(const char* pairs, f3 o, f3 inv, const char* px,
 }
 
 // The wave-level walk loop (see walk_run).
-template <bool COUNTERS, bool D16, bool SIMPLE_TREE, bool FIX, typename StackT>
-BRT_DEV void walk_loop_wave(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, const char* px, const char* py, const char* pz,
+template <bool COUNTERS, bool D16, bool SIMPLE_TREE, bool FIX, int MODE, typename StackT>
+BRT_DEV void walk_loop_wave(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, uint32_t ox, uint32_t oy, uint32_t oz,
                             float& closest, uint32_t& closest_idx, uint32_t& cur, StackT*& sp, uint32_t& n,
                             uint32_t exit_at, uint32_t vote, HitCounters& hc) {
     using DS = Desc<D16>;
@@ -314,7 +330,7 @@ BRT_DEV void walk_loop_wave(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, co
         for (;;) {
             const bool interior = DS::is_interior(cur) && (SIMPLE_TREE || n < 31u);
             if (__ballot(interior) == 0ull) break;
-            if (interior) walk_interior_step<64, COUNTERS, FIX>(sc.pairs, o, inv, px, py, pz, below, cur, sp, n, hc);
+            if (interior) walk_interior_step<64, COUNTERS, FIX, D16, MODE>(sc, o, inv, ox, oy, oz, below, cur, sp, n, hc);
             const uint32_t want_leaf = (uint32_t)__popcll(__ballot(DS::is_leaf(cur) && (SIMPLE_TREE || n < 31u)));
             if (want_leaf >= vote) break;
         }
@@ -327,7 +343,7 @@ BRT_DEV void walk_loop_wave(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, co
     }
 }
 
-template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, typename StackT>
+template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, int MODE, typename StackT>
 BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, f3 o, f3 d,
                       uint32_t exit_lanes, uint32_t leaf_vote, HitCounters& hc) {
     using DS = Desc<D16>;
@@ -338,9 +354,7 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, f3
     uint32_t cur = w.cur;
     StackT* sp = w.sp;
     uint32_t n = w.n;
-    const char* const px = w.px;
-    const char* const py = w.py;
-    const char* const pz = w.pz;
+    const uint32_t ox = w.ox, oy = w.oy, oz = w.oz;
     const bool pending = cur != DS::DONE && (SIMPLE_TREE || n < 31u);
     const bool unsafe = !sc.boxes_ordered || (pending && !ray_is_safe(o, inv));
     if (STRIDE == 64) {
@@ -362,20 +376,20 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, f3
         const uint32_t vote = leaf_vote < 1u ? 1u : leaf_vote;
         if (n_walking > exit_at) {
             if (__ballot(unsafe) == 0ull)
-                walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, false>(sc, o, d, a, inv, px, py, pz, closest, closest_idx, cur, sp, n,
-                                                                  exit_at, vote, hc);
+                walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, false, MODE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp,
+                                                                        n, exit_at, vote, hc);
             else
-                walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, true>(sc, o, d, a, inv, px, py, pz, closest, closest_idx, cur, sp, n,
-                                                                 exit_at, vote, hc);
+                walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, true, MODE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp,
+                                                                       n, exit_at, vote, hc);
         }
     } else {
         while (cur != DS::DONE && (SIMPLE_TREE || n < 31u)) {
             if (DS::is_leaf(cur))
                 walk_leaf_step<STRIDE, COUNTERS, D16, SIMPLE_TREE>(sc, o, d, a, closest, closest_idx, cur, sp, n, hc);
             else if (unsafe)
-                walk_interior_step<STRIDE, COUNTERS, true>(sc.pairs, o, inv, px, py, pz, float_below(closest), cur, sp, n, hc);
+                walk_interior_step<STRIDE, COUNTERS, true, D16, MODE>(sc, o, inv, ox, oy, oz, float_below(closest), cur, sp, n, hc);
             else
-                walk_interior_step<STRIDE, COUNTERS, false>(sc.pairs, o, inv, px, py, pz, float_below(closest), cur, sp, n, hc);
+                walk_interior_step<STRIDE, COUNTERS, false, D16, MODE>(sc, o, inv, ox, oy, oz, float_below(closest), cur, sp, n, hc);
         }
     }
     w.closest = closest;
@@ -391,7 +405,7 @@ BRT_DEV void raycast(const ScenePtrs& sc, uint32_t root_desc, StackT* stk, f3 o,
                      float& t_out, uint32_t& idx_out, HitCounters& hc) {
     WalkState<StackT> w;
     walk_begin<D16>(w, sc, root_desc, stk, d);
-    walk_run<STRIDE, COUNTERS, D16, SIMPLE_TREE>(sc, w, stk, o, d, 0u, 0u, hc);
+    walk_run<STRIDE, COUNTERS, D16, SIMPLE_TREE, SCENE_GLOBAL>(sc, w, stk, o, d, 0u, 0u, hc);
     t_out = w.closest;
     idx_out = w.closest_idx;
 }

@@ -48,6 +48,7 @@ int32_t validate_and_encode(const Model* models, uint32_t n_models, const Materi
     std::vector<uint32_t> order;  // interior nodes in BFS order
     order.reserve(n_nodes / 2 + 1);
     uint32_t max_leaf_depth = 0;
+    uint32_t n_general_leaves = 0;   // leaves of more than one sphere (they go through the leaf table)
 
     auto leaf_check = [&](uint32_t n) -> bool {
         uint64_t end = (uint64_t)nodes[n].index + (uint64_t)nodes[n].model_count;
@@ -67,6 +68,7 @@ int32_t validate_and_encode(const Model* models, uint32_t n_models, const Materi
                 return BRT_ERR_INVALID_BVH;
             }
             max_leaf_depth = std::max(max_leaf_depth, depth[n]);
+            if (nd.model_count > 1) n_general_leaves++;
             continue;
         }
         uint64_t c0 = nd.index, c1 = (uint64_t)nd.index + 1;
@@ -93,14 +95,13 @@ int32_t validate_and_encode(const Model* models, uint32_t n_models, const Materi
     if ((uint64_t)e.n_pairs * PAIR_UNITS > 0x7FFFFFFFull) { *err = "scene too large for 31-bit record offsets"; return BRT_ERR_UNSUPPORTED; }
     e.pairs.assign(pair_array_bytes(e.n_pairs) / 4, 0.0f);
 
-    // 16-bit descriptors when every index fits 14 bits (general leaves <= nodes)
-    e.desc16 = (n_models <= DESC16_MAX_INDEX) && (n_nodes <= DESC16_MAX_INDEX) &&
-               ((uint64_t)e.n_pairs * PAIR_UNITS <= 0x7FFFu);
+    // 16-bit descriptors when every index fits 14 bits: sphere ids, pair-record ids, leaf-table ids
+    e.desc16 = (n_models <= DESC16_MAX_INDEX) && (e.n_pairs <= DESC16_MAX_INDEX) && (n_general_leaves <= DESC16_MAX_INDEX);
     const uint32_t LEAF = e.desc16 ? Desc<true>::LEAF : Desc<false>::LEAF;
     const uint32_t LEAF1 = e.desc16 ? Desc<true>::LEAF1 : Desc<false>::LEAF1;
     auto desc_of = [&](uint32_t n) -> uint32_t {
         const BVHNode& nd = nodes[n];
-        if (nd.model_count == 0) return pair_id[n] * PAIR_UNITS;   // record offset in 16-byte units
+        if (nd.model_count == 0) return e.desc16 ? Desc<true>::interior(pair_id[n]) : Desc<false>::interior(pair_id[n]);
         if (nd.model_count == 1) return LEAF | LEAF1 | nd.index;
         uint32_t id = (uint32_t)(e.leaf_table.size() / 2);
         e.leaf_table.push_back(nd.index);

@@ -21,14 +21,14 @@ struct TraceLaunch {
     const float* raster_rgba;
     const float* raster_depth;
     unsigned long long* counters;       // 5 x u64, zeroed by the caller
-    bool lds_scene;
+    int scene_mode;                     // SceneMode (brt_layout.h)
     bool counters_on;
     uint32_t grid, block;
     size_t lds_bytes;
     hipStream_t stream;
 };
 
-size_t trace_lds_bytes(const DeviceSceneView& sv, bool lds_scene, uint32_t block, uint32_t pool_cap);
+size_t trace_lds_bytes(const DeviceSceneView& sv, int scene_mode, uint32_t block, uint32_t pool_cap);
 constexpr uint32_t POOL_RECORD_BYTES = 96;   // one path in the drain pool (k_trace_persistent)
 constexpr uint32_t WGQ_BYTES = 64;           // a workgroup's share of the pixel queue: 8 control words + 8 tile ids
 hipError_t launch_trace_persistent(const TraceLaunch& tl);

@@ -30,478 +30,9 @@
 // k_debug_eval        evaluates single device functions for per-function parity tests.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-#include <type_traits>
-
-#include "brt_device.h"
-#include "brt_kernels.h"
+#include "brt_trace.h"
 
 namespace brt {
-
-// ---- queue slot -> pixel -------------------------------------------------------------------
-// Slot q: tile = q / 64, inside the tile row-major 8x8.  Tiles run along x inside a strip of
-// BRT_STRIP_ROWS (= 8) rows; local strip k of part p is frame strip k * n_parts + p.
-struct PixelCoord {
-    uint32_t px, py;        // frame coordinates
-    uint32_t local_row;     // row in the dense tile buffer
-    uint32_t tile;          // tile id (strip * tiles_x + tx)
-    bool inside;
-};
-BRT_DEV uint32_t slot_tile(const FrameParams& fp, uint32_t slot_tile_index) {
-    return fp.tile_order ? fp.tile_order[slot_tile_index] : slot_tile_index;   // dispatch order, if known
-}
-BRT_DEV PixelCoord slot_to_pixel(const FrameParams& fp, uint32_t q, uint32_t tile) {
-    const uint32_t t = q & 63u;
-    const uint32_t sq = tile / fp.tiles_x, tx = tile - sq * fp.tiles_x;
-    // queue order: bottom strips first when fp.bottom_up (longest-pixels-first heuristic)
-    const uint32_t strip = fp.bottom_up ? (fp.local_strips - 1u - sq) : sq;
-    PixelCoord c;
-    c.px = tx * 8u + (t & 7u);
-    const uint32_t r = t >> 3;
-    c.local_row = strip * 8u + r;
-    c.py = (strip * fp.n_parts + fp.part) * 8u + r;
-    c.tile = tile;
-    c.inside = (c.px < fp.width) && (c.py < fp.height);
-    return c;
-}
-
-BRT_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-BRT_DEV uint32_t mbcnt64(uint64_t mask) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
-
-BRT_DEV uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-// Per-pixel state of a lane
-struct PixelState {
-    float ndc0x, ndc0y;     // uv.x*2-1, 1-uv.y*2   (raytrace.wgsl:146-147)
-    f3 sum;                 // running colour sum    (raytrace.wgsl:165)
-    float dsum;             // running depth sum     (raytrace.wgsl:166)
-    uint32_t rng;
-    uint32_t sample;
-    uint32_t out_index;     // pixel index in the tile buffer
-    uint32_t frame_index;   // pixel index in the frame (raster inputs)
-    uint32_t tile;          // for the per-tile cost measurement
-    uint32_t rays_begin;    // lane's ray counter when the pixel started
-};
-
-BRT_DEV void pixel_begin(const FrameParams& fp, const PixelCoord& c, PixelState& ps) {
-    const float uvx = ((float)c.px + 0.5f) / (float)fp.width;
-    const float uvy = ((float)c.py + 0.5f) / (float)fp.height;
-    ps.rng = pixel_seed(fp, uvx, uvy);
-    ps.ndc0x = uvx * 2.0f - 1.0f;
-    ps.ndc0y = 1.0f - uvy * 2.0f;
-    ps.sum = mk3(0.0f, 0.0f, 0.0f);
-    ps.dsum = 0.0f;
-    ps.sample = 0;
-    ps.out_index = c.local_row * fp.width + c.px;
-    ps.frame_index = c.py * fp.width + c.px;
-    ps.tile = c.tile;
-}
-
-BRT_DEV void pixel_finish(const FrameParams& fp, const PixelState& ps, float* out_tile, const float* raster_rgba,
-                          const float* raster_depth) {
-    const f3 avg = mk3(ps.sum.x / fp.spp_f, ps.sum.y / fp.spp_f, ps.sum.z / fp.spp_f);   // :169
-    const float avg_depth = ps.dsum / fp.spp_f;                                           // :170
-    reinterpret_cast<float4*>(out_tile)[ps.out_index] =
-        resolve_pixel(fp, avg, avg_depth, raster_rgba, raster_depth, ps.frame_index);
-}
-
-// One ray segment of the bounce loop, raytrace.wgsl:189-212, after raycast returned (t, idx).
-// Returns true when the sample has ended; then `color` is its gamma-encoded colour (:223).
-template <bool COUNTERS>
-BRT_DEV bool shade_segment(const ScenePtrs& sc, const FrameParams& fp, f3& o, f3& d, f3& tput, uint32_t& bounce,
-                           float& first_depth, float t, uint32_t idx, uint32_t& rng, f3& color, HitCounters& hc) {
-    if (bounce == 0) first_depth = t;                               // :193-195
-    f3 light = mk3(0.0f, 0.0f, 0.0f);
-    bool ended;
-    if (t == kInf) {                                                // :198-201
-        light = background_gradient(d);
-        ended = true;
-    } else {
-        hc.hits++;
-        f3 att;
-        const bool absorbed = scatter<COUNTERS>(sc, o, d, t, idx, rng, att, hc);  // :204
-        if (absorbed) {
-            ended = true;                                           // :207-209, light stays 0
-        } else {
-            tput = tput * att;                                      // :211
-            bounce++;
-            ended = bounce > fp.bounce_count;                       // loop exit, :189
-            if (ended) tput = mk3(0.0f, 0.0f, 0.0f);                // :215-217
-        }
-    }
-    if (ended) {
-        const f3 c = tput * light;
-        color = mk3(__builtin_sqrtf(c.x), __builtin_sqrtf(c.y), __builtin_sqrtf(c.z));  // :223
-    }
-    return ended;
-}
-
-// ---- drain pool ------------------------------------------------------------------------------
-// When the pixel queue is empty a wave's lanes run out of pixels one by one, but a round costs the
-// wave the same instructions with 5 live lanes as with 60: on the cover frame 18 % of all rounds were
-// executed in that phase with 22 live lanes on average.  So the waves of a workgroup CONSOLIDATE:
-// a wave that is down to `drain_donate` live paths finishes the walks in flight, writes its paths
-// (pixel state + next ray segment, 23 words) to a pool in LDS and ends; waves with idle lanes take
-// them over and continue them.  A path is the same sequence of operations whichever lane runs it, so
-// pixels and counters do not change.
-// Control words {lock, count, alive waves}; all three only change under the lock.  Invariants: the
-// last alive wave never donates, and a wave only leaves when the pool is empty -- so every pooled
-// path is picked up.  The lock holder runs straight-line code (no waiting inside).
-BRT_DEV void pool_lock(uint32_t* ctl, uint32_t lane) {
-    if (lane == 0)
-        while (atomicCAS(&ctl[0], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-BRT_DEV void pool_unlock(uint32_t* ctl, uint32_t lane) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) atomicExch(&ctl[0], 0u);
-}
-BRT_DEV uint32_t pool_peek(const uint32_t* ctl, int i) { return __atomic_load_n(&ctl[i], __ATOMIC_RELAXED); }
-
-// ---- persistent kernel -----------------------------------------------------------------------
-
-// LDS_SCENE: pair records, spheres and material ids live in LDS (descriptors are then always
-// 16-bit); the 32-byte materials stay in global memory (one read per hit).  D16: 16-bit
-// descriptors and u16 stack entries.  SIMPLE: see raycast (brt_device.h).
-template <bool LDS_SCENE, bool D16, bool SIMPLE, bool COUNTERS>
-__global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView sv, FrameParams fp,
-                                                                uint32_t* __restrict__ queue_counter,
-                                                                float* __restrict__ out_tile,
-                                                                const float* __restrict__ raster_rgba,
-                                                                const float* __restrict__ raster_depth,
-                                                                unsigned long long* __restrict__ counters) {
-    static_assert(!LDS_SCENE || D16, "an LDS-resident scene always uses 16-bit descriptors");
-    using StackT = typename std::conditional<D16, int16_t, int32_t>::type;   // sign-extending loads: brt_layout.h
-    extern __shared__ uint4 smem[];
-    ScenePtrs sc;
-    StackT* stacks;
-    sc.materials = reinterpret_cast<const float4*>(sv.materials);
-    sc.boxes_ordered = sv.boxes_ordered != 0u;
-    if (LDS_SCENE) {
-        // carve: pair records | spheres | leaf_table | sphere_material | stacks
-        const uint32_t pair_granules = (uint32_t)(pair_array_bytes(sv.n_pairs) / 16);
-        float4* p = reinterpret_cast<float4*>(smem);
-        float4* l_pairs = p; p += pair_granules;
-        float4* l_sp = p; p += sv.n_models;
-        uint2* p2 = reinterpret_cast<uint2*>(p);
-        uint2* l_lt = p2; p2 += sv.n_leaf_table;
-        uint32_t* p1 = reinterpret_cast<uint32_t*>(p2);
-        uint32_t* l_sm = p1; p1 += sv.n_models;
-        stacks = reinterpret_cast<StackT*>(p1);
-        const float4* g_pairs = reinterpret_cast<const float4*>(sv.pairs);
-        const float4* g_sp = reinterpret_cast<const float4*>(sv.spheres);
-        const uint2* g_lt = reinterpret_cast<const uint2*>(sv.leaf_table);
-        for (uint32_t i = threadIdx.x; i < pair_granules; i += blockDim.x) l_pairs[i] = g_pairs[i];
-        for (uint32_t i = threadIdx.x; i < sv.n_models; i += blockDim.x) { l_sp[i] = g_sp[i]; l_sm[i] = sv.sphere_material[i]; }
-        for (uint32_t i = threadIdx.x; i < sv.n_leaf_table; i += blockDim.x) l_lt[i] = g_lt[i];
-        sc.pairs = reinterpret_cast<const char*>(l_pairs);
-        sc.spheres = l_sp; sc.sphere_material = l_sm; sc.leaf_table = l_lt;
-    } else {
-        sc.pairs = reinterpret_cast<const char*>(sv.pairs);
-        sc.spheres = reinterpret_cast<const float4*>(sv.spheres);
-        sc.sphere_material = sv.sphere_material;
-        sc.leaf_table = reinterpret_cast<const uint2*>(sv.leaf_table);
-        stacks = reinterpret_cast<StackT*>(smem);
-    }
-    const uint32_t lane = lane_id();
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t n_waves = blockDim.x >> 6;
-    StackT* stk = stacks + wave * ((sv.stack_entries + 2u) * 64u) + lane;   // + 2: DONE sentinel (entry 0) and one spare entry
-    // behind the stacks (same sums as trace_lds_bytes): the workgroup's share of the pixel queue, then the
-    // drain pool (4 control words, then the records)
-    char* const lds = reinterpret_cast<char*>(smem);
-    uint32_t off = (uint32_t)(reinterpret_cast<char*>(stacks + n_waves * ((sv.stack_entries + 2u) * 64u)) - lds);
-    off = (off + 15u) & ~15u;
-    uint32_t* const wgq = reinterpret_cast<uint32_t*>(lds + off);
-    off += WGQ_BYTES;
-    uint32_t* pool_ctl = nullptr;
-    float4* pool = nullptr;
-    if (fp.pool_cap != 0u) {
-        pool_ctl = reinterpret_cast<uint32_t*>(lds + off);
-        pool = reinterpret_cast<float4*>(lds + off + 16u);
-        if (threadIdx.x == 0) { pool_ctl[0] = 0u; pool_ctl[1] = 0u; pool_ctl[2] = n_waves; pool_ctl[3] = 0u; }
-    }
-    if (threadIdx.x < WGQ_BYTES / 4u) wgq[threadIdx.x] = 0u;
-    __syncthreads();
-    // slots a workgroup takes from the global queue at a time (chosen by the host, brt_api.cpp launch_part)
-    const uint32_t wgq_batch = fp.wgq_batch >= 64u ? fp.wgq_batch : 64u;
-
-    PixelState ps;
-    ps.sample = 0; ps.rng = 0; ps.out_index = 0; ps.frame_index = 0; ps.tile = 0; ps.rays_begin = 0;
-    ps.ndc0x = ps.ndc0y = 0.0f; ps.sum = mk3(0.0f, 0.0f, 0.0f); ps.dsum = 0.0f;
-    f3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f), tput = mk3(1.0f, 1.0f, 1.0f);
-    uint32_t bounce = 0;
-    float first_depth = kInf;
-    bool active = false, exhausted = false;
-    bool in_flight = false;           // this lane's walk was suspended by walk_run's early exit
-    bool crit = false;                // this lane's pixel is one of the frame's longest chains (FrameParams::crit_*)
-    bool wave_crit = false;
-    WalkState<StackT> walk;
-    walk.a = 0.0f; walk.inv = mk3(0.0f, 0.0f, 0.0f); walk.closest = kInf; walk.closest_idx = 0xffffffffu;
-    walk.cur = Desc<D16>::DONE; walk.sp = stk; walk.n = 0;
-    walk.px = walk.py = walk.pz = sc.pairs;
-    uint32_t n_rays = 0;
-    HitCounters hc = {};
-    // COUNTERS build: when this wave started, when it first found the pixel queue empty, when it ended
-    // (100 MHz wall clock; read by brt_debug_profile as words 24..29)
-    unsigned long long t_start = 0, t_empty = 0, drain_lane_rounds = 0;
-    unsigned long long t_mark = 0, ticks_refill = 0, ticks_walk = 0, ticks_shade = 0, ticks_pre = 0;   // phase times of this wave
-    if (COUNTERS) t_start = t_mark = wall_clock64();
-
-    bool tiles_done = false;          // the tile queue (slots FrameParams::queue_lane .. queue_size) is empty
-    // lane takes queue slot q of `tile`
-    auto begin_pixel = [&](uint32_t q, uint32_t tile) {
-        const PixelCoord c = slot_to_pixel(fp, q, tile);
-        if (c.inside) {
-            pixel_begin(fp, c, ps);
-            crit = q >= fp.crit_begin && q < fp.crit_end;
-            ps.rays_begin = n_rays;
-            if (fp.sample_count == 0) {
-                // 0/0 per channel.  The sums are compile-time zeros here; keep them opaque: hipcc 7.2
-                // otherwise folds the four divisions into one and then drops two channels of the
-                // level-1/2 result (found by scripts/fuzz_parity.py; tests: sample_count 0).
-                asm volatile("" : "+v"(ps.sum.x), "+v"(ps.sum.y), "+v"(ps.sum.z), "+v"(ps.dsum));
-                pixel_finish(fp, ps, out_tile, raster_rgba, raster_depth);
-            } else { active = true; bounce = 0; }
-        }
-    };
-
-    for (;;) {
-        // A wave that carries one of the frame's CRITICAL pixels (FrameParams::crit_*) issues ahead of its SIMD
-        // mates and takes no new pixels: its rounds get shorter as its other pixels end, and the frame cannot
-        // end before that chain has.
-        if (fp.crit_end != 0u) {
-            const bool wc = __ballot(active && crit) != 0ull;
-            if (wc != wave_crit) {
-                wave_crit = wc;
-                if (wc) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-            }
-        }
-        if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_shade += now - t_mark; t_mark = now; }
-        // ---- refill empty lanes from the pixel queue (wave-aggregated) ----
-        for (;;) {
-            const bool need = !active && !exhausted && !wave_crit;
-            const uint64_t m = __ballot(need);
-            if (m == 0) break;
-            // keep a wave's pixels of one cost class: take new ones only in batches of refill_min
-            // (a round costs the max over its lanes, so a cheap pixel dropped among expensive ones
-            // pays their price for each of its samples); always refill when nothing else runs
-            if ((uint32_t)__popcll(m) < fp.refill_min && __ballot(active) != 0ull) break;
-            // The workgroup takes slots from the global queue a batch at a time (one atomic on the hot address
-            // and one read of the order table per batch instead of per refill) and its waves share the batch
-            // through LDS: {lock, lo, hi, batch base, queue empty} + the batch's tile ids.
-            const uint32_t n_need = (uint32_t)__popcll(m);
-            const uint32_t rank = mbcnt64(m);
-            uint32_t q = 0xffffffffu, tile = 0;
-            bool none_left;
-            {
-                pool_lock(wgq, lane);
-                uint32_t lo = pool_peek(wgq, 1), hi = pool_peek(wgq, 2), bbase = pool_peek(wgq, 3);
-                bool done = pool_peek(wgq, 4) != 0u;
-                if (lo == hi && !done) {
-                    // guided: the batches shrink with what is left of the queue (judged from this workgroup's last
-                    // batch), down to single tiles, so that no workgroup sits on a big share when the queue runs dry
-                    const uint32_t left = fp.queue_lane > bbase ? fp.queue_lane - bbase : 0u;
-                    uint32_t batch = (left / (gridDim.x * 4u)) & ~63u;
-                    batch = batch > wgq_batch ? wgq_batch : (batch < 64u ? 64u : batch);
-                    // single tiles until the queue is past the CRITICAL tiles: the waves that carry them run at raised
-                    // priority and should sit on different CUs, not eight to a workgroup
-                    if (bbase < fp.crit_end) batch = 64u;
-                    uint32_t b = 0;
-                    if (lane == 0) b = atomicAdd(queue_counter, batch);
-                    b = (uint32_t)__shfl((int)b, 0, 64);
-                    bbase = b;
-                    lo = b < fp.queue_lane ? b : fp.queue_lane;
-                    hi = b + batch < fp.queue_lane ? b + batch : fp.queue_lane;
-                    if (hi < lo) hi = lo;
-                    done = lo == hi;
-                    const uint32_t ti = (b >> 6) + lane;
-                    if (lane < (batch >> 6) && ti < (fp.queue_lane >> 6)) wgq[8u + lane] = slot_tile(fp, ti);
-                    if (lane == 0) { wgq[2] = hi; wgq[3] = bbase; wgq[4] = done ? 1u : 0u; }
-                }
-                const uint32_t avail = hi - lo;
-                const uint32_t take = n_need < avail ? n_need : avail;
-                if (need && rank < take) {
-                    q = lo + rank;
-                    tile = wgq[8u + ((q - bbase) >> 6)];
-                }
-                if (lane == 0) wgq[1] = lo + take;
-                none_left = done && take == 0u;
-                pool_unlock(wgq, lane);
-            }
-            if (need) {
-                if (none_left) {
-                    exhausted = true;
-                    if (COUNTERS && t_empty == 0) t_empty = wall_clock64();
-                } else if (q != 0xffffffffu) {
-                    begin_pixel(q, tile);
-                }
-            }
-        }
-        // ---- nothing left to do (and the lane queue, if any, is empty): the next whole tile ----
-        if (fp.queue_lane != fp.queue_size && !tiles_done && !wave_crit && __ballot(active) == 0ull &&
-            __ballot(!exhausted) == 0ull) {
-            uint32_t b = 0;
-            if (lane == 0) b = atomicAdd(queue_counter + 1, 64u);
-            b = fp.queue_lane + (uint32_t)__shfl((int)b, 0, 64);
-            if (b < fp.queue_size) begin_pixel(b + lane, slot_tile(fp, b >> 6));
-            else tiles_done = true;
-        }
-        if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_refill += now - t_mark; t_mark = now; }
-        // ---- drain: hand the paths over / take paths over / leave (see "drain pool" above) ----
-        bool finish_walks = false;    // this round runs every walk to its end so that the wave can hand over next round
-        if (fp.pool_cap != 0u && __ballot(exhausted) != 0ull && !wave_crit) {
-            const uint64_t am = __ballot(active);
-            const uint32_t live = (uint32_t)__popcll(am);
-            const bool quiet = __ballot(in_flight) == 0ull;              // no suspended walk: every live path is between two rays
-            const bool thin = live != 0u && live <= fp.drain_donate;
-            bool leave = false;
-            if (live == 0u || (thin && quiet && pool_peek(pool_ctl, 2) > 1u) || (live <= fp.pool_adopt && pool_peek(pool_ctl, 1) != 0u)) {
-                pool_lock(pool_ctl, lane);
-                const uint32_t count = pool_peek(pool_ctl, 1), alive = pool_peek(pool_ctl, 2);
-                if (thin && quiet && alive > 1u && count + live <= fp.pool_cap) {
-                    // hand over: live lane r writes record count + r
-                    if (active) {
-                        float4* rec = pool + 6u * (count + mbcnt64(am));
-                        rec[0] = make_float4(ps.ndc0x, ps.ndc0y, ps.sum.x, ps.sum.y);
-                        rec[1] = make_float4(ps.sum.z, ps.dsum, __uint_as_float(ps.rng), __uint_as_float(ps.sample));
-                        rec[2] = make_float4(__uint_as_float(ps.out_index), __uint_as_float(ps.frame_index), __uint_as_float(ps.tile),
-                                             __uint_as_float(n_rays - ps.rays_begin));
-                        rec[3] = make_float4(o.x, o.y, o.z, d.x);
-                        rec[4] = make_float4(d.y, d.z, tput.x, tput.y);
-                        rec[5] = make_float4(tput.z, __uint_as_float(bounce), first_depth, __uint_as_float(crit ? 1u : 0u));
-                        active = false;
-                    }
-                    // (while the tile queue has tiles the wave stays: it takes one next round)
-                    const bool stay = fp.queue_lane != fp.queue_size && !tiles_done;
-                    if (lane == 0) { pool_ctl[1] = count + live; if (!stay) pool_ctl[2] = alive - 1u; }
-                    leave = !stay;
-                } else if (count != 0u && live < 64u) {
-                    // take over: idle lane r of k takes record count - k + r
-                    const uint64_t im = ~am;
-                    const uint32_t idle = 64u - live;
-                    const uint32_t k = idle < count ? idle : count;
-                    const uint32_t r = mbcnt64(im);
-                    if (!active && r < k) {
-                        const float4* rec = pool + 6u * (count - k + r);
-                        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5];
-                        ps.ndc0x = r0.x; ps.ndc0y = r0.y; ps.sum = mk3(r0.z, r0.w, r1.x); ps.dsum = r1.y;
-                        ps.rng = __float_as_uint(r1.z); ps.sample = __float_as_uint(r1.w);
-                        ps.out_index = __float_as_uint(r2.x); ps.frame_index = __float_as_uint(r2.y); ps.tile = __float_as_uint(r2.z);
-                        ps.rays_begin = n_rays - __float_as_uint(r2.w);
-                        o = mk3(r3.x, r3.y, r3.z); d = mk3(r3.w, r4.x, r4.y); tput = mk3(r4.z, r4.w, r5.x);
-                        bounce = __float_as_uint(r5.y); first_depth = r5.z; crit = __float_as_uint(r5.w) != 0u;
-                        active = true; in_flight = false; exhausted = true;
-                    }
-                    if (lane == 0) pool_ctl[1] = count - k;
-                } else if (live == 0u && count == 0u && (fp.queue_lane == fp.queue_size || tiles_done)) {
-                    if (lane == 0) pool_ctl[2] = alive - 1u;
-                    leave = true;
-                }
-                pool_unlock(pool_ctl, lane);
-            }
-            if (leave) break;
-            finish_walks = (uint32_t)__popcll(__ballot(active)) <= fp.drain_donate;
-        } else if (__ballot(active) == 0 && (fp.queue_lane == fp.queue_size || tiles_done || __ballot(!exhausted) != 0ull)) {
-            break;
-        }
-        if (__ballot(active) == 0) continue;      // (pool on) nothing live but paths may still arrive
-
-        prof_section<COUNTERS>(hc, SEC_ROUND, active);
-        if (COUNTERS && __ballot(exhausted) != 0ull) drain_lane_rounds += (unsigned long long)__popcll(__ballot(active)) | (1ull << 32);
-        const bool fresh = active && !in_flight;       // starts a ray segment in this round
-        prof_section<COUNTERS>(hc, SEC_CAMERA, fresh && bounce == 0);
-        if (fresh && bounce == 0) {
-            // new sample: raytrace.wgsl:162 + :175-186
-            d = camera_ray_dir(fp, ps.ndc0x, ps.ndc0y, ps.rng);
-            o = mk3(fp.cam_pos[0], fp.cam_pos[1], fp.cam_pos[2]);
-            tput = mk3(1.0f, 1.0f, 1.0f);
-            first_depth = kInf;
-        }
-        if (fresh) walk_begin<D16>(walk, sc, sv.root_desc, stk, d);
-        if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_pre += now - t_mark; t_mark = now; }
-        if (active) walk_run<64, COUNTERS, D16, SIMPLE>(sc, walk, stk, o, d, finish_walks ? 0u : fp.walk_exit_lanes, fp.leaf_vote, hc);
-        in_flight = active && walk_pending<D16, SIMPLE>(walk);
-        if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_walk += now - t_mark; t_mark = now; }
-        const bool landed = active && !in_flight;      // walk finished: shade this segment now
-        const float t = walk.closest;
-        const uint32_t idx = walk.closest_idx;
-        prof_section<COUNTERS>(hc, SEC_SCATTER, landed && t != kInf);
-        prof_section<COUNTERS>(hc, SEC_SKY, landed && t == kInf);
-        if (landed) {
-            n_rays++;
-            f3 color;
-            if (shade_segment<COUNTERS>(sc, fp, o, d, tput, bounce, first_depth, t, idx, ps.rng, color, hc)) {
-                ps.sum = ps.sum + color;                                                   // :165
-                ps.dsum = ps.dsum + (first_depth == kInf ? fp.fallback_far : first_depth); // :166,219-221
-                ps.sample++;
-                bounce = 0;
-                if (ps.sample == fp.sample_count) {
-                    pixel_finish(fp, ps, out_tile, raster_rgba, raster_depth);
-                    if (fp.tile_cost) {
-                        atomicAdd(&fp.tile_cost[ps.tile], n_rays - ps.rays_begin);
-                        atomicMax(&fp.tile_cost[fp.local_strips * fp.tiles_x + ps.tile], n_rays - ps.rays_begin);
-                    }
-                    active = false;
-                }
-            }
-        }
-    }
-
-    // ---- counters: one atomic per wave ----
-    const uint32_t r = wave_sum(n_rays);
-    if (lane == 0) atomicAdd(&counters[0], (unsigned long long)r);
-    if (COUNTERS) {
-        const uint32_t a = wave_sum(hc.node_pops), b = wave_sum(hc.interior), c = wave_sum(hc.sphere_tests);
-        if (lane == 0) {
-            atomicAdd(&counters[1], (unsigned long long)a);
-            atomicAdd(&counters[2], (unsigned long long)b);
-            atomicAdd(&counters[3], (unsigned long long)c);
-        }
-    }
-    if (COUNTERS) {
-        const unsigned long long t_end = wall_clock64();
-        unsigned long long te = 0;   // earliest "queue empty" seen by a lane of this wave
-        for (int l = 0; l < 64; l++) {
-            const unsigned long long v = __shfl(t_empty, l, 64);
-            if (v != 0 && (te == 0 || v < te)) te = v;
-        }
-        if (lane == 0) {
-            atomicMax(&counters[24], ~t_start);                 // min start
-            if (te) { atomicMax(&counters[25], ~te); atomicMax(&counters[26], te); atomicAdd(&counters[28], t_end - te); }
-            atomicMax(&counters[27], t_end);
-            atomicAdd(&counters[29], 1ull);
-            atomicAdd(&counters[30], drain_lane_rounds & 0xffffffffull);   // live lanes summed over the rounds after "empty"
-            atomicAdd(&counters[31], drain_lane_rounds >> 32);              // those rounds
-            atomicAdd(&counters[5], ticks_refill);    // wave time in: the pixel refill loop (queue atomic, tile order, pixel_begin)
-            atomicAdd(&counters[6], ticks_walk);      //               the walk loop
-            atomicAdd(&counters[7], ticks_shade + (t_end - t_mark));   // shading of the landed rays, pixel finish
-            atomicAdd(&counters[43], ticks_pre);                       // drain logic, camera ray, walk_begin
-        }
-    }
-    if (COUNTERS) {
-        unsigned long long tb = hc.ticks_ball;   // sum over the lanes that booked it
-        for (int off = 32; off > 0; off >>= 1) tb += __shfl_down(tb, off, 64);
-        if (lane == 0) atomicAdd(&counters[44], tb);
-    }
-    if (COUNTERS) {
-        const uint32_t h = wave_sum(hc.hits);
-        if (lane == 0) atomicAdd(&counters[4], (unsigned long long)h);
-        for (int k = 0; k < 8; k++) {   // each execution was booked by ONE lane of the wave: sum over lanes
-            const uint32_t e = wave_sum(hc.sec_exec[k]), l = wave_sum(hc.sec_lanes[k]);
-            if (lane == 0) {
-                atomicAdd(&counters[8 + 2 * k], (unsigned long long)e);
-                atomicAdd(&counters[9 + 2 * k], (unsigned long long)l);
-            }
-        }
-    }
-}
 
 // ---- bring-up kernel ---------------------------------------------------------------------------
 
@@ -513,6 +44,8 @@ __global__ __launch_bounds__(256) void k_trace_simple(DeviceSceneView sv, FrameP
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     ScenePtrs sc;
     sc.pairs = reinterpret_cast<const char*>(sv.pairs);
+    sc.pairs_far = sc.pairs;
+    sc.near_bytes = 0u;
     sc.boxes_ordered = sv.boxes_ordered != 0u;
     sc.spheres = reinterpret_cast<const float4*>(sv.spheres);
     sc.sphere_material = sv.sphere_material;
@@ -630,11 +163,13 @@ __global__ void k_debug_eval(uint32_t op, const float* __restrict__ in, float* _
 
 // ---- host-callable launchers ----------------------------------------------------------------------
 
-size_t trace_lds_bytes(const DeviceSceneView& sv, bool lds_scene, uint32_t block, uint32_t pool_cap) {
+size_t trace_lds_bytes(const DeviceSceneView& sv, int scene_mode, uint32_t block, uint32_t pool_cap) {
     size_t bytes = 0;
-    if (lds_scene) {
+    if (scene_mode == SCENE_LDS) {
         bytes += pair_array_bytes(sv.n_pairs) + (size_t)sv.n_models * 16;
         bytes += (size_t)sv.n_leaf_table * 8 + (size_t)sv.n_models * 4;
+    } else if (scene_mode == SCENE_LDS_TOP) {
+        bytes += pair_array_bytes(sv.lds_pairs);
     }
     bytes += (size_t)(block / 64) * (sv.stack_entries + 2) * 64 * (sv.desc16 ? 2 : 4);   // + 2: DONE sentinel, one spare entry
     bytes = (bytes + 15) & ~(size_t)15;
@@ -643,30 +178,11 @@ size_t trace_lds_bytes(const DeviceSceneView& sv, bool lds_scene, uint32_t block
     return bytes;
 }
 
-template <bool L, bool D, bool S, bool C>
-static hipError_t launch_persistent_t(const TraceLaunch& tl) {
-    auto kern = k_trace_persistent<L, D, S, C>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)tl.lds_bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(tl.grid), dim3(tl.block), tl.lds_bytes, tl.stream, tl.scene, tl.frame, tl.queue_counter,
-                       tl.out_tile, tl.raster_rgba, tl.raster_depth, tl.counters);
-    return hipGetLastError();
-}
-
-template <bool L, bool D>
-static hipError_t launch_persistent_ld(const TraceLaunch& tl) {
-    if (tl.scene.simple_tree)
-        return tl.counters_on ? launch_persistent_t<L, D, true, true>(tl) : launch_persistent_t<L, D, true, false>(tl);
-    return tl.counters_on ? launch_persistent_t<L, D, false, true>(tl) : launch_persistent_t<L, D, false, false>(tl);
-}
-
+// the instantiations live in brt_trace_prod.hip (knobs folded) and brt_trace_tune.hip (knobs live)
+hipError_t launch_trace_persistent_prod(const TraceLaunch& tl);
+hipError_t launch_trace_persistent_tune(const TraceLaunch& tl);
 hipError_t launch_trace_persistent(const TraceLaunch& tl) {
-    if (tl.lds_scene) {
-        if (!tl.scene.desc16) return hipErrorInvalidValue;
-        return launch_persistent_ld<true, true>(tl);
-    }
-    return tl.scene.desc16 ? launch_persistent_ld<false, true>(tl) : launch_persistent_ld<false, false>(tl);
+    return tl.frame.tunable ? launch_trace_persistent_tune(tl) : launch_trace_persistent_prod(tl);
 }
 
 template <bool D, bool C>

@@ -73,14 +73,16 @@ static_assert(sizeof(Window) == 16 && offsetof(Window, height) == 4, "Window");
 // each interior node becomes a "pair record" with both children's boxes and descriptors.
 // The push/pop ORDER is the reference's, so results (ties, stack-overflow rule) are the same.
 //
-// Descriptor (32-bit form; scenes too large for LDS):
+// Descriptor (32-bit form; scenes of more than 16 382 spheres):
 //   bit31 = 0                 interior: bits[30:0] = offset of the pair record in 16-byte units (index * 7), so that
 //                             a granule address is one shift-add
 //   bit31 = 1, bit30 = 1      leaf with exactly one sphere: bits[29:0] = model index
 //   bit31 = 1, bit30 = 0      general leaf: bits[29:0] = index into the leaf table {first, count}
-// 16-bit form (every index < 16384, always the case for an LDS-resident scene): the same three
+// 16-bit form (every index < 16383, always the case for an LDS-resident scene): the same three
 // cases with the flags in bits 15/14 and a 14-bit index, so that a traversal-stack entry is 16 bits
-// and 32 waves' stacks fit beside the scene in a CU's LDS.
+// and 16 waves' stacks fit beside the scene (or its top levels) in a CU's LDS.  The interior index is
+// the pair record's INDEX here (byte offset = index * 112, one v_mul_u32_u24 -- the same instruction
+// count as the shift of the 32-bit form), so that the form covers trees of up to 16 382 interior nodes.
 // REGISTER form (what the kernels compare, what pair records and root_desc hold): the 16-bit form
 // SIGN-EXTENDED to 32 bits, the 32-bit form as it is.  All-ones (-1) is the "walk finished" marker,
 // so as signed integers:   interior >= 0,   leaf < -1,   finished == -1   -- one compare each, and a
@@ -94,6 +96,9 @@ struct Desc {
     static constexpr uint32_t DONE = 0xFFFFFFFFu;                       // "walk finished" marker, never a real descriptor
     static constexpr bool is_interior(uint32_t d) { return (int32_t)d >= 0; }
     static constexpr bool is_leaf(uint32_t d) { return (int32_t)d < -1; }
+    // interior descriptor of pair record `index`, and back to the record's byte offset
+    static constexpr uint32_t interior(uint32_t index) { return D16 ? index : index * 7u; }
+    static constexpr uint32_t record_offset(uint32_t d) { return D16 ? d * 112u : d << 4; }
 };
 constexpr uint32_t DESC32_MAX_INDEX = 0x3FFFFFFEu;   // largest encodable index (all-ones is DONE)
 constexpr uint32_t DESC16_MAX_INDEX = 0x3FFEu;
@@ -125,6 +130,14 @@ constexpr size_t pair_array_bytes(uint32_t n_pairs) { return (size_t)n_pairs * P
 // raytrace.wgsl:375), material ids in a parallel u32 array.
 // Materials: two float4 per material, as on the wire.
 
+// Where the kernel reads pair records / spheres from (chosen per launch, brt_api.cpp plan_launch):
+enum SceneMode : int {
+    SCENE_GLOBAL = 0,    // everything from global memory (L2)
+    SCENE_LDS = 1,       // pair records, spheres, material ids and leaf table copied to LDS by every workgroup
+    SCENE_LDS_TOP = 2    // the first `lds_pairs` pair records (breadth-first order: the top of the tree) in LDS,
+                         // deeper records, spheres and material ids from global memory
+};
+
 struct DeviceSceneView {
     const float* pairs;      // n_pairs records of PAIR_BYTES
     const float* spheres;    // float4[n_models]
@@ -137,7 +150,13 @@ struct DeviceSceneView {
     uint32_t desc16;         // 1: descriptors are in the 16-bit form
     uint32_t simple_tree;    // 1: every leaf holds one sphere and max leaf depth + 1 < 31
     uint32_t boxes_ordered;  // 1: every child box is finite with min <= max
+    uint32_t lds_pairs;      // SCENE_LDS_TOP: pair records [0, lds_pairs) are staged in LDS (set per launch)
 };
+
+// Defaults of the tuning knobs in FrameParams.  The production kernel (TUNABLE = false) has them folded in as
+// constants and the lane queue compiled out; brt_api.cpp picks the TUNABLE instantiation when the environment
+// asks for anything else.
+constexpr uint32_t kRefillMin = 1, kWalkExitLanes = 12, kLeafVote = 12, kDrainDonate = 40, kPoolAdopt = 56;
 
 // Frame-uniform values, evaluated once on the host with the reference's expressions
 // (raytrace.wgsl:95,141-153,177-182).
@@ -182,6 +201,7 @@ struct FrameParams {
     // of each finished pixel, tile_cost[n_tiles + tile] = max of them.  Either may be null.
     const uint32_t* tile_order;
     uint32_t* tile_cost;
+    uint32_t tunable;                // 1: some knob above differs from its default -> the TUNABLE kernel instantiation
 };
 
 }  // namespace brt

@@ -93,7 +93,7 @@ typedef struct brt_stats {
     double   gather_ms;        /* tile copy-out / gather time */
     double   total_ms;         /* host wall time of the call */
     uint32_t lds_bytes;        /* dynamic LDS per workgroup of the trace kernel */
-    uint32_t scene_in_lds;     /* 1 if spheres + BVH + materials are LDS-resident */
+    uint32_t scene_in_lds;     /* 1: BVH + spheres LDS-resident; 2: the top levels of the BVH in LDS, the rest from L2; 0: all from L2 */
     uint32_t n_workgroups;
     uint32_t threads_per_workgroup;
 } brt_stats;

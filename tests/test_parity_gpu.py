@@ -505,6 +505,10 @@ def test_sample_count_zero_is_zero_over_zero(plugin, oracle, level):
     {"BRT_WGQ_BATCH": "512", "BRT_FORCE_GLOBAL_SCENE": "1", "BRT_REFILL_MIN": "5"},
     # who takes pooled paths over: nearly full waves too, only thin ones (thinner than the donors: paths wait in the pool)
     {"BRT_POOL_ADOPT": "62"}, {"BRT_POOL_ADOPT": "20", "BRT_DRAIN_DONATE": "40"}, {"BRT_POOL_ADOPT": "0"},
+    # the knobs-live instantiation with every knob at its default; top-of-tree LDS tile of 1 / 37 / 300 / all records
+    {"BRT_TUNABLE": "1"}, {"BRT_FORCE_LDS_TOP": "1"}, {"BRT_FORCE_LDS_TOP": "37"},
+    {"BRT_FORCE_LDS_TOP": "300", "BRT_TUNABLE": "1"}, {"BRT_FORCE_LDS_TOP": "100000"},
+    {"BRT_FORCE_LDS_TOP": "64", "BRT_BLOCK_THREADS": "512", "BRT_WALK_EXIT": "5"},
 ])
 def test_tuning_knobs_do_not_change_results(plugin, oracle, env):
     b = brt.generate_scene(brt.SCENE_COVER, 1)
@@ -526,6 +530,8 @@ def test_tuning_knobs_do_not_change_results(plugin, oracle, env):
     assert {k: stats[k] for k in COUNTER_KEYS} == cnt
     if "BRT_FORCE_GLOBAL_SCENE" in env:
         assert stats["scene_in_lds"] == 0
+    if "BRT_FORCE_LDS_TOP" in env:
+        assert stats["scene_in_lds"] == 2
     if "BRT_BLOCK_THREADS" in env:
         assert stats["threads_per_workgroup"] == int(env["BRT_BLOCK_THREADS"])
 
@@ -559,7 +565,11 @@ def _random_case(rng):
     return b, lvl, cam, win, w, h
 
 
-def test_randomized_scenes_bit_exact(plugin, oracle):
+@pytest.mark.parametrize("lds_top", [None, "5"])
+def test_randomized_scenes_bit_exact(plugin, oracle, lds_top, monkeypatch):
+    # lds_top: the same scenes through the SCENE_LDS_TOP kernel with a 5-record tile (most records then come from L2)
+    if lds_top:
+        monkeypatch.setenv("BRT_FORCE_LDS_TOP", lds_top)
     rng = np.random.default_rng(2024)
     for case in range(40):
         b, lvl, cam, win, w, h = _random_case(rng)

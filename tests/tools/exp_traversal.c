@@ -1,0 +1,296 @@
+/*
+ * exp_traversal.c -- EXPERIMENT (test infrastructure, not product): wave-level cost of BVH traversal variants.
+ *
+ * Simulates what one 64-lane wave of k_trace_persistent does on an 8x8 tile -- a lane per pixel, one ray segment
+ * per round, the nested walk loop with its leaf vote and early exit -- on the CPU, with the ORACLE's own arithmetic
+ * for rays, hits and scattering (this file includes oracle/bevyray_oracle.c), and counts how often the wave
+ * executes the interior body and the leaf body, for:
+ *   width 2 / 4 / 8 nodes (the caller's binary tree collapsed, or a binned-SAH tree built here),
+ *   reference order vs near-first order, with or without culling at pop time,
+ *   leaves visited as a separate step, or their spheres tested inside the parent's step.
+ * All variants return the same hit (closest t); only the work differs.  Used to decide which kernel to build.
+ */
+#include "../../oracle/bevyray_oracle.c"
+
+#include <stdio.h>
+
+#define MAXW 8
+typedef struct {
+    int n;                       /* children in use */
+    float bmin[MAXW][3], bmax[MAXW][3];
+    int child[MAXW];             /* >= 0: wide node id; < 0: leaf, sphere id = -child-1 */
+} WNode;
+
+typedef struct { WNode* nodes; int n_nodes; int root_is_leaf; int root_leaf; } WTree;
+
+static float box_area(const float* lo, const float* hi) {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+
+/* collapse the binary tree (BVHNode array, leaves of 1 sphere) rooted at `bn` into a wide node */
+static int collapse(const BVHNode* b, uint32_t bn, int width, WTree* t) {
+    int id = t->n_nodes++;
+    uint32_t kids[MAXW]; int nk = 2;
+    kids[0] = b[bn].index; kids[1] = b[bn].index + 1;
+    for (;;) {
+        if (nk >= width) break;
+        int best = -1; float best_a = -1.0f;
+        for (int i = 0; i < nk; i++) {
+            if (b[kids[i]].model_count > 0) continue;
+            float a = box_area(&b[kids[i]].minx, &b[kids[i]].maxx);
+            if (a > best_a) { best_a = a; best = i; }
+        }
+        if (best < 0) break;
+        uint32_t k = kids[best];
+        /* keep the reference's child order: the pair replaces its parent in place */
+        for (int i = nk; i > best + 1; i--) kids[i] = kids[i - 1];
+        kids[best] = b[k].index; kids[best + 1] = b[k].index + 1;
+        nk++;
+    }
+    WNode* w = &t->nodes[id];
+    w->n = nk;
+    for (int i = 0; i < nk; i++) {
+        const BVHNode* c = &b[kids[i]];
+        w->bmin[i][0] = c->minx; w->bmin[i][1] = c->miny; w->bmin[i][2] = c->minz;
+        w->bmax[i][0] = c->maxx; w->bmax[i][1] = c->maxy; w->bmax[i][2] = c->maxz;
+    }
+    for (int i = 0; i < nk; i++) {
+        const BVHNode* c = &b[kids[i]];
+        int ch = c->model_count > 0 ? -(int)c->index - 1 : collapse(b, kids[i], width, t);
+        t->nodes[id].child[i] = ch;
+    }
+    return id;
+}
+
+/* ---- binned SAH BVH2 over the padded sphere boxes (Model::aabb, extract.rs:220-227) -> BVHNode array ---- */
+typedef struct { float lo[3], hi[3]; uint32_t id; } Prim;
+static void grow(float* lo, float* hi, const float* plo, const float* phi) {
+    for (int k = 0; k < 3; k++) { if (plo[k] < lo[k]) lo[k] = plo[k]; if (phi[k] > hi[k]) hi[k] = phi[k]; }
+}
+static void sah_build(Prim* p, int n, BVHNode* out, uint32_t slot, uint32_t* n_out) {
+    float lo[3] = {INF, INF, INF}, hi[3] = {-INF, -INF, -INF};
+    for (int i = 0; i < n; i++) grow(lo, hi, p[i].lo, p[i].hi);
+    BVHNode* nd = &out[slot];
+    memset(nd, 0, sizeof *nd);
+    nd->minx = lo[0]; nd->miny = lo[1]; nd->minz = lo[2]; nd->maxx = hi[0]; nd->maxy = hi[1]; nd->maxz = hi[2];
+    if (n == 1) { nd->index = p[0].id; nd->model_count = 1; return; }
+    /* full sweep SAH on each axis (n is small) */
+    int best_axis = 0, best_split = n / 2; float best_cost = INF;
+    float* right_area = (float*)malloc(sizeof(float) * (size_t)n);
+    for (int axis = 0; axis < 3; axis++) {
+        for (int i = 1; i < n; i++) {           /* insertion sort by centroid */
+            Prim key = p[i]; float kc = key.lo[axis] + key.hi[axis]; int j = i - 1;
+            while (j >= 0 && p[j].lo[axis] + p[j].hi[axis] > kc) { p[j + 1] = p[j]; j--; }
+            p[j + 1] = key;
+        }
+        float rlo[3] = {INF, INF, INF}, rhi[3] = {-INF, -INF, -INF};
+        for (int i = n - 1; i > 0; i--) { grow(rlo, rhi, p[i].lo, p[i].hi); right_area[i] = box_area(rlo, rhi); }
+        float llo[3] = {INF, INF, INF}, lhi[3] = {-INF, -INF, -INF};
+        for (int i = 1; i < n; i++) {
+            grow(llo, lhi, p[i - 1].lo, p[i - 1].hi);
+            float cost = box_area(llo, lhi) * (float)i + right_area[i] * (float)(n - i);
+            if (cost < best_cost) { best_cost = cost; best_axis = axis; best_split = i; }
+        }
+    }
+    free(right_area);
+    for (int i = 1; i < n; i++) {
+        Prim key = p[i]; float kc = key.lo[best_axis] + key.hi[best_axis]; int j = i - 1;
+        while (j >= 0 && p[j].lo[best_axis] + p[j].hi[best_axis] > kc) { p[j + 1] = p[j]; j--; }
+        p[j + 1] = key;
+    }
+    uint32_t first = *n_out; *n_out += 2;
+    nd->index = first; nd->model_count = 0;
+    sah_build(p, best_split, out, first, n_out);
+    sah_build(p + best_split, n - best_split, out, first + 1, n_out);
+}
+
+/* ---- per-lane walk over a wide tree ---- */
+typedef struct { int id; float tnear; } SEnt;
+typedef struct {
+    int cur;            /* >= 0 wide node, <= -2: leaf (sphere -cur-2), -1: done */
+    float cur_tnear;
+    SEnt stack[256]; int sp;
+    float closest; int closest_idx;
+    Ray ray; vec3 inv;
+} Walk;
+enum { DONE = -1 };
+static inline int is_int(int c) { return c >= 0; }
+static inline int is_leaf(int c) { return c <= -2; }
+
+typedef struct {
+    int width, near_first, pop_cull, leaf_in_parent;
+    int vote, exit_lanes;
+} Variant;
+
+typedef struct {
+    uint64_t rounds, round_lanes, int_exec, int_lanes, leaf_exec, leaf_lanes, rays, pop_skips, sphere_tests, box_tests;
+} SimCnt;
+
+static float slab(const Walk* w, const float* lo, const float* hi) {
+    return ray_bounding_dst(w->ray, V(lo[0], lo[1], lo[2]), V(hi[0], hi[1], hi[2]));
+}
+static void sphere(const Scene* s, Walk* w, int idx, SimCnt* c) {
+    c->sphere_tests++;
+    float t = hit_sphere(&s->models[idx], w->ray);
+    if (t != -1.0f && t > 0.001f && t < w->closest) { w->closest = t; w->closest_idx = idx; }
+}
+static void pop(Walk* w, const Variant* v, SimCnt* c) {
+    for (;;) {
+        if (w->sp == 0) { w->cur = DONE; return; }
+        SEnt e = w->stack[--w->sp];
+        if (v->pop_cull && !(e.tnear < w->closest)) { c->pop_skips++; continue; }
+        w->cur = e.id; w->cur_tnear = e.tnear; return;
+    }
+}
+static void step_interior(const Scene* s, const WTree* t, Walk* w, const Variant* v, SimCnt* c) {
+    const WNode* n = &t->nodes[w->cur];
+    SEnt hit[MAXW]; int nh = 0;
+    for (int i = 0; i < n->n; i++) {
+        if (v->leaf_in_parent && n->child[i] < 0) { sphere(s, w, -n->child[i] - 1, c); continue; }
+        c->box_tests++;
+        float d = slab(w, n->bmin[i], n->bmax[i]);
+        if (d != INF && d < w->closest) { hit[nh].id = n->child[i] < 0 ? n->child[i] - 1 : n->child[i]; hit[nh].tnear = d; nh++; }
+    }
+    if (v->near_first) {   /* farthest pushed first */
+        for (int i = 1; i < nh; i++) { SEnt k = hit[i]; int j = i - 1; while (j >= 0 && hit[j].tnear < k.tnear) { hit[j + 1] = hit[j]; j--; } hit[j + 1] = k; }
+    }
+    /* leaf_in_parent may have shrunk closest after some boxes were accepted: cull again when pushing */
+    for (int i = 0; i < nh; i++) if (!v->pop_cull || hit[i].tnear < w->closest) w->stack[w->sp++] = hit[i];
+    pop(w, v, c);
+}
+static void step_leaf(const Scene* s, Walk* w, const Variant* v, SimCnt* c) {
+    sphere(s, w, -w->cur - 2, c);
+    pop(w, v, c);
+}
+
+typedef struct {
+    int active, in_flight;
+    uint32_t rng, sample, bounce;
+    float uvx, uvy, first_depth;
+    vec3 tput;
+    Walk w;
+} Lane;
+
+/* one tile = one wave; runs until the wave has thinned to `stop_live` live lanes (the real kernel hands the rest over) */
+static void sim_tile(const Scene* s, const WTree* t, const Variant* v, uint32_t tx, uint32_t ty, uint32_t W, uint32_t H,
+                     int stop_live, SimCnt* c) {
+    static __thread Lane L[64];
+    int live = 0;
+    for (int l = 0; l < 64; l++) {
+        uint32_t px = tx * 8 + (l & 7), py = ty * 8 + (l >> 3);
+        Lane* a = &L[l];
+        memset(a, 0, sizeof *a);
+        if (px >= W || py >= H) continue;
+        a->uvx = ((float)px + 0.5f) / (float)W; a->uvy = ((float)py + 0.5f) / (float)H;
+        a->rng = f32_to_u32((s->window.random_seed * 10000.0f) * (a->uvx * 402.0f) * (a->uvy * 31.5f));
+        a->active = 1; live++;
+    }
+    while (live > stop_live) {
+        c->rounds++; c->round_lanes += (uint64_t)live;
+        int n_walking = 0;
+        for (int l = 0; l < 64; l++) {
+            Lane* a = &L[l];
+            if (!a->active) continue;
+            if (!a->in_flight) {
+                if (a->bounce == 0) {
+                    a->w.ray = random_ray_from_uv(s, a->uvx, a->uvy, &a->rng);
+                    a->tput = V(1, 1, 1); a->first_depth = INF;
+                }
+                Walk* w = &a->w;
+                w->inv = V(1.0f / w->ray.direction.x, 1.0f / w->ray.direction.y, 1.0f / w->ray.direction.z);
+                w->closest = INF; w->closest_idx = -1; w->sp = 0;
+                w->cur = t->root_is_leaf ? -t->root_leaf - 2 : 0; w->cur_tnear = 0.0f;
+            }
+            n_walking++;
+        }
+        int exit_at = n_walking >> 1; if (exit_at > v->exit_lanes) exit_at = v->exit_lanes;
+        for (;;) {
+            for (;;) {
+                int ni = 0;
+                for (int l = 0; l < 64; l++) if (L[l].active && is_int(L[l].w.cur)) ni++;
+                if (!ni) break;
+                c->int_exec++; c->int_lanes += (uint64_t)ni;
+                for (int l = 0; l < 64; l++) if (L[l].active && is_int(L[l].w.cur)) step_interior(s, t, &L[l].w, v, c);
+                int nl = 0;
+                for (int l = 0; l < 64; l++) if (L[l].active && is_leaf(L[l].w.cur)) nl++;
+                if (nl >= v->vote) break;
+            }
+            int nl = 0;
+            for (int l = 0; l < 64; l++) if (L[l].active && is_leaf(L[l].w.cur)) nl++;
+            if (nl) {
+                c->leaf_exec++; c->leaf_lanes += (uint64_t)nl;
+                for (int l = 0; l < 64; l++) if (L[l].active && is_leaf(L[l].w.cur)) step_leaf(s, &L[l].w, v, c);
+            }
+            int nw = 0;
+            for (int l = 0; l < 64; l++) if (L[l].active && L[l].w.cur != DONE) nw++;
+            if (nw <= exit_at) break;
+        }
+        for (int l = 0; l < 64; l++) {
+            Lane* a = &L[l];
+            if (!a->active) continue;
+            a->in_flight = a->w.cur != DONE;
+            if (a->in_flight) continue;
+            c->rays++;
+            Walk* w = &a->w;
+            if (a->bounce == 0) a->first_depth = w->closest;
+            int ended = 0;
+            if (w->closest == INF) ended = 1;
+            else {
+                HitInfo h;
+                const Model* m = &s->models[w->closest_idx];
+                h.distance = w->closest;
+                h.position = ray_at(w->ray, w->closest);
+                h.normal = normalize(vsub(h.position, V(m->px, m->py, m->pz)));
+                h.material = m->material_id;
+                h.front_face = dot(w->ray.direction, h.normal) < 0.0f;
+                vec3 att;
+                int absorbed = scatter(s, &w->ray, &att, &h, &a->rng);
+                if (absorbed) ended = 1;
+                else { a->bounce++; if (a->bounce > s->camera.bounce_count) ended = 1; }
+            }
+            if (ended) {
+                a->bounce = 0; a->sample++;
+                if (a->sample == s->camera.sample_count) { a->active = 0; live--; }
+            }
+        }
+    }
+}
+
+/* Python entry: runs `n_tiles` tiles (tile coordinates in tiles_xy) through one variant; out10 = SimCnt */
+int exp_run(const void* models, uint32_t n_models, const void* materials, uint32_t n_materials, const void* bvh_nodes,
+            uint32_t n_nodes, const void* camera80, const void* window16, uint32_t W, uint32_t H, const uint32_t* tiles_xy,
+            uint32_t n_tiles, int width, int near_first, int pop_cull, int leaf_in_parent, int vote, int exit_lanes,
+            int use_sah, int stop_live, uint64_t* out10) {
+    Scene s;
+    s.models = (const Model*)models; s.n_models = n_models;
+    s.materials = (const Material*)materials; s.n_materials = n_materials;
+    s.bvh = (const BVHNode*)bvh_nodes; s.n_nodes = n_nodes;
+    memcpy(&s.camera, camera80, 80); memcpy(&s.window, window16, 16);
+    s.level = 3; s.tan_half_fov = oracle_tan_half_fov(s.camera.fov);
+    BVHNode* own = NULL;
+    const BVHNode* b = s.bvh;
+    if (use_sah) {
+        Prim* p = (Prim*)malloc(sizeof(Prim) * n_models);
+        for (uint32_t i = 0; i < n_models; i++) {
+            const Model* m = &s.models[i]; float r = m->radius + 0.1f;
+            p[i].lo[0] = m->px - r; p[i].lo[1] = m->py - r; p[i].lo[2] = m->pz - r;
+            p[i].hi[0] = m->px + r; p[i].hi[1] = m->py + r; p[i].hi[2] = m->pz + r; p[i].id = i;
+        }
+        own = (BVHNode*)calloc(2 * (size_t)n_models, sizeof(BVHNode));
+        uint32_t n_out = 1;
+        sah_build(p, (int)n_models, own, 0, &n_out);
+        free(p);
+        b = own;
+    }
+    WTree t; t.nodes = (WNode*)calloc(n_models + 1, sizeof(WNode)); t.n_nodes = 0;
+    t.root_is_leaf = b[0].model_count > 0; t.root_leaf = (int)b[0].index;
+    if (!t.root_is_leaf) collapse(b, 0, width, &t);
+    Variant v = {width, near_first, pop_cull, leaf_in_parent, vote, exit_lanes};
+    SimCnt c; memset(&c, 0, sizeof c);
+    for (uint32_t i = 0; i < n_tiles; i++) sim_tile(&s, &t, &v, tiles_xy[2 * i], tiles_xy[2 * i + 1], W, H, stop_live, &c);
+    memcpy(out10, &c, sizeof c);
+    out10[10] = (uint64_t)t.n_nodes;
+    free(t.nodes); free(own);
+    return 0;
+}

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Driver of exp_traversal.c: wave-level execution counts of traversal variants on a tile sample of the headline frame."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import numpy as np
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("BRT_NO_TORCH", "1")
+import bevyray_amd as brt  # noqa: E402
+
+so = os.path.join(HERE, "_exp_traversal.so")
+src = os.path.join(HERE, "exp_traversal.c")
+if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-o", so, src, "-lm"])
+lib = C.CDLL(so)
+VP, U32, I = C.c_void_p, C.c_uint32, C.c_int
+lib.exp_run.argtypes = [VP, U32, VP, U32, VP, U32, VP, VP, U32, U32, VP, U32, I, I, I, I, I, I, I, I, VP]
+
+
+def run(b, cam, win, W, H, tiles, width=2, near=0, cull=0, lip=0, vote=12, exit_lanes=12, sah=0, stop_live=40):
+    out = np.zeros(16, np.uint64)
+    t = np.ascontiguousarray(tiles, np.uint32)
+    lib.exp_run(b.models.ctypes.data, len(b.models), b.materials.ctypes.data, len(b.materials), b.bvh.ctypes.data, len(b.bvh),
+                cam.ctypes.data, win.ctypes.data, W, H, t.ctypes.data, len(t), width, near, cull, lip, vote, exit_lanes, sah,
+                stop_live, out.ctypes.data)
+    k = ["rounds", "round_lanes", "int_exec", "int_lanes", "leaf_exec", "leaf_lanes", "rays", "pop_skips", "sphere_tests", "box_tests", "nodes"]
+    return dict(zip(k, [int(x) for x in out[:11]]))
+
+
+COST_INT = {2: 64, 4: 135, 8: 260}     # wave instructions per interior-body execution (estimates; width 2 measured)
+COST_LEAF = 75
+
+
+def main():
+    scene = int(sys.argv[1]) if len(sys.argv) > 1 else brt.SCENE_COVER
+    W, H, spp, bounces = 1920, 1080, 64, 8
+    b = brt.generate_scene(scene, 1)
+    lvl, cam, win = brt.cover_camera(W, H, spp, bounces)
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+    rng = np.random.default_rng(5)
+    tiles = np.stack([rng.integers(0, W // 8, n), rng.integers(0, H // 8, n)], 1)
+    print(f"{n} tiles, scene {scene}, {len(b.models)} spheres")
+    hdr = f"{'variant':44s} {'int/ray':>8s} {'leaf/ray':>8s} {'box/ray':>8s} {'sph/ray':>8s} {'intX/rnd':>8s} {'lanes':>6s} {'leafX/rnd':>9s} {'lanes':>6s} {'walk instr/round':>16s}"
+    print(hdr)
+    for name, kw in [
+        ("w2 reference order (baseline)", dict()),
+        ("w2 near-first + pop cull", dict(near=1, cull=1)),
+        ("w2 near-first + cull + leaf-in-parent", dict(near=1, cull=1, lip=1)),
+        ("w2 SAH tree, reference order", dict(sah=1)),
+        ("w2 SAH near-first + cull", dict(sah=1, near=1, cull=1)),
+        ("w4 reference order", dict(width=4)),
+        ("w4 near-first + cull", dict(width=4, near=1, cull=1)),
+        ("w4 unordered + cull", dict(width=4, near=0, cull=1)),
+        ("w4 near-first + cull + leaf-in-parent", dict(width=4, near=1, cull=1, lip=1)),
+        ("w4 unordered + cull + leaf-in-parent", dict(width=4, near=0, cull=1, lip=1)),
+        ("w4 SAH near-first + cull", dict(width=4, near=1, cull=1, sah=1)),
+        ("w4 SAH near-first + cull + lip", dict(width=4, near=1, cull=1, sah=1, lip=1)),
+        ("w8 reference order", dict(width=8)),
+        ("w8 near-first + cull", dict(width=8, near=1, cull=1)),
+        ("w8 unordered + cull", dict(width=8, near=0, cull=1)),
+        ("w8 near-first + cull + leaf-in-parent", dict(width=8, near=1, cull=1, lip=1)),
+        ("w8 SAH near-first + cull + lip", dict(width=8, near=1, cull=1, sah=1, lip=1)),
+    ]:
+        r = run(b, cam, win, W, H, tiles, **kw)
+        w = kw.get("width", 2)
+        rounds = r["rounds"]
+        cost = (r["int_exec"] * COST_INT[w] + r["leaf_exec"] * COST_LEAF) / rounds
+        print(f"{name:44s} {r['int_lanes']/r['rays']:8.2f} {r['leaf_lanes']/r['rays']:8.2f} {r['box_tests']/r['rays']:8.1f} {r['sphere_tests']/r['rays']:8.2f} "
+              f"{r['int_exec']/rounds:8.2f} {r['int_lanes']/max(1,r['int_exec']):6.1f} {r['leaf_exec']/rounds:9.2f} {r['leaf_lanes']/max(1,r['leaf_exec']):6.1f} {cost:16.0f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
