@@ -122,6 +122,7 @@ struct ScenePtrs {
     // tree in breadth-first order), `pairs_far` the whole array in global memory
     const char* pairs_far;
     uint32_t near_bytes;
+    uint32_t near_base;      // LDS byte address of the tile
     bool boxes_ordered;      // every child box finite with min <= max (decided at upload)
     const float4* spheres;
     const uint32_t* sphere_material;
@@ -262,13 +263,36 @@ BRT_DEV void walk_interior_step(const ScenePtrs& sc, f3 o, f3 inv, uint32_t ox, 
     const uint32_t ro = Desc<D16>::record_offset(cur);   // byte offset of the pair record
     float4 gx, gy, gz;                                   // per axis { near L, near R, far L, far R }
     uint2 D;
-    if (MODE == SCENE_LDS_TOP && ro >= sc.near_bytes) {
-        // a record below the LDS tile: from global memory (L2).  Lanes of one wave take either side.
-        const char* rec = sc.pairs_far + ro;
-        gx = *reinterpret_cast<const float4*>(rec + ox);
-        gy = *reinterpret_cast<const float4*>(rec + oy);
-        gz = *reinterpret_cast<const float4*>(rec + oz);
-        D = *reinterpret_cast<const uint2*>(rec + PAIR_DESC);
+    if (MODE == SCENE_LDS_TOP) {
+        // Lanes of one wave take either side.  The two sides use pointers of DIFFERENT address spaces on purpose:
+        // with generic pointers the optimiser merges the branches into one set of flat_load instructions, which
+        // send every lane through the texture addresser (measured on the 10k-sphere scene: TA busy 74 % with or
+        // without the tile); ds_read_b128 for the lanes in the tile leaves the vector-memory path to the others.
+        typedef float vf4 __attribute__((ext_vector_type(4)));
+        typedef uint32_t vu2 __attribute__((ext_vector_type(2)));
+        typedef const __attribute__((address_space(3))) vf4 lds_f4;
+        typedef const __attribute__((address_space(3))) vu2 lds_u2;
+        typedef const __attribute__((address_space(1))) vf4 glb_f4;
+        typedef const __attribute__((address_space(1))) vu2 glb_u2;
+        vf4 vx, vy, vz;
+        vu2 vd;
+        if (ro < sc.near_bytes) {
+            const uint32_t rec = sc.near_base + ro;      // LDS byte address of the record
+            vx = *reinterpret_cast<lds_f4*>((uintptr_t)(rec + ox));
+            vy = *reinterpret_cast<lds_f4*>((uintptr_t)(rec + oy));
+            vz = *reinterpret_cast<lds_f4*>((uintptr_t)(rec + oz));
+            vd = *reinterpret_cast<lds_u2*>((uintptr_t)(rec + PAIR_DESC));
+        } else {
+            const char* rec = sc.pairs_far + ro;
+            vx = *(glb_f4*)(rec + ox);
+            vy = *(glb_f4*)(rec + oy);
+            vz = *(glb_f4*)(rec + oz);
+            vd = *(glb_u2*)(rec + PAIR_DESC);
+        }
+        gx = make_float4(vx.x, vx.y, vx.z, vx.w);
+        gy = make_float4(vy.x, vy.y, vy.z, vy.w);
+        gz = make_float4(vz.x, vz.y, vz.z, vz.w);
+        D = make_uint2(vd.x, vd.y);
     } else {
         const char* rec = sc.pairs + ro;
         gx = *reinterpret_cast<const float4*>(rec + ox);

@@ -164,6 +164,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     sc.boxes_ordered = sv.boxes_ordered != 0u;
     sc.pairs_far = reinterpret_cast<const char*>(sv.pairs);
     sc.near_bytes = 0u;
+    sc.near_base = 0u;
     if (MODE == SCENE_LDS) {
         // carve: pair records | spheres | leaf_table | sphere_material | stacks
         const uint32_t pair_granules = (uint32_t)(pair_array_bytes(sv.n_pairs) / 16);
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             for (uint32_t i = threadIdx.x; i < pair_granules; i += blockDim.x) l_pairs[i] = g_pairs[i];
             sc.pairs = reinterpret_cast<const char*>(l_pairs);
             sc.near_bytes = sv.lds_pairs * PAIR_BYTES;
+            sc.near_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(l_pairs);
             stacks = reinterpret_cast<StackT*>(l_pairs + pair_granules);
         } else {
             sc.pairs = reinterpret_cast<const char*>(sv.pairs);

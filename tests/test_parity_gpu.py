@@ -168,7 +168,7 @@ def test_scenes_match_oracle(plugin, oracle, kind, w, h, spp, bounces):
     b = brt.generate_scene(kind, 1)
     lvl, cam, win = brt.cover_camera(w, h, spp, bounces)
     _, stats = render_both(plugin, oracle, b, lvl, cam, win, w, h)
-    assert stats["scene_in_lds"] == (0 if kind == brt.SCENE_STRESS_GRID else 1)
+    assert stats["scene_in_lds"] == (2 if kind == brt.SCENE_STRESS_GRID else 1)   # 2: top of the tree in LDS, the rest from L2
     # timing build (no counters) gives the same pixels and ray count
     render_both(plugin, oracle, b, lvl, cam, win, w, h, flags=0)
 
@@ -426,7 +426,7 @@ def test_config5_10k_spheres_full_size(plugin, oracle):
     lvl, cam, win = brt.cover_camera(w, h, spp, bounces)
     f1 = plugin.node.run(lvl, cam, win, w, h, buffers=b)
     s1 = dict(plugin.node.last_stats)
-    assert s1["scene_in_lds"] == 0
+    assert s1["scene_in_lds"] in (0, 2)   # not LDS resident: all from L2, or the top of the tree in an LDS tile
     f2 = plugin.node.run(lvl, cam, win, w, h)
     assert np.array_equal(f1.view(np.uint32), f2.view(np.uint32)) and plugin.node.last_stats["rays"] == s1["rays"]
     _frame_properties(f1, s1, w, h, spp, bounces)
