@@ -27,7 +27,7 @@ class BrtStats(C.Structure):
         ("sphere_tests", C.c_uint64), ("hits", C.c_uint64), ("paths", C.c_uint64),
         ("kernel_ms", C.c_double), ("gather_ms", C.c_double), ("total_ms", C.c_double),
         ("lds_bytes", C.c_uint32), ("scene_in_lds", C.c_uint32), ("n_workgroups", C.c_uint32),
-        ("threads_per_workgroup", C.c_uint32),
+        ("threads_per_workgroup", C.c_uint32), ("prepass_ms", C.c_double),
     ]
 
     def as_dict(self):

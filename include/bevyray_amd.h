@@ -96,6 +96,8 @@ typedef struct brt_stats {
     uint32_t scene_in_lds;     /* 1: BVH + spheres LDS-resident; 2: the top levels of the BVH in LDS, the rest from L2; 0: all from L2 */
     uint32_t n_workgroups;
     uint32_t threads_per_workgroup;
+    double   prepass_ms;       /* kernel time of the dispatch-order pre-pass that ran before this frame (first frame
+                                  of a view on the synchronous paths; else 0).  Not part of kernel_ms. */
 } brt_stats;
 
 uint32_t brt_abi_version(void);
