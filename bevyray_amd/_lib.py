@@ -13,7 +13,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "libbevyray_amd.so")
+LIB_PATH = os.environ.get("BRT_LIB_PATH") or os.path.join(_HERE, "libbevyray_amd.so")   # BRT_LIB_PATH: A/B of builds
 _SOURCES = ["brt_api.cpp", "brt_host.cpp", "brt_kernels.hip", "brt_trace_prod.hip", "brt_trace_tune.hip", "brt_trace.h",
             "brt_host.h", "brt_kernels.h", "brt_layout.h", "brt_device.h", "brt_ploc.h", "brt_bvh.hip", "Makefile"]
 
@@ -44,6 +44,8 @@ def _stale() -> bool:
 
 def build(force: bool = False) -> str:
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if os.environ.get("BRT_LIB_PATH"):
+        return LIB_PATH          # an explicitly chosen build is used as it is
     with _lock:
         if force or _stale():
             cmd = ["make", "-C", _CSRC, "-j", str(min(6, os.cpu_count() or 1))] + (["-B"] if force else [])

@@ -174,8 +174,9 @@ int32_t make_frame_params(brt_ctx* ctx, const void* camera80, const void* window
     fp.crit_begin = fp.crit_end = 0;   // set by attach_tile_order
     fp.wgq_batch = env_u32("BRT_WGQ_BATCH", 0) & ~63u;
     if (fp.wgq_batch > 512u) fp.wgq_batch = 512u;
+    fp.policy_flags = env_u32("BRT_POLICY_OR_SHORT_CIRCUIT", 0) ? 1u : 0u;
     // any knob off its default (or the lane queue asked for) -> the TUNABLE instantiation of the kernel
-    fp.tunable = (fp.bottom_up != 0u || fp.refill_min != kRefillMin || fp.walk_exit_lanes != kWalkExitLanes ||
+    fp.tunable = (fp.policy_flags != 0u || fp.bottom_up != 0u || fp.refill_min != kRefillMin || fp.walk_exit_lanes != kWalkExitLanes ||
                   fp.leaf_vote != kLeafVote || fp.drain_donate != kDrainDonate || fp.pool_adopt != kPoolAdopt ||
                   fp.wgq_batch != 0u || env_u32("BRT_LPT_LANE_PERMILLE", 0) != 0u || env_u32("BRT_TUNABLE", 0) != 0u)
                      ? 1u : 0u;

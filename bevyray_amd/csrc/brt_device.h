@@ -461,8 +461,12 @@ BRT_DEV float schlick(float cosine, float ri) {
 // the kind, then ONE rejection loop serves every lane that still needs a ball (metal 1,
 // diffuse 2, glass 0) and ONE normalize serves metal (reflected direction) and glass (incoming
 // direction).  Per lane the RNG draws and the arithmetic are the shader's, in its order.
+// or_short_circuit: the alternative reading of raytrace.wgsl:269 (no RNG draw when cannot_refract); only the
+// TUNABLE kernel instantiation can switch it on (BRT_POLICY_OR_SHORT_CIRCUIT=1), for the alternative-policy
+// fixtures -- the product's policy is "always draw" (DESIGN.md section 2).
 template <bool COUNTERS>
-BRT_DEV bool scatter(const ScenePtrs& sc, f3& o, f3& d, float t, uint32_t idx, uint32_t& rng, f3& attenuation, HitCounters& hc) {
+BRT_DEV bool scatter(const ScenePtrs& sc, f3& o, f3& d, float t, uint32_t idx, uint32_t& rng, f3& attenuation, HitCounters& hc,
+                     bool or_short_circuit = false) {
     const float4 s = sc.spheres[idx];
     const f3 pos = mk3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);          // ray_at, :130-132
     const f3 nrm = normalize3(mk3(pos.x - s.x, pos.y - s.y, pos.z - s.z));    // :356
@@ -520,8 +524,9 @@ BRT_DEV bool scatter(const ScenePtrs& sc, f3& o, f3& d, float t, uint32_t idx, u
             const float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
             const bool cannot_refract = ri * sin_theta > 1.0f;
             const float refl = schlick(cos_theta, ri);
-            const float draw = rng_float(rng);                                // always drawn
-            d = (cannot_refract || refl > draw) ? reflect3(u, nrm) : refract3(u, nrm, ri);
+            bool reflects = cannot_refract;
+            if (!(or_short_circuit && cannot_refract)) reflects = reflects || (refl > rng_float(rng));   // default: always drawn
+            d = reflects ? reflect3(u, nrm) : refract3(u, nrm, ri);
             attenuation = mk3(1.0f, 1.0f, 1.0f);
         }
     }

@@ -202,6 +202,7 @@ struct FrameParams {
     const uint32_t* tile_order;
     uint32_t* tile_cost;
     uint32_t tunable;                // 1: some knob above differs from its default -> the TUNABLE kernel instantiation
+    uint32_t policy_flags;           // TUNABLE only; bit 0: `||` of raytrace.wgsl:269 short-circuits (alternative policy)
 };
 
 }  // namespace brt

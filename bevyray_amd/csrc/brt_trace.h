@@ -91,7 +91,8 @@ BRT_DEV void pixel_finish(const FrameParams& fp, const PixelState& ps, float* ou
 // Returns true when the sample has ended; then `color` is its gamma-encoded colour (:223).
 template <bool COUNTERS>
 BRT_DEV bool shade_segment(const ScenePtrs& sc, const FrameParams& fp, f3& o, f3& d, f3& tput, uint32_t& bounce,
-                           float& first_depth, float t, uint32_t idx, uint32_t& rng, f3& color, HitCounters& hc) {
+                           float& first_depth, float t, uint32_t idx, uint32_t& rng, f3& color, HitCounters& hc,
+                           bool or_short_circuit = false) {
     if (bounce == 0) first_depth = t;                               // :193-195
     f3 light = mk3(0.0f, 0.0f, 0.0f);
     bool ended;
@@ -101,7 +102,7 @@ BRT_DEV bool shade_segment(const ScenePtrs& sc, const FrameParams& fp, f3& o, f3
     } else {
         hc.hits++;
         f3 att;
-        const bool absorbed = scatter<COUNTERS>(sc, o, d, t, idx, rng, att, hc);  // :204
+        const bool absorbed = scatter<COUNTERS>(sc, o, d, t, idx, rng, att, hc, or_short_circuit);  // :204
         if (absorbed) {
             ended = true;                                           // :207-209, light stays 0
         } else {
@@ -440,7 +441,8 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         if (landed) {
             n_rays++;
             f3 color;
-            if (shade_segment<COUNTERS>(sc, fp, o, d, tput, bounce, first_depth, t, idx, ps.rng, color, hc)) {
+            if (shade_segment<COUNTERS>(sc, fp, o, d, tput, bounce, first_depth, t, idx, ps.rng, color, hc,
+                                        TUNABLE && (fp.policy_flags & 1u))) {
                 ps.sum = ps.sum + color;                                                   // :165
                 ps.dsum = ps.dsum + (first_depth == kInf ? fp.fallback_far : first_depth); // :166,219-221
                 ps.sample++;

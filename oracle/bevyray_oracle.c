@@ -75,14 +75,32 @@ static inline vec3 normalize(vec3 v) {
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
-/* IEEE-754-2008 minNum / maxNum, -0 ordered below +0 */
+/* ---- alternative policies (tests/golden/policy_frames.npz) -------------------
+ * Three choices of the numeric policy above are left to the implementation by WGSL, are made by naga/wgpu
+ * in the reference, and are pinned by nothing in the reference.  The default (all 0) is what the product
+ * implements; oracle_set_policy switches this oracle to the alternatives so that fixtures for them exist
+ * the day a real wgpu run can be compared.  Process-wide; set it before a render, reset it after.
+ *   or_short_circuit  raytrace.wgsl:269: 1 = the RNG draw of the right operand of || is skipped when
+ *                     cannot_refract (the WGSL specification's reading)
+ *   minmax_select     raytrace.wgsl:391-394,263,405: 1 = min(a,b) = b < a ? b : a, max(a,b) = a < b ? b : a
+ *   pow_exp2_log2     raytrace.wgsl:415: 1 = pow(x, 5.0) = exp2(5 * log2(x)) (double, rounded to f32 once) */
+static struct { int or_short_circuit, minmax_select, pow_exp2_log2; } g_policy = {0, 0, 0};
+void oracle_set_policy(int or_short_circuit, int minmax_select, int pow_exp2_log2) {
+    g_policy.or_short_circuit = or_short_circuit;
+    g_policy.minmax_select = minmax_select;
+    g_policy.pow_exp2_log2 = pow_exp2_log2;
+}
+
+/* IEEE-754-2008 minNum / maxNum, -0 ordered below +0 (default policy) */
 static inline float min_f(float a, float b) {
+    if (g_policy.minmax_select) return b < a ? b : a;
     if (a != a) return b;
     if (b != b) return a;
     if (a == b) return u2f(f2u(a) | f2u(b));   /* equal values or +-0: keep a sign bit */
     return a < b ? a : b;
 }
 static inline float max_f(float a, float b) {
+    if (g_policy.minmax_select) return a < b ? b : a;
     if (a != a) return b;
     if (b != b) return a;
     if (a == b) return u2f(f2u(a) & f2u(b));   /* +-0: +0 wins */
@@ -282,8 +300,17 @@ static inline float reflectance_(float cosine, float refraction_index) {
     float r0 = (1.0f - refraction_index) / (1.0f + refraction_index);
     r0 = r0 * r0;
     float x = 1.0f - cosine;
-    float x2 = x * x;
-    return r0 + (1.0f - r0) * ((x2 * x2) * x);
+    float p5;
+    if (g_policy.pow_exp2_log2) {
+        if (x != x || x < 0.0f) p5 = NAN;
+        else if (x == 0.0f) p5 = 0.0f;
+        else if (isinf(x)) p5 = INFINITY;
+        else p5 = (float)pow(2.0, 5.0 * log2((double)x));
+    } else {
+        float x2 = x * x;
+        p5 = (x2 * x2) * x;
+    }
+    return r0 + (1.0f - r0) * p5;
 }
 
 /* raytrace.wgsl:418-421 */
@@ -314,11 +341,17 @@ static int scatter(const Scene* s, Ray* scattered, vec3* attenuation, const HitI
             float cos_theta = min_f(dot(vneg(unit_direction), hit->normal), 1.0f);
             float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
             int cannot_refract = ri * sin_theta > 1.0f;
-            /* both operands of || are evaluated: the draw always happens */
-            float refl = reflectance_(cos_theta, ri);
-            float draw = rngNextFloat(state);
+            int reflects;
+            if (g_policy.or_short_circuit) {
+                reflects = cannot_refract || reflectance_(cos_theta, ri) > rngNextFloat(state);
+            } else {
+                /* default policy: both operands of || are evaluated, the draw always happens */
+                float refl = reflectance_(cos_theta, ri);
+                float draw = rngNextFloat(state);
+                reflects = cannot_refract || refl > draw;
+            }
             vec3 direction;
-            if (cannot_refract || refl > draw) direction = reflect_(unit_direction, hit->normal);
+            if (reflects) direction = reflect_(unit_direction, hit->normal);
             else direction = refract_(unit_direction, hit->normal, ri);
 
             scattered->origin = hit->position;

@@ -26,6 +26,10 @@ int oracle_render_strided(const void* models, uint32_t n_models, const void* mat
                           uint32_t row_step, const float* raster_rgba, const float* raster_depth, float* out_rgba,
                           uint64_t* counters5, int n_threads);
 
+/* Alternative readings of three implementation-defined points of the shader (bevyray_oracle.c, "alternative
+ * policies"); all 0 = the default policy, which is what the product implements.  Process-wide. */
+void oracle_set_policy(int or_short_circuit, int minmax_select, int pow_exp2_log2);
+
 float oracle_tan_half_fov(float fov);
 uint32_t oracle_rng_next(uint32_t state);
 float oracle_rng_float(uint32_t* state);

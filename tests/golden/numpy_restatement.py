@@ -7,6 +7,19 @@ suite) against those frames bit for bit.  Far too slow for anything but a few hu
 
 Same numeric policy as DESIGN.md section 3 (every np.float32 operation is separately rounded;
 min/max = minNum/maxNum via np.fmin/np.fmax; pow(x,5) as multiplies; tan in double on the host).
+
+POLICY: three choices of that policy are things WGSL leaves to the implementation and that the real
+naga/wgpu lowering may make differently (nothing in the reference pins them).  The default
+is what the product implements; the alternatives exist so that fixtures for them are on file the day a real
+wgpu run can be compared (tests/golden/policy_frames.npz):
+    or_short_circuit   raytrace.wgsl:269 `cannot_refract || reflectance(..) > rngNextFloat(..)`: False (default) =
+                       both operands evaluated, the RNG draw always happens; True = WGSL-spec short circuit, no
+                       draw when cannot_refract
+    minmax             raytrace.wgsl:391-394, 263, 405 min()/max(): "minnum" (default: a NaN operand yields the
+                       other one) or "select" (min(a,b) = b < a ? b : a, max(a,b) = a < b ? b : a: a NaN in the
+                       SECOND operand is dropped, a NaN in the first is returned)
+    pow                raytrace.wgsl:415 pow(1 - cosine, 5.0): "mul" (default: (x*x)*(x*x)*x) or "exp2log2"
+                       (WGSL's definition exp2(5 * log2(x)), evaluated in double and rounded to f32 once)
 """
 import math
 
@@ -63,14 +76,30 @@ def f32_to_u32(f):
     return int(math.floor(float(f)))
 
 
+DEFAULT_POLICY = dict(or_short_circuit=False, minmax="minnum", pow="mul")
+
+
 class Shader:
     """models / materials / bvh: structured arrays with the reference's wire layouts; camera, window: single records."""
 
-    def __init__(self, models, materials, bvh, camera, window, level):
+    def __init__(self, models, materials, bvh, camera, window, level, policy=None):
+        self.policy = dict(DEFAULT_POLICY, **(policy or {}))
         self.models, self.materials, self.bvh = models, materials, bvh
         self.cam, self.win, self.level = camera, window, int(level)
         self.tan_half_fov = F(math.tan(float(F(camera["fov"]) * F(0.5))))
         self.rays = 0
+
+    def fmin(self, a, b):
+        if self.policy["minmax"] == "select":
+            with np.errstate(all="ignore"):
+                return np.where(b < a, b, a).astype(F)[()]
+        return np.fmin(a, b)
+
+    def fmax(self, a, b):
+        if self.policy["minmax"] == "select":
+            with np.errstate(all="ignore"):
+                return np.where(a < b, b, a).astype(F)[()]
+        return np.fmax(a, b)
 
     # raytrace.wgsl:387-398
     def ray_bounding_dst(self, o, d, bmin, bmax):
@@ -78,9 +107,9 @@ class Shader:
             inv = v3(F(1.0) / d[0], F(1.0) / d[1], F(1.0) / d[2])
             tmin = (bmin - o).astype(F) * inv
             tmax = (bmax - o).astype(F) * inv
-            t1, t2 = np.fmin(tmin, tmax), np.fmax(tmin, tmax)
-            t_near = np.fmax(np.fmax(t1[0], t1[1]), t1[2])
-            t_far = np.fmin(np.fmin(t2[0], t2[1]), t2[2])
+            t1, t2 = self.fmin(tmin, tmax), self.fmax(tmin, tmax)
+            t_near = self.fmax(self.fmax(t1[0], t1[1]), t1[2])
+            t_far = self.fmin(self.fmin(t2[0], t2[1]), t2[2])
         hit = (t_far >= t_near) and (t_far > 0)
         return (t_near if t_near > 0 else F(0.0)) if hit else INF
 
@@ -126,20 +155,30 @@ class Shader:
     def reflect(v, n):          # raytrace.wgsl:400-402
         return (v - (F(F(2.0) * dot(v, n)) * n).astype(F)).astype(F)
 
-    @staticmethod
-    def refract(v, n, eta):     # raytrace.wgsl:404-409
-        cos_theta = np.fmin(dot(-v, n), F(1.0))
+    def refract(self, v, n, eta):     # raytrace.wgsl:404-409
+        cos_theta = self.fmin(dot(-v, n), F(1.0))
         perp = (eta * (v + (cos_theta * n).astype(F)).astype(F)).astype(F)
         par = (F(-np.sqrt(np.abs(F(F(1.0) - dot(perp, perp))), dtype=F)) * n).astype(F)
         return (perp + par).astype(F)
 
-    @staticmethod
-    def reflectance(cosine, ri):  # raytrace.wgsl:411-416, pow(x, 5) as multiplies
+    def reflectance(self, cosine, ri):  # raytrace.wgsl:411-416
         r0 = F(F(F(1.0) - ri) / F(F(1.0) + ri))
         r0 = F(r0 * r0)
         x = F(F(1.0) - cosine)
-        x2 = F(x * x)
-        return F(r0 + F(F(F(1.0) - r0) * F(F(x2 * x2) * x)))
+        if self.policy["pow"] == "exp2log2":       # pow(x, 5.0) = exp2(5 * log2(x)), in double, rounded once
+            xf = float(x)
+            if xf != xf or xf < 0.0:
+                p5 = F(np.nan)
+            elif xf == 0.0:
+                p5 = F(0.0)
+            elif xf == math.inf:
+                p5 = F(np.inf)
+            else:
+                p5 = F(math.pow(2.0, 5.0 * math.log2(xf)))
+        else:                                      # default: pow(x, 5) as multiplies
+            x2 = F(x * x)
+            p5 = F(F(x2 * x2) * x)
+        return F(r0 + F(F(F(1.0) - r0) * p5))
 
     # raytrace.wgsl:231-299 -> (absorbed, origin, direction, attenuation)
     def scatter(self, d, hit, rng):
@@ -152,12 +191,16 @@ class Shader:
         if rng.next_float() < F(mat["specular_transmission"]):
             ri = F(F(1.0) / F(mat["ior"])) if hit["front_face"] else F(mat["ior"])
             u = normalize(d)
-            cos_theta = np.fmin(dot(-u, n), F(1.0))
+            cos_theta = self.fmin(dot(-u, n), F(1.0))
             sin_theta = np.sqrt(F(F(1.0) - F(cos_theta * cos_theta)), dtype=F)
             cannot = F(ri * sin_theta) > F(1.0)
-            refl = self.reflectance(cos_theta, ri)
-            draw = rng.next_float()            # both operands of || are evaluated
-            direction = self.reflect(u, n) if (cannot or refl > draw) else self.refract(u, n, ri)
+            if self.policy["or_short_circuit"]:
+                reflects = bool(cannot) or bool(self.reflectance(cos_theta, ri) > rng.next_float())
+            else:
+                refl = self.reflectance(cos_theta, ri)
+                draw = rng.next_float()        # both operands of || are evaluated
+                reflects = bool(cannot or refl > draw)
+            direction = self.reflect(u, n) if reflects else self.refract(u, n, ri)
             return False, hit["position"], direction, v3(1, 1, 1)
         b1 = rng.unit_ball()
         b2 = rng.unit_ball()
@@ -232,8 +275,8 @@ class Shader:
         return np.array([avg[0], avg[1], avg[2], F(1.0)], F)
 
 
-def render(models, materials, bvh, camera, window, level, W, H, raster_rgba=None, raster_depth=None):
-    sh = Shader(models, materials, bvh, camera, window, level)
+def render(models, materials, bvh, camera, window, level, W, H, raster_rgba=None, raster_depth=None, policy=None):
+    sh = Shader(models, materials, bvh, camera, window, level, policy)
     out = np.zeros((H, W, 4), F)
     for py in range(H):
         for px in range(W):

@@ -54,6 +54,8 @@ class Oracle:
         lib.oracle_render_strided.restype = C.c_int
         lib.oracle_render_strided.argtypes = [VP, U32, VP, U32, VP, U32, VP, VP, U32, U32, U32, U32, U32, U32, VP, VP, VP, VP,
                                               C.c_int]
+        lib.oracle_set_policy.restype = None
+        lib.oracle_set_policy.argtypes = [C.c_int, C.c_int, C.c_int]
         lib.oracle_tan_half_fov.restype = F
         lib.oracle_tan_half_fov.argtypes = [F]
         lib.oracle_rng_next.restype = U32
@@ -98,6 +100,19 @@ class Oracle:
             raise RuntimeError(f"oracle_render failed: {rc}")
         names = ["rays", "node_pops", "interior_visits", "sphere_tests", "hits"]
         return out, dict(zip(names, [int(x) for x in cnt]))
+
+    def policy(self, or_short_circuit=False, minmax="minnum", pow="mul"):
+        """Context manager: render under an alternative policy (same names as numpy_restatement.DEFAULT_POLICY)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            self.lib.oracle_set_policy(int(bool(or_short_circuit)), int(minmax == "select"), int(pow == "exp2log2"))
+            try:
+                yield self
+            finally:
+                self.lib.oracle_set_policy(0, 0, 0)
+        return cm()
 
     def rng_floats(self, state, n):
         s = C.c_uint32(state)

@@ -278,3 +278,73 @@ def test_levels_blend_against_raster(oracle):
     lvl, cam, win = brt.cover_camera(w, h, 2, 3, brt.Raytracing.FallbackRaytraced, 0.5)
     f2, _ = oracle.render(b, lvl, cam, win, w, h)
     assert np.array_equal(f2, pure)
+
+
+# ---- alternative readings of the three implementation-defined points (tests/golden/policy_frames.npz) ----------------
+
+POLICIES = {
+    "default": {},
+    "or_short_circuit": dict(or_short_circuit=True),
+    "minmax_select": dict(minmax="select"),
+    "pow_exp2log2": dict(pow="exp2log2"),
+    "all_three": dict(or_short_circuit=True, minmax="select", pow="exp2log2"),
+}
+
+
+def _policy_cases():
+    z = np.load(os.path.join(GOLDEN, "policy_frames.npz"))
+    for name in sorted({k.split(".")[0] for k in z.files}):
+        g = lambda k: z[f"{name}.{k}"]
+        b = brt.Buffers(g("models").view(brt.MODEL_DTYPE), g("materials").view(brt.MATERIAL_DTYPE), g("bvh").view(brt.BVH_NODE_DTYPE))
+        w, h = (int(x) for x in g("size"))
+        yield name, b, g("level").view(brt.LEVEL_DTYPE), g("camera").view(brt.CAMERA_DTYPE), g("window").view(brt.WINDOW_DTYPE), w, h, z
+
+
+def _moved(a, b):
+    same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+    return int((~same).any(axis=2).sum())
+
+
+def test_oracle_reproduces_every_policy_fixture(oracle):
+    """The frames were rendered by the independent numpy restatement under each policy; the C oracle under the
+    same policy must give the same bits (and the same ray count: the `||` policy changes the RNG stream)."""
+    for name, b, lvl, cam, win, w, h, z in _policy_cases():
+        for pname, pol in POLICIES.items():
+            with oracle.policy(**pol):
+                got, cnt = oracle.render(b, lvl, cam, win, w, h)
+            want = z[f"{name}.frame.{pname}"]
+            assert _moved(got, want) == 0, (name, pname)
+            assert cnt["rays"] == int(z[f"{name}.rays.{pname}"][0]), (name, pname)
+    # the policy switch is process-wide: it must be back at the default
+    name, b, lvl, cam, win, w, h, z = next(_policy_cases())
+    got, _ = oracle.render(b, lvl, cam, win, w, h)
+    assert _moved(got, z[f"{name}.frame.default"]) == 0
+
+
+def test_which_pixels_each_policy_moves():
+    """What DESIGN.md section 2 states about the three unpinned choices, as data:
+      * `||` short circuit: moves pixels wherever glass with ior < 1 is hit (ri = 1/ior > 1, total internal
+        reflection on ENTRY); with ior >= 1 `cannot_refract` needs a hit from inside, which hit_sphere's
+        near-root-only rule (raytrace.wgsl:382) never produces;
+      * compare-select min/max: moves pixels only when a bound (or the ray) is NaN;
+      * pow as exp2(5 log2 x): differs from the multiplies in the last bits of the reflectance, which only matters
+        when `reflectance > rng` flips -- no pixel of these frames."""
+    z = np.load(os.path.join(GOLDEN, "policy_frames.npz"))
+    moved = {(s, p): _moved(z[f"{s}.frame.{p}"], z[f"{s}.frame.default"])
+             for s in ("glass_tir", "axis_parallel", "nan_box") for p in POLICIES}
+    assert moved[("glass_tir", "or_short_circuit")] > 0 and moved[("glass_tir", "all_three")] > 0
+    assert moved[("glass_tir", "minmax_select")] == 0 and moved[("glass_tir", "pow_exp2log2")] == 0
+    assert all(moved[("axis_parallel", p)] == 0 for p in POLICIES)      # 0 * inf = NaN in the slab test: same boxes entered
+    assert moved[("nan_box", "minmax_select")] > 0 and moved[("nan_box", "pow_exp2log2")] == 0
+
+
+def test_short_circuit_policy_cannot_be_seen_on_the_benchmark_scenes(oracle):
+    """Every glass sphere of the cover and RTIOW scenes has ior 1.5: `cannot_refract` is never true there (no hits
+    from inside a sphere, raytrace.wgsl:382), so the `||` policy does not change a single bit of those frames."""
+    for kind in (brt.SCENE_COVER, brt.SCENE_RTIOW_FINAL):
+        b = brt.generate_scene(kind, 1)
+        lvl, cam, win = brt.cover_camera(240, 135, 6, 8)
+        base, c0 = oracle.render(b, lvl, cam, win, 240, 135)
+        with oracle.policy(or_short_circuit=True):
+            alt, c1 = oracle.render(b, lvl, cam, win, 240, 135)
+        assert _moved(base, alt) == 0 and c0 == c1

@@ -773,3 +773,25 @@ def test_two_ranks_over_rccl_match_one_gpu(plugin, oracle, tmp_path):
         want, _ = oracle.render(b, lvl, cam, win, w, h)
         assert_frames_equal(f, want)
         assert_frames_equal(plugin.node.run(lvl, cam, win, w, h, buffers=b), want)
+
+
+def test_short_circuit_policy_switch_matches_the_oracle_under_that_policy(plugin, oracle, monkeypatch):
+    """The alternative reading of `||` (raytrace.wgsl:269) exists in the kernel too (TUNABLE instantiation,
+    BRT_POLICY_OR_SHORT_CIRCUIT=1): on the ior < 1 fixture it must give the oracle's frame under that policy,
+    which differs from the default one."""
+    z = np.load(os.path.join(GOLDEN, "policy_frames.npz"))
+    g = lambda k: z[f"glass_tir.{k}"]
+    b = brt.Buffers(g("models").view(brt.MODEL_DTYPE), g("materials").view(brt.MATERIAL_DTYPE), g("bvh").view(brt.BVH_NODE_DTYPE))
+    lvl, cam, win = g("level").view(brt.LEVEL_DTYPE), g("camera").view(brt.CAMERA_DTYPE), g("window").view(brt.WINDOW_DTYPE)
+    w, h = (int(x) for x in g("size"))
+    got = plugin.node.run(lvl, cam, win, w, h, buffers=b)
+    assert_frames_equal(got, g("frame.default"))
+    monkeypatch.setenv("BRT_POLICY_OR_SHORT_CIRCUIT", "1")
+    got = plugin.node.run(lvl, cam, win, w, h, buffers=b, flags=brt.FLAG_COUNTERS)
+    assert_frames_equal(got, g("frame.or_short_circuit"))
+    assert plugin.node.last_stats["rays"] == int(g("rays.or_short_circuit")[0])
+    with oracle.policy(or_short_circuit=True):
+        want, cnt = oracle.render(b, lvl, cam, win, w, h)
+    assert_frames_equal(got, want)
+    assert {k: plugin.node.last_stats[k] for k in COUNTER_KEYS} == cnt
+    assert not np.array_equal(g("frame.default").view(np.uint32), g("frame.or_short_circuit").view(np.uint32))

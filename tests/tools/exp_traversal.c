@@ -257,6 +257,117 @@ static void sim_tile(const Scene* s, const WTree* t, const Variant* v, uint32_t 
     }
 }
 
+
+/* ---- two pixels per lane: a lane walks the ray of its slot 0, then (in the same loop) the ray of slot 1 ---- */
+typedef struct {
+    int active, in_flight, has_ray;
+    uint32_t rng, sample, bounce;
+    float uvx, uvy, first_depth;
+    vec3 tput;
+    Walk w;
+} Slot;
+
+static void slot_shade(const Scene* s, Slot* a, SimCnt* c, int* live) {
+    Walk* w = &a->w;
+    c->rays++;
+    if (a->bounce == 0) a->first_depth = w->closest;
+    int ended = 0;
+    if (w->closest == INF) ended = 1;
+    else {
+        HitInfo h;
+        const Model* m = &s->models[w->closest_idx];
+        h.distance = w->closest;
+        h.position = ray_at(w->ray, w->closest);
+        h.normal = normalize(vsub(h.position, V(m->px, m->py, m->pz)));
+        h.material = m->material_id;
+        h.front_face = dot(w->ray.direction, h.normal) < 0.0f;
+        vec3 att;
+        int absorbed = scatter(s, &w->ray, &att, &h, &a->rng);
+        if (absorbed) ended = 1;
+        else { a->bounce++; if (a->bounce > s->camera.bounce_count) ended = 1; }
+    }
+    if (ended) {
+        a->bounce = 0; a->sample++;
+        if (a->sample == s->camera.sample_count) { a->active = 0; (*live)--; }
+    }
+}
+
+static void sim_tile_p2(const Scene* s, const WTree* t, const Variant* v, uint32_t tx, uint32_t ty, uint32_t W, uint32_t H,
+                        int stop_live, SimCnt* c) {
+    static __thread Slot S[64][2];
+    int live = 0;
+    for (int l = 0; l < 64; l++) for (int k = 0; k < 2; k++) {
+        uint32_t px = (tx + (uint32_t)k) * 8 + (l & 7), py = ty * 8 + (l >> 3);
+        Slot* a = &S[l][k];
+        memset(a, 0, sizeof *a);
+        if (px >= W || py >= H) continue;
+        a->uvx = ((float)px + 0.5f) / (float)W; a->uvy = ((float)py + 0.5f) / (float)H;
+        a->rng = f32_to_u32((s->window.random_seed * 10000.0f) * (a->uvx * 402.0f) * (a->uvy * 31.5f));
+        a->active = 1; live++;
+    }
+    while (live > 2 * stop_live) {
+        c->rounds++; c->round_lanes += (uint64_t)live;
+        int cur_slot[64];
+        for (int l = 0; l < 64; l++) {
+            for (int k = 0; k < 2; k++) {
+                Slot* a = &S[l][k];
+                if (!a->active) { a->has_ray = 0; continue; }
+                if (!a->in_flight) {
+                    if (a->bounce == 0) { a->w.ray = random_ray_from_uv(s, a->uvx, a->uvy, &a->rng); a->tput = V(1, 1, 1); a->first_depth = INF; }
+                    Walk* w = &a->w;
+                    w->closest = INF; w->closest_idx = -1; w->sp = 0;
+                    w->cur = t->root_is_leaf ? -t->root_leaf - 2 : 0;
+                }
+                a->has_ray = 1;
+            }
+            /* continue the suspended one first */
+            cur_slot[l] = (S[l][1].has_ray && S[l][1].in_flight && !(S[l][0].has_ray && S[l][0].in_flight)) ? 1 : 0;
+            if (!S[l][cur_slot[l]].has_ray) cur_slot[l] ^= 1;
+        }
+        #define CUR(l) (S[l][cur_slot[l]])
+        #define WALKING(l) (CUR(l).has_ray && CUR(l).w.cur != DONE)
+        int n_walking = 0;
+        for (int l = 0; l < 64; l++) if (S[l][0].has_ray || S[l][1].has_ray) n_walking++;
+        int exit_at = n_walking >> 1; if (exit_at > v->exit_lanes) exit_at = v->exit_lanes;
+        for (;;) {
+            for (;;) {
+                /* a lane whose current walk has ended moves on to its other ray (ideal: no cost) */
+                for (int l = 0; l < 64; l++) if (CUR(l).has_ray && CUR(l).w.cur == DONE) {
+                    Slot* o = &S[l][cur_slot[l] ^ 1];
+                    if (o->has_ray && o->w.cur != DONE) cur_slot[l] ^= 1;
+                }
+                int ni = 0;
+                for (int l = 0; l < 64; l++) if (WALKING(l) && is_int(CUR(l).w.cur)) ni++;
+                if (!ni) break;
+                c->int_exec++; c->int_lanes += (uint64_t)ni;
+                for (int l = 0; l < 64; l++) if (WALKING(l) && is_int(CUR(l).w.cur)) step_interior(s, t, &CUR(l).w, v, c);
+                int nl = 0;
+                for (int l = 0; l < 64; l++) if (WALKING(l) && is_leaf(CUR(l).w.cur)) nl++;
+                if (nl >= v->vote) break;
+            }
+            int nl = 0;
+            for (int l = 0; l < 64; l++) if (WALKING(l) && is_leaf(CUR(l).w.cur)) nl++;
+            if (nl) {
+                c->leaf_exec++; c->leaf_lanes += (uint64_t)nl;
+                for (int l = 0; l < 64; l++) if (WALKING(l) && is_leaf(CUR(l).w.cur)) step_leaf(s, &CUR(l).w, v, c);
+            }
+            int nw = 0;
+            for (int l = 0; l < 64; l++) {
+                int busy = 0;
+                for (int k = 0; k < 2; k++) if (S[l][k].has_ray && S[l][k].w.cur != DONE) busy = 1;
+                nw += busy;
+            }
+            if (nw <= exit_at) break;
+        }
+        for (int l = 0; l < 64; l++) for (int k = 0; k < 2; k++) {
+            Slot* a = &S[l][k];
+            if (!a->has_ray) continue;
+            a->in_flight = a->w.cur != DONE;
+            if (!a->in_flight) slot_shade(s, a, c, &live);
+        }
+    }
+}
+
 /* Python entry: runs `n_tiles` tiles (tile coordinates in tiles_xy) through one variant; out10 = SimCnt */
 int exp_run(const void* models, uint32_t n_models, const void* materials, uint32_t n_materials, const void* bvh_nodes,
             uint32_t n_nodes, const void* camera80, const void* window16, uint32_t W, uint32_t H, const uint32_t* tiles_xy,
@@ -270,7 +381,7 @@ int exp_run(const void* models, uint32_t n_models, const void* materials, uint32
     s.level = 3; s.tan_half_fov = oracle_tan_half_fov(s.camera.fov);
     BVHNode* own = NULL;
     const BVHNode* b = s.bvh;
-    if (use_sah) {
+    if (use_sah & 1) {
         Prim* p = (Prim*)malloc(sizeof(Prim) * n_models);
         for (uint32_t i = 0; i < n_models; i++) {
             const Model* m = &s.models[i]; float r = m->radius + 0.1f;
@@ -288,7 +399,10 @@ int exp_run(const void* models, uint32_t n_models, const void* materials, uint32
     if (!t.root_is_leaf) collapse(b, 0, width, &t);
     Variant v = {width, near_first, pop_cull, leaf_in_parent, vote, exit_lanes};
     SimCnt c; memset(&c, 0, sizeof c);
-    for (uint32_t i = 0; i < n_tiles; i++) sim_tile(&s, &t, &v, tiles_xy[2 * i], tiles_xy[2 * i + 1], W, H, stop_live, &c);
+    for (uint32_t i = 0; i < n_tiles; i++) {
+        if (use_sah & 2) sim_tile_p2(&s, &t, &v, tiles_xy[2 * i] & ~1u, tiles_xy[2 * i + 1], W, H, stop_live, &c);
+        else sim_tile(&s, &t, &v, tiles_xy[2 * i], tiles_xy[2 * i + 1], W, H, stop_live, &c);
+    }
     memcpy(out10, &c, sizeof c);
     out10[10] = (uint64_t)t.n_nodes;
     free(t.nodes); free(own);

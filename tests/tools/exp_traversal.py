@@ -47,6 +47,9 @@ def main():
     print(hdr)
     for name, kw in [
         ("w2 reference order (baseline)", dict()),
+        ("w2 reference order, TWO pixels per lane", dict(sah=2)),
+        ("w2 two pixels per lane, exit 6", dict(sah=2, exit_lanes=6)),
+        ("w2 two pixels per lane, vote 16 exit 8", dict(sah=2, vote=16, exit_lanes=8)),
         ("w2 near-first + pop cull", dict(near=1, cull=1)),
         ("w2 near-first + cull + leaf-in-parent", dict(near=1, cull=1, lip=1)),
         ("w2 SAH tree, reference order", dict(sah=1)),
