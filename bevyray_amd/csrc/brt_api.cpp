@@ -423,6 +423,8 @@ int32_t prepass_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const 
     pp.sample_count = k;
     pp.spp_f = (float)k;
     pp.tile_order = nullptr;
+    pp.tunable = 1u;   // the knobs-live instantiation (all knobs at their defaults): the pre-pass then shows up under its own
+                       // kernel name in rocprofv3 --stats instead of pulling down the average of the frame kernel
     pp.queue_lane = 0u;
     pp.crit_begin = pp.crit_end = 0u;
     const uint32_t n_tiles = pp.local_strips * pp.tiles_x;

@@ -525,7 +525,10 @@ BRT_DEV bool scatter(const ScenePtrs& sc, f3& o, f3& d, float t, uint32_t idx, u
             const bool cannot_refract = ri * sin_theta > 1.0f;
             const float refl = schlick(cos_theta, ri);
             bool reflects = cannot_refract;
-            if (!(or_short_circuit && cannot_refract)) reflects = reflects || (refl > rng_float(rng));   // default: always drawn
+            if (!(or_short_circuit && cannot_refract)) {
+                const float draw = rng_float(rng);                            // default policy: always drawn
+                reflects = reflects || (refl > draw);
+            }
             d = reflects ? reflect3(u, nrm) : refract3(u, nrm, ri);
             attenuation = mk3(1.0f, 1.0f, 1.0f);
         }

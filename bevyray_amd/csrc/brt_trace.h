@@ -355,7 +355,10 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             if (lane == 0) b = atomicAdd(queue_counter + 1, 64u);
             b = queue_lane + (uint32_t)__shfl((int)b, 0, 64);
             if (b < fp.queue_size) begin_pixel(b + lane, slot_tile(fp, b >> 6));
-            else tiles_done = true;
+            else {
+                tiles_done = true;
+                if (COUNTERS && t_empty == 0) t_empty = wall_clock64();
+            }
         }
         if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_refill += now - t_mark; t_mark = now; }
         // ---- drain: hand the paths over / take paths over / leave (see "drain pool" above) ----

@@ -50,8 +50,9 @@ def random_material(rng, wild):
 def random_case(rng):
     wild = rng.random() < 0.5            # half of the cases stay "sane" but structurally varied
     n = int(rng.choice([1, 2, 3, int(rng.integers(4, 40)), int(rng.integers(40, 400)), int(rng.integers(400, 3000)),
-                        int(rng.integers(8200, 12000))],      # > 16382 nodes: 32-bit descriptors
-                       p=[0.05, 0.05, 0.05, 0.45, 0.29, 0.1, 0.01]))
+                        int(rng.integers(8200, 12000)),       # does not fit LDS: top-of-tree tile, 16-bit descriptors
+                        int(rng.integers(16400, 18000))],     # > 16382 spheres: 32-bit descriptors, all from L2
+                       p=[0.05, 0.05, 0.05, 0.45, 0.285, 0.1, 0.01, 0.005]))
     spread = float(rng.choice([0.5, 4.0, 30.0]))
     data = []
     for i in range(n):
@@ -190,6 +191,12 @@ def main():
             break
         c = random_case(rng)
         b = c["buffers"]
+        # kernel variant of this case: default plan, top-of-tree tile of a few records, everything from L2, knobs live
+        variant = [{}, {}, {"BRT_FORCE_LDS_TOP": str(int(rng.integers(1, 200)))}, {"BRT_FORCE_GLOBAL_SCENE": "1"},
+                   {"BRT_TUNABLE": "1"}, {"BRT_FORCE_LDS_TOP": "100000", "BRT_TUNABLE": "1"}][int(rng.integers(0, 6))]
+        for k in ("BRT_FORCE_LDS_TOP", "BRT_FORCE_GLOBAL_SCENE", "BRT_TUNABLE"):
+            os.environ.pop(k, None)
+        os.environ.update(variant)
         try:
             if b.bvh is None:             # callee-built: GPU PLOC must equal the CPU builder byte for byte
                 cpu_nodes = brt.build_bvh(b.models)
@@ -219,7 +226,7 @@ def main():
             rays += cnt["rays"]
         except AssertionError as e:
             fails += 1
-            msg = (f"case {case} FAILED: {e} | {len(b.models)} spheres, topo {c['topo']}, wild {c['wild']}, mode {c['mode']}/{c['n_parts']}, {c['w']}x{c['h']}, "
+            msg = (f"case {case} FAILED: {e} | variant {variant} | {len(b.models)} spheres, topo {c['topo']}, wild {c['wild']}, mode {c['mode']}/{c['n_parts']}, {c['w']}x{c['h']}, "
                    f"level {int(c['level'][0]['level']) if hasattr(c['level'], 'dtype') else c['level']}")
             print(msg, flush=True)
             lines.append(msg)
