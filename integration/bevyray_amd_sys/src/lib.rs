@@ -1,0 +1,77 @@
+//! UNVERIFIED SOURCE: written against `include/bevyray_amd.h` (BRT_ABI_VERSION 2), never compiled (no Rust
+//! toolchain in the build environment).  What IS compiled and tested against the same ABI: the ctypes binding
+//! `bevyray_amd/_lib.py` (every GPU test goes through it) and the C++ host `bevyray_amd/host/raytracing.hpp`.
+//!
+//! One declaration per export the Rust node needs; the doc comment of each names the reference code it replaces.
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_void};
+
+pub const BRT_ABI_VERSION: u32 = 2;
+pub const BRT_STRIP_ROWS: u32 = 8;
+
+pub const BRT_OK: i32 = 0;
+pub const BRT_ERR_INVALID_ARGUMENT: i32 = -1;
+pub const BRT_ERR_NO_DEVICE: i32 = -2;
+pub const BRT_ERR_HIP: i32 = -3;
+pub const BRT_ERR_INVALID_BVH: i32 = -4;
+pub const BRT_ERR_INVALID_SCENE: i32 = -5;
+pub const BRT_ERR_EMPTY_SCENE: i32 = -6;
+pub const BRT_ERR_NO_SCENE: i32 = -7;
+pub const BRT_ERR_UNSUPPORTED: i32 = -8;
+pub const BRT_ERR_CAPACITY: i32 = -9;
+
+/// brt_render* flags
+pub const BRT_FLAG_COUNTERS: u32 = 1;
+pub const BRT_FLAG_KERNEL_SIMPLE: u32 = 2;
+pub const BRT_FLAG_CALLER_STREAM: u32 = 4;
+
+#[repr(C)]
+pub struct brt_ctx { _private: [u8; 0] }
+
+#[repr(C)]
+#[derive(Default, Debug, Clone, Copy)]
+pub struct brt_stats {
+    pub rays: u64, pub node_pops: u64, pub interior_visits: u64, pub sphere_tests: u64, pub hits: u64,
+    pub paths: u64,
+    pub kernel_ms: f64, pub gather_ms: f64, pub total_ms: f64,
+    pub lds_bytes: u32, pub scene_in_lds: u32, pub n_workgroups: u32, pub threads_per_workgroup: u32,
+    pub prepass_ms: f64,
+}
+
+extern "C" {
+    pub fn brt_abi_version() -> u32;
+    pub fn brt_last_error(ctx: *const brt_ctx) -> *const c_char;
+    /// replaces RaytracingPipeline::from_world (pipeline.rs:233-331)
+    pub fn brt_create(device_ids: *const i32, n_devices: i32, out_ctx: *mut *mut brt_ctx) -> i32;
+    pub fn brt_destroy(ctx: *mut brt_ctx) -> i32;
+    /// replaces model_buffer / material_buffer / bvh_buffer .write_buffer (pipeline.rs:136-138)
+    pub fn brt_upload_scene(ctx: *mut brt_ctx, models: *const c_void, n_models: u32, materials: *const c_void,
+                            n_materials: u32, bvh_nodes: *const c_void, n_nodes: u32) -> i32;
+    /// replaces set_bind_group x2 + draw(0..3, 0..1) (pipeline.rs:160-217) and the fragment() grid (raytrace.wgsl:93-123)
+    pub fn brt_render(ctx: *mut brt_ctx, camera80: *const c_void, window16: *const c_void, level: u32, width: u32,
+                      height: u32, raster_rgba: *const f32, raster_depth: *const f32, out_rgba: *mut f32, flags: u32,
+                      stats_or_null: *mut brt_stats) -> i32;
+    pub fn brt_host_alloc(ctx: *mut brt_ctx, bytes: u64, out_ptr: *mut *mut c_void) -> i32;
+    pub fn brt_host_free(ctx: *mut brt_ctx, ptr: *mut c_void) -> i32;
+    /// one rank's strips into a device tile (row tiling over N GPUs)
+    pub fn brt_render_part_device(ctx: *mut brt_ctx, camera80: *const c_void, window16: *const c_void, level: u32,
+                                  width: u32, height: u32, part: u32, n_parts: u32, d_raster_rgba: *const f32,
+                                  d_raster_depth: *const f32, d_out_tile: *mut f32, hip_stream: *mut c_void, flags: u32,
+                                  stats_or_null: *mut brt_stats) -> i32;
+    pub fn brt_tile_rows(height: u32, n_parts: u32) -> u32;
+    pub fn brt_deinterleave_device(ctx: *mut brt_ctx, d_tiles: *const f32, n_parts: u32, width: u32, height: u32,
+                                   d_frame: *mut f32, hip_stream: *mut c_void, flags: u32) -> i32;
+    /// replaces obvhs::ploc::build_ploc::<24> + flatten (extract.rs:315-332)
+    pub fn brt_build_bvh(models: *const c_void, n_models: u32, out_nodes: *mut c_void, capacity: u32,
+                         out_n_nodes: *mut u32) -> i32;
+    pub fn brt_build_bvh_device(ctx: *mut brt_ctx, models: *const c_void, n_models: u32, out_nodes: *mut c_void,
+                                capacity: u32, out_n_nodes: *mut u32, out_build_ms: *mut f64) -> i32;
+    pub fn brt_validate_scene(models: *const c_void, n_models: u32, materials: *const c_void, n_materials: u32,
+                              bvh_nodes: *const c_void, n_nodes: u32, out_max_depth: *mut u32) -> i32;
+}
+
+/// Text of the last error as an owned String (ctx may be null).
+pub unsafe fn last_error(ctx: *const brt_ctx) -> String {
+    let p = brt_last_error(ctx);
+    if p.is_null() { String::new() } else { std::ffi::CStr::from_ptr(p).to_string_lossy().into_owned() }
+}
