@@ -484,13 +484,13 @@ void free_device(DeviceCtx& dc) {
     dc = DeviceCtx();
 }
 
-constexpr uint32_t kMaxGpuBuildModels = 1u << 20;
+constexpr uint32_t kMaxGpuBuildModels = 1u << 24;   // scratch ~ 250 B per sphere; the grid version of the builder has no structural limit
 
 // PLOC on the context's first device: models (host) -> nodes (host vector), build time in ms.
 int32_t build_bvh_on_device(brt_ctx* ctx, const Model* models, uint32_t n, std::vector<BVHNode>* out, double* build_ms) {
     out->clear();
     if (n == 0) return BRT_OK;
-    if (n > kMaxGpuBuildModels) return ctx_fail(ctx, BRT_ERR_UNSUPPORTED, "GPU BVH build supports up to 2^20 spheres");
+    if (n > kMaxGpuBuildModels) return ctx_fail(ctx, BRT_ERR_UNSUPPORTED, "GPU BVH build supports up to 2^24 spheres");
     DeviceCtx& dc = ctx->devs[0];
     HIP_TRY(ctx, hipSetDevice(dc.device));
     int32_t rc = ensure(ctx, &dc.d_bvh_scratch, &dc.bvh_scratch_cap, ploc_scratch_bytes(n, nullptr));

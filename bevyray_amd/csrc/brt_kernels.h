@@ -41,6 +41,8 @@ hipError_t launch_debug_eval(uint32_t op, const float* in, float* out, uint32_t 
 // GPU PLOC builder (brt_bvh.hip): scratch size for n models, and the launch; *d_out / *d_info
 // point into the scratch (nodes in the reference's 48-byte format; info[0] = node count,
 // info[1] = PLOC rounds)
+constexpr uint32_t kPlocOneBlockMax = 6000;    // up to here the one-workgroup build (no kernel boundaries) is faster; above: the grid version
+uint32_t ploc_one_block_max();                 // kPlocOneBlockMax, or BRT_PLOC_ONE_BLOCK_MAX (tests)
 size_t ploc_scratch_bytes(uint32_t n, uint32_t* n_pow2_out);
 hipError_t launch_build_ploc(const Model* d_models, uint32_t n, char* d_scratch, BVHNode** d_out, uint32_t** d_info,
                              hipStream_t stream);

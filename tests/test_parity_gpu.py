@@ -437,7 +437,31 @@ def test_config5_10k_spheres_full_size(plugin, oracle):
 
 # ---- GPU BVH build --------------------------------------------------------------------
 
-def test_gpu_ploc_build_is_byte_identical_to_cpu_build(plugin, oracle):
+def test_gpu_ploc_grid_build_of_a_large_scene(plugin):
+    """200 000 spheres (above the one-workgroup limit: radix sort + grid-wide PLOC rounds): byte-identical to the
+    CPU builder, and a valid tree for brt_upload_scene."""
+    rng = np.random.default_rng(5)
+    n = 200_000
+    m = np.zeros(n, brt.MODEL_DTYPE)
+    m["position"] = rng.uniform(-300, 300, (n, 3)).astype(np.float32)
+    m["position"][:, 1] = np.abs(m["position"][:, 1]) * 0.02
+    m["radius"] = rng.uniform(0.05, 0.6, n).astype(np.float32)
+    m["position"][::1000] = m["position"][1::1000]            # duplicates: equal Morton codes and areas
+    m["radius"][::1000] = m["radius"][1::1000]
+    gpu, ms = plugin.build_bvh(m)
+    cpu = brt.build_bvh(m)
+    assert len(gpu) == 2 * n - 1 and np.array_equal(cpu.view(np.uint8), gpu.view(np.uint8))
+    mats = np.zeros(1, brt.MATERIAL_DTYPE)
+    mats["base_color"] = 0.5
+    assert brt.validate_scene(m, mats, gpu) < 64
+
+
+
+@pytest.mark.parametrize("grid", [False, True])
+def test_gpu_ploc_build_is_byte_identical_to_cpu_build(plugin, oracle, grid, monkeypatch):
+    # grid: the multi-kernel version of the builder (used above 32 768 spheres) forced on every size
+    if grid:
+        monkeypatch.setenv("BRT_PLOC_ONE_BLOCK_MAX", "0")
     rng = np.random.default_rng(11)
     scenes = [brt.generate_scene(brt.SCENE_COVER, s).models for s in (1, 2, 3)]
     scenes += [brt.generate_scene(brt.SCENE_RTIOW_FINAL, 1).models, brt.generate_scene(brt.SCENE_STRESS_GRID, 1).models]
@@ -795,3 +819,33 @@ def test_short_circuit_policy_switch_matches_the_oracle_under_that_policy(plugin
     assert_frames_equal(got, want)
     assert {k: plugin.node.last_stats[k] for k in COUNTER_KEYS} == cnt
     assert not np.array_equal(g("frame.default").view(np.uint32), g("frame.or_short_circuit").view(np.uint32))
+
+
+def test_first_frame_prepass_orders_tiles_without_changing_pixels(oracle, monkeypatch):
+    """The first frame of a view runs a 2-spp dispatch-order pre-pass into the frame's own tile buffer and then
+    the frame itself: same pixels and counters as the oracle, prepass_ms reported; BRT_PREPASS_SPP=0 turns it
+    off; the second frame of the view needs none."""
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    w, h = 320, 180
+    lvl, cam, win = brt.cover_camera(w, h, 32, 8)
+    want, cnt = oracle.render(b, lvl, cam, win, w, h)
+    with brt.RaytracePlugin([0]) as p:
+        f1 = p.node.run(lvl, cam, win, w, h, buffers=b, flags=brt.FLAG_COUNTERS)
+        s1 = dict(p.node.last_stats)
+        f2 = p.node.run(lvl, cam, win, w, h, flags=brt.FLAG_COUNTERS)
+        s2 = dict(p.node.last_stats)
+    assert_frames_equal(f1, want)
+    assert_frames_equal(f2, want)
+    assert {k: s1[k] for k in COUNTER_KEYS} == cnt and {k: s2[k] for k in COUNTER_KEYS} == cnt
+    assert s1["prepass_ms"] > 0.0 and s2["prepass_ms"] == 0.0
+    monkeypatch.setenv("BRT_PREPASS_SPP", "0")
+    with brt.RaytracePlugin([0]) as p:
+        f3 = p.node.run(lvl, cam, win, w, h, buffers=b)
+        assert p.node.last_stats["prepass_ms"] == 0.0
+    assert_frames_equal(f3, want)
+    # frames of fewer than 16x the pre-pass samples run without one
+    monkeypatch.delenv("BRT_PREPASS_SPP")
+    lvl, cam, win = brt.cover_camera(w, h, 8, 8)
+    with brt.RaytracePlugin([0]) as p:
+        p.node.run(lvl, cam, win, w, h, buffers=b)
+        assert p.node.last_stats["prepass_ms"] == 0.0
