@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Renders a few frames of the headline workload (cover scene 1920x1080, 64 spp, 8 bounces) through the C ABI
-without importing torch: the program bench.py and scripts/pmc.sh put behind `rocprofv3 --pmc ... --`.
+without importing torch: the program bench.py, scripts/pmc_sets.py and scripts/collect_profiles.sh put behind `rocprofv3 --pmc ... --`.
 The first frame runs in raster order and measures the tile costs, the later ones use the order built from
 them (brt_api.cpp); counter readers take the LAST dispatch of k_trace_persistent."""
 import os
