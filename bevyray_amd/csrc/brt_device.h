@@ -33,12 +33,69 @@ BRT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); 
 BRT_DEV f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
 BRT_DEV f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 BRT_DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-BRT_DEV f3 normalize3(f3 v) {
-    const float len = __builtin_sqrtf(dot3(v, v));
-    return mk3(v.x / len, v.y / len, v.z / len);
-}
 BRT_DEV float min_f(float a, float b) { return __builtin_fminf(a, b); }
 BRT_DEV float max_f(float a, float b) { return __builtin_fmaxf(a, b); }
+
+// ---- correctly rounded division with a shared reciprocal ----------------------------------------------------
+// hipcc expands the correctly rounded f32 quotient n / d (-fhip-fp32-correctly-rounded-divide-sqrt) to
+//     ds = v_div_scale(d), ns = v_div_scale(n)            operands scaled by 2^+-64 when a result would leave the normal range
+//     r0 = v_rcp_f32(ds);  r1 = fma(fma(-ds, r0, 1), r0, r0)
+//     q0 = ns * r1;  q1 = fma(fma(-ds, q0, ns), r1, q0);  q2 = v_div_fmas(fma(-ds, q1, ns), r1, q1)   (an fma, rescaled)
+//     v_div_fixup(q2, d, n)                               zeros, infinities, NaNs, overflow / underflow
+// (11 instructions, one of them quarter rate).  With |d| and |n| both in [2^-40, 2^40] ("plain"): nothing is scaled,
+// v_div_fmas is the fma, v_div_fixup returns q2 -- so div_plain(n, rcp_refined(d)) below IS that expansion,
+// instruction for instruction, without its three no-ops; and r1 depends on d alone, so the three quotients of a
+// normalize() or the sphere tests of one ray share it.  Outside the plain range the callers use `/`.  Whether a
+// WAVE takes the short form is decided by ballot (all its active lanes plain), so there is one straight-line body
+// either way.  tests: BRT_DBG_DIV / BRT_DBG_DIV_SWEEP compare both forms bit for bit (2^-40 .. 2^40 x all mantissas).
+#ifndef BRT_SHARED_RCP
+#define BRT_SHARED_RCP 3   // bit 0: normalize(), bit 1: 1 / direction.  (A/B on one MI355X, headline frame: 13.33 ms without,
+                           // 13.18 with bit 0, 13.08 with both; the sphere test's `/ a` with a per-ray reciprocal did NOT pay --
+                           // its range guard and wave vote cost the leaf step what the shorter quotient saves: 13.16 ms)
+#endif
+constexpr float kPlainLo = 0x1p-40f, kPlainHi = 0x1p40f;
+struct RcpRef { float d, r1; };
+BRT_DEV RcpRef rcp_refined(float d) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r0, 1.0f);
+    RcpRef R;
+    R.d = d;
+    R.r1 = __builtin_fmaf(e, r0, r0);
+    return R;
+}
+BRT_DEV float div_plain(float n, RcpRef R) {
+    float q = n * R.r1;
+    float e = __builtin_fmaf(-R.d, q, n);
+    q = __builtin_fmaf(e, R.r1, q);
+    e = __builtin_fmaf(-R.d, q, n);
+    return __builtin_fmaf(e, R.r1, q);
+}
+// 1.0f / d in the plain range: q0 = 1 * r1 is exact
+BRT_DEV float recip_plain(float d) {
+    const RcpRef R = rcp_refined(d);
+    float e = __builtin_fmaf(-d, R.r1, 1.0f);
+    const float q = __builtin_fmaf(e, R.r1, R.r1);
+    e = __builtin_fmaf(-d, q, 1.0f);
+    return __builtin_fmaf(e, R.r1, q);
+}
+// all three components of v have a magnitude in [lo, hi] (a NaN or zero component fails)
+BRT_DEV bool all_within(f3 v, float lo, float hi) {
+    const float ax = __builtin_fabsf(v.x), ay = __builtin_fabsf(v.y), az = __builtin_fabsf(v.z);
+    return min_f(min_f(ax, ay), az) >= lo && max_f(max_f(ax, ay), az) <= hi;
+}
+BRT_DEV bool wave_all(bool p) { return __ballot(!p) == 0ull; }   // over the lanes that are active at the call
+
+BRT_DEV f3 normalize3(f3 v) {
+    const float len = __builtin_sqrtf(dot3(v, v));
+#if BRT_SHARED_RCP & 1
+    // components in [2^-40, 2^39]  =>  len in [max |v_i|, 2 max |v_i|) is plain too (sqrt is monotone, the sum has 3 terms)
+    if (wave_all(all_within(v, kPlainLo, 0x1p39f))) {
+        const RcpRef R = rcp_refined(len);
+        return mk3(div_plain(v.x, R), div_plain(v.y, R), div_plain(v.z, R));
+    }
+#endif
+    return mk3(v.x / len, v.y / len, v.z / len);
+}
 
 BRT_DEV uint32_t f32_to_u32_sat(float f) {
     if (!(f > 0.0f)) return 0u;
@@ -192,7 +249,11 @@ struct WalkState {
 template <bool D16, typename StackT>
 BRT_DEV void walk_begin(WalkState<StackT>& w, const ScenePtrs& sc, uint32_t root_desc, StackT* stk, f3 d) {
     w.a = dot3(d, d);
-    w.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+#if BRT_SHARED_RCP & 2
+    if (wave_all(all_within(d, kPlainLo, kPlainHi))) w.inv = mk3(recip_plain(d.x), recip_plain(d.y), recip_plain(d.z));
+    else
+#endif
+        w.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     w.ox = PAIR_X + (w.inv.x < 0.0f ? 16u : 0u);
     w.oy = PAIR_Y + (w.inv.y < 0.0f ? 16u : 0u);
     w.oz = PAIR_Z + (w.inv.z < 0.0f ? 16u : 0u);

@@ -158,6 +158,36 @@ __global__ void k_debug_eval(uint32_t op, const float* __restrict__ in, float* _
             r[0] = __uint_as_float(pixel_seed(fp, uvx, uvy));
             break;
         }
+        case BRT_DBG_DIV: {   // n, d -> n / d, div_plain(n, rcp_refined(d)), 1 / d, recip_plain(d)  (the short forms UNGUARDED)
+            r[0] = a[0] / a[1];
+            r[1] = div_plain(a[0], rcp_refined(a[1]));
+            r[2] = 1.0f / a[1];
+            r[3] = recip_plain(a[1]);
+            break;
+        }
+        case BRT_DBG_DIV_SWEEP: {   // seed (bits), count (float) -> mismatches of both short forms against `/` over `count`
+            // pseudo-random pairs of the plain range: every exponent -40 .. 40, random mantissas and signs
+            uint32_t st = __float_as_uint(a[0]) ^ (i * 0x9E3779B9u);
+            const uint32_t count = (uint32_t)a[1];
+            uint32_t bad = 0, bad_n = 0, bad_d = 0;
+            for (uint32_t k = 0; k < count; k++) {
+                st = rng_next(st + k);
+                const uint32_t en = 127u - 40u + (st % 81u);
+                const uint32_t mn = rng_next(st ^ 0x12345u);
+                st = rng_next(st);
+                const uint32_t ed = 127u - 40u + (st % 81u);
+                const uint32_t md = rng_next(st ^ 0xabcdeu);
+                float n = __uint_as_float((mn & 0x807fffffu) | (en << 23));
+                float d = __uint_as_float((md & 0x807fffffu) | (ed << 23));
+                if (en == 167u) n = __uint_as_float((mn & 0x80000000u) | (en << 23));   // 2^40 itself is the last plain value
+                if (ed == 167u) d = __uint_as_float((md & 0x80000000u) | (ed << 23));
+                const bool ok = __float_as_uint(div_plain(n, rcp_refined(d))) == __float_as_uint(n / d) &&
+                                __float_as_uint(recip_plain(d)) == __float_as_uint(1.0f / d);
+                if (!ok) { if (!bad) { bad_n = __float_as_uint(n); bad_d = __float_as_uint(d); } bad++; }
+            }
+            r[0] = (float)bad; r[1] = __uint_as_float(bad_n); r[2] = __uint_as_float(bad_d);
+            break;
+        }
         default: break;
     }
 }

@@ -849,3 +849,37 @@ def test_first_frame_prepass_orders_tiles_without_changing_pixels(oracle, monkey
     with brt.RaytracePlugin([0]) as p:
         p.node.run(lvl, cam, win, w, h, buffers=b)
         assert p.node.last_stats["prepass_ms"] == 0.0
+
+
+# ---- the shared-reciprocal division (brt_device.h) against the compiler's correctly rounded `/` ---------------------
+
+DBG_DIV, DBG_DIV_SWEEP = 6, 7
+
+
+def test_shared_reciprocal_division_is_the_compilers_division_in_the_plain_range(plugin):
+    """div_plain / recip_plain are hipcc's own expansion of `/` without the operand scaling and the special-case
+    fixup, valid for operands in [2^-40, 2^40]: bit-identical there -- 2.1e9 pseudo-random pairs over every
+    exponent combination on the device, and every boundary value from the host -- and the callers' range guards
+    keep everything else (zeros, denormals, huge, NaN) on `/`."""
+    seeds = np.arange(1, 32769, dtype=np.uint32)
+    inp = np.zeros((len(seeds), 16), np.float32)
+    inp[:, 0] = seeds.view(np.float32)
+    inp[:, 1] = 65536.0
+    out = plugin.debug_eval(DBG_DIV_SWEEP, inp)
+    bad = out[:, 0].sum()
+    first = out[out[:, 0] > 0][:1]
+    assert bad == 0, f"{bad} mismatches, first n/d bits {first[:, 1:3].view(np.uint32)}"
+    # boundaries of the plain range and a dense mantissa sweep at fixed exponents, checked on the host
+    rng = np.random.default_rng(3)
+    edge = np.array([2.0 ** -40, np.nextafter(np.float32(2.0 ** -40), np.float32(1)), 1.0, np.nextafter(np.float32(1), np.float32(2)),
+                     np.nextafter(np.float32(1), np.float32(0)), 3.0, 2.0 ** 40, np.nextafter(np.float32(2.0 ** 40), np.float32(0)),
+                     1.9999999, 0.33333334, 7.0, 1e-9, 1e9], np.float32)
+    edge = np.concatenate([edge, -edge])
+    n, d = np.meshgrid(edge, edge)
+    n = np.concatenate([n.ravel(), (rng.random(400000, dtype=np.float32) + 1) * np.float32(2.0) ** rng.integers(-40, 40, 400000).astype(np.float32)])
+    d = np.concatenate([d.ravel(), (rng.random(400000, dtype=np.float32) + 1) * np.float32(2.0) ** rng.integers(-40, 40, 400000).astype(np.float32)])
+    out = plugin.debug_eval(DBG_DIV, _inputs([n, d]))
+    assert_frames_equal(out[:, 0], n / d)                 # the compiler's `/` is IEEE division (numpy on x86 is too)
+    assert_frames_equal(out[:, 1], n / d)
+    assert_frames_equal(out[:, 2], np.float32(1.0) / d)
+    assert_frames_equal(out[:, 3], np.float32(1.0) / d)
