@@ -85,15 +85,29 @@ BRT_DEV bool all_within(f3 v, float lo, float hi) {
 }
 BRT_DEV bool wave_all(bool p) { return __ballot(!p) == 0ull; }   // over the lanes that are active at the call
 
+// The correctly rounded sqrt likewise: hipcc emits v_sqrt_f32 (1 ulp) and picks the best of {s - 1 ulp, s, s + 1 ulp} by
+// the sign of two exact residuals, wrapped in a 2^32 pre-scale for tiny arguments and a class test for 0 / inf / NaN
+// (16 instructions).  For x in [2^-80, 2^80] the wrapping does nothing: these 9 instructions are the rest, verbatim.
+// (BRT_DBG_SQRT_SWEEP: every float of that range, bit for bit against __builtin_sqrtf.)
+BRT_DEV float sqrt_plain(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+    float r = (0.0f >= r_dn) ? s_dn : s;
+    r = (0.0f < r_up) ? s_up : r;
+    return r;
+}
+
 BRT_DEV f3 normalize3(f3 v) {
-    const float len = __builtin_sqrtf(dot3(v, v));
 #if BRT_SHARED_RCP & 1
-    // components in [2^-40, 2^39]  =>  len in [max |v_i|, 2 max |v_i|) is plain too (sqrt is monotone, the sum has 3 terms)
+    // components in [2^-40, 2^39]  =>  dot in [2^-80, 2^80) and len in [max |v_i|, 2 max |v_i|): both plain
+    // (products and sums of positive terms are monotone, sqrt is monotone, the sum has 3 terms)
     if (wave_all(all_within(v, kPlainLo, 0x1p39f))) {
-        const RcpRef R = rcp_refined(len);
+        const RcpRef R = rcp_refined(sqrt_plain(dot3(v, v)));
         return mk3(div_plain(v.x, R), div_plain(v.y, R), div_plain(v.z, R));
     }
 #endif
+    const float len = __builtin_sqrtf(dot3(v, v));
     return mk3(v.x / len, v.y / len, v.z / len);
 }
 

@@ -188,6 +188,18 @@ __global__ void k_debug_eval(uint32_t op, const float* __restrict__ in, float* _
             r[0] = (float)bad; r[1] = __uint_as_float(bad_n); r[2] = __uint_as_float(bad_d);
             break;
         }
+        case BRT_DBG_SQRT_SWEEP: {   // first bits, count -> mismatches of sqrt_plain against __builtin_sqrtf over `count` consecutive floats
+            const uint32_t first = __float_as_uint(a[0]) + i * (uint32_t)a[1];
+            const uint32_t count = (uint32_t)a[1];
+            uint32_t bad = 0, bad_x = 0;
+            for (uint32_t k = 0; k < count; k++) {
+                const float x = __uint_as_float(first + k);
+                if (!(x >= 0x1p-80f && x <= 0x1p80f)) continue;
+                if (__float_as_uint(sqrt_plain(x)) != __float_as_uint(__builtin_sqrtf(x))) { if (!bad) bad_x = first + k; bad++; }
+            }
+            r[0] = (float)bad; r[1] = __uint_as_float(bad_x);
+            break;
+        }
         default: break;
     }
 }

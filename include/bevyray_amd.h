@@ -180,8 +180,10 @@ enum {
     BRT_DBG_SPHERE = 4,    /* in: o3 d3 center3 radius        out: accepted t or INF */
     BRT_DBG_SEED = 5,      /* in: seed px py W H (floats)     out: rng seed (bits) */
     BRT_DBG_DIV = 6,       /* in: n, d            out: n / d, shared-reciprocal short form, 1 / d, its short form (brt_device.h) */
-    BRT_DBG_DIV_SWEEP = 7  /* in: seed (bits), count          out: mismatches of the short forms over `count` random plain-range pairs,
+    BRT_DBG_DIV_SWEEP = 7, /* in: seed (bits), count          out: mismatches of the short forms over `count` random plain-range pairs,
                               bits of the first mismatching n and d */
+    BRT_DBG_SQRT_SWEEP = 8 /* in: first (bits), count         out: mismatches of the short sqrt over `count` consecutive floats per element
+                              (element i starts at first + i * count), bits of the first mismatching argument */
 };
 int32_t brt_debug_eval(brt_ctx* ctx, uint32_t op, const float* in16, float* out8, uint32_t n);
 

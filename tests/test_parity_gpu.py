@@ -853,7 +853,21 @@ def test_first_frame_prepass_orders_tiles_without_changing_pixels(oracle, monkey
 
 # ---- the shared-reciprocal division (brt_device.h) against the compiler's correctly rounded `/` ---------------------
 
-DBG_DIV, DBG_DIV_SWEEP = 6, 7
+DBG_DIV, DBG_DIV_SWEEP, DBG_SQRT_SWEEP = 6, 7, 8
+
+
+def test_short_sqrt_is_the_compilers_sqrt_on_every_float_of_its_range(plugin):
+    """sqrt_plain (hipcc's correctly rounded sqrt without its tiny-argument scaling and class test) against
+    __builtin_sqrtf on EVERY float in [2^-80, 2^80]: 1.34e9 values, bit for bit."""
+    lo = int(np.float32(2.0 ** -80).view(np.uint32))
+    hi = int(np.float32(2.0 ** 80).view(np.uint32))
+    per = 65536
+    n = (hi - lo) // per + 2
+    inp = np.zeros((n, 16), np.float32)
+    inp[:, 0] = np.full(n, lo - 3, np.uint32).view(np.float32)     # element i covers [lo - 3 + i * per, +per)
+    inp[:, 1] = float(per)
+    out = plugin.debug_eval(DBG_SQRT_SWEEP, inp)
+    assert out[:, 0].sum() == 0, f"first mismatching argument bits {out[out[:, 0] > 0][:1, 1].view(np.uint32)}"
 
 
 def test_shared_reciprocal_division_is_the_compilers_division_in_the_plain_range(plugin):
