@@ -25,6 +25,7 @@ struct DeviceCtx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_last = nullptr;   // end of the last launch that used the control block (any stream)
+    hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;   // around the dispatch-order pre-pass of a first frame
     int num_cus = 0;
     size_t max_lds = 0;
     // scene
@@ -50,6 +51,10 @@ struct DeviceCtx {
     uint32_t order_lane = 0;                             // tiles of the lane queue; the rest of d_tile_order is the tile queue
     uint32_t order_crit = 0;                             // d_tile_order[0 .. crit) are the CRITICAL tiles
     size_t tile_order_cap = 0;
+    uint32_t* d_order_meta = nullptr;                    // order built on the GPU: [0] critical tiles, [1] longest pixel
+    char* d_order_scratch = nullptr;
+    size_t order_scratch_cap = 0;
+    bool order_on_device = false;                        // d_tile_order / d_order_meta were written by brt_order.hip
     bool order_valid = false;
     uint32_t order_age = 0;                       // frames since the costs were last measured
     uint32_t order_key[6] = {0, 0, 0, 0, 0, 0};   // width, height, part, n_parts, scene epoch, n_tiles
@@ -311,6 +316,7 @@ int32_t attach_tile_order(brt_ctx* ctx, DeviceCtx& dc, FrameParams& fp, hipStrea
         fp.queue_lane = dc.order_lane * 64u;
         fp.crit_begin = 0u;
         fp.crit_end = dc.order_crit * 64u;
+        fp.order_meta = dc.order_on_device ? dc.d_order_meta : nullptr;   // then the kernel reads the critical count there
     }
     if (may_measure && (!match || ++dc.order_age >= kLptRefresh)) {
         int32_t rc = ensure(ctx, &dc.d_tile_cost, &dc.tile_cost_cap, (size_t)n_tiles * 8);   // sums, then maxima
@@ -321,13 +327,12 @@ int32_t attach_tile_order(brt_ctx* ctx, DeviceCtx& dc, FrameParams& fp, hipStrea
     return BRT_OK;
 }
 
-// after a measuring frame has completed on `stream`: build the order of the next frames
+// after a measuring frame has been enqueued on `stream`: build the order of the next frames.  Default settings: on the
+// GPU, on the same stream, no host round trip (brt_order.hip).  BRT_ORDER_ON_HOST=1, or any non-default ordering knob
+// (BRT_LPT_SORT, BRT_LPT_SKY_SLACK, BRT_LPT_LANE_PERMILLE, BRT_CRIT): counts to the host, build_tile_order, order back up.
 int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hipStream_t stream) {
     if (!fp.tile_cost) return BRT_OK;
     const uint32_t n_tiles = fp.local_strips * fp.tiles_x;
-    dc.h_cost.resize(2 * (size_t)n_tiles);
-    HIP_TRY(ctx, hipMemcpyAsync(dc.h_cost.data(), dc.d_tile_cost, (size_t)n_tiles * 8, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(ctx, hipStreamSynchronize(stream));
     TileOrderParams tp{};
     tp.sample_count = fp.sample_count;
     tp.grid_lanes = (uint64_t)dc.num_cus * BRT_BLOCK;
@@ -335,15 +340,33 @@ int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hi
     tp.sky_slack_permille = env_u32("BRT_LPT_SKY_SLACK", 20);
     tp.lane_permille = env_u32("BRT_LPT_LANE_PERMILLE", 0);
     tp.critical = env_u32("BRT_CRIT", 1);
-    TileOrder to;
-    build_tile_order(dc.h_cost.data(), dc.h_cost.data() + n_tiles, n_tiles, tp, &to);   // sums, then longest pixels (brt_host.cpp)
-    dc.h_order.swap(to.order);
-    dc.order_lane = to.n_lane;
-    dc.order_crit = to.n_critical;
     int32_t rc = ensure(ctx, &dc.d_tile_order, &dc.tile_order_cap, (size_t)n_tiles * 4);
     if (rc != BRT_OK) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(dc.d_tile_order, dc.h_order.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, stream));
-    HIP_TRY(ctx, hipStreamSynchronize(stream));   // h_order may be reused by the next call
+    const bool on_device = tp.sorted == 1u && tp.critical == 1u && tp.lane_permille == 0u && env_u32("BRT_ORDER_ON_HOST", 0) == 0u;
+    if (on_device) {
+        if (!dc.d_order_meta) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dc.d_order_meta), 256));
+        rc = ensure(ctx, &dc.d_order_scratch, &dc.order_scratch_cap, order_scratch_bytes(n_tiles));
+        if (rc != BRT_OK) return rc;
+        const uint64_t sky_cost = (uint64_t)64 * tp.sample_count * (1000 + tp.sky_slack_permille) / 1000;   // as build_tile_order
+        HIP_TRY(ctx, launch_build_order(dc.d_tile_cost, dc.d_tile_cost + n_tiles, n_tiles, sky_cost, tp.grid_lanes, dc.d_tile_order,
+                                        dc.d_order_meta, dc.d_order_scratch, stream));
+        HIP_TRY(ctx, hipEventRecord(dc.ev_last, stream));   // a later launch on another stream starts behind the order build
+        dc.order_lane = 0;
+        dc.order_crit = 0;
+        dc.order_on_device = true;
+    } else {
+        dc.h_cost.resize(2 * (size_t)n_tiles);
+        HIP_TRY(ctx, hipMemcpyAsync(dc.h_cost.data(), dc.d_tile_cost, (size_t)n_tiles * 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        TileOrder to;
+        build_tile_order(dc.h_cost.data(), dc.h_cost.data() + n_tiles, n_tiles, tp, &to);   // sums, then longest pixels (brt_host.cpp)
+        dc.h_order.swap(to.order);
+        dc.order_lane = to.n_lane;
+        dc.order_crit = to.n_critical;
+        dc.order_on_device = false;
+        HIP_TRY(ctx, hipMemcpyAsync(dc.d_tile_order, dc.h_order.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, stream));
+        HIP_TRY(ctx, hipStreamSynchronize(stream));   // h_order may be reused by the next call
+    }
     order_key_of(ctx, fp, dc.order_key);
     dc.order_valid = true;
     dc.order_age = 0;
@@ -412,8 +435,8 @@ int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const fl
 // synchronous paths (the order is built on the host), only when the frame is at least 16x the pre-pass.  The
 // pre-pass renders into the frame's own tile buffer; the frame overwrites every pixel of it afterwards.
 int32_t prepass_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const float* d_raster_rgba,
-                      const float* d_raster_depth, float* d_out_tile, hipStream_t stream, uint32_t flags, double* ms_out) {
-    *ms_out = 0.0;
+                      const float* d_raster_depth, float* d_out_tile, hipStream_t stream, uint32_t flags, bool* ran) {
+    *ran = false;
     const uint32_t k = env_u32("BRT_PREPASS_SPP", 2);
     if (k == 0u || !lpt_enabled() || fp.level == 0u || fp.sample_count < 16u * k || (flags & BRT_FLAG_KERNEL_SIMPLE)) return BRT_OK;
     uint32_t key[6];
@@ -423,6 +446,7 @@ int32_t prepass_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const 
     pp.sample_count = k;
     pp.spp_f = (float)k;
     pp.tile_order = nullptr;
+    pp.order_meta = nullptr;
     pp.tunable = 1u;   // the knobs-live instantiation (all knobs at their defaults): the pre-pass then shows up under its own
                        // kernel name in rocprofv3 --stats instead of pulling down the average of the frame kernel
     pp.queue_lane = 0u;
@@ -432,14 +456,24 @@ int32_t prepass_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const 
     if (rc != BRT_OK) return rc;
     HIP_TRY(ctx, hipMemsetAsync(dc.d_tile_cost, 0, (size_t)n_tiles * 8, stream));
     pp.tile_cost = dc.d_tile_cost;
-    rc = launch_part(ctx, dc, pp, d_raster_rgba, d_raster_depth, d_out_tile, stream, flags & ~(uint32_t)BRT_FLAG_COUNTERS, true, nullptr);
+    HIP_TRY(ctx, hipEventRecord(dc.ev_p0, stream));
+    rc = launch_part(ctx, dc, pp, d_raster_rgba, d_raster_depth, d_out_tile, stream, flags & ~(uint32_t)BRT_FLAG_COUNTERS, false, nullptr);
     if (rc != BRT_OK) return rc;
-    rc = update_tile_order(ctx, dc, pp, stream);      // synchronises, builds and uploads the order
+    HIP_TRY(ctx, hipEventRecord(dc.ev_p1, stream));
+    rc = update_tile_order(ctx, dc, pp, stream);      // on the GPU, behind the pre-pass, no host round trip (default settings)
     if (rc != BRT_OK) return rc;
-    float ms = 0.0f;
-    HIP_TRY(ctx, hipEventElapsedTime(&ms, dc.ev0, dc.ev1));
-    *ms_out = ms;
     dc.order_age = kLptRefresh - 1u;                  // the frame that follows measures again, at full sample count
+    *ran = true;
+    return BRT_OK;
+}
+
+// kernel time of the pre-pass that prepass_order enqueued (its events have completed once the frame behind it has)
+int32_t prepass_elapsed(brt_ctx* ctx, DeviceCtx& dc, bool ran, double* ms_out) {
+    *ms_out = 0.0;
+    if (!ran) return BRT_OK;
+    float ms = 0.0f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, dc.ev_p0, dc.ev_p1));
+    *ms_out = ms;
     return BRT_OK;
 }
 
@@ -476,10 +510,14 @@ void free_device(DeviceCtx& dc) {
     if (dc.d_bvh_scratch) (void)hipFree(dc.d_bvh_scratch);
     if (dc.d_tile_cost) (void)hipFree(dc.d_tile_cost);
     if (dc.d_tile_order) (void)hipFree(dc.d_tile_order);
+    if (dc.d_order_meta) (void)hipFree(dc.d_order_meta);
+    if (dc.d_order_scratch) (void)hipFree(dc.d_order_scratch);
     if (dc.d_bvh_models) (void)hipFree(dc.d_bvh_models);
     if (dc.ev0) (void)hipEventDestroy(dc.ev0);
     if (dc.ev1) (void)hipEventDestroy(dc.ev1);
     if (dc.ev_last) (void)hipEventDestroy(dc.ev_last);
+    if (dc.ev_p0) (void)hipEventDestroy(dc.ev_p0);
+    if (dc.ev_p1) (void)hipEventDestroy(dc.ev_p1);
     if (dc.stream) (void)hipStreamDestroy(dc.stream);
     dc = DeviceCtx();
 }
@@ -556,6 +594,8 @@ int32_t brt_create(const int32_t* device_ids, int32_t n_devices, brt_ctx** out_c
             HIP_TRY(ctx, hipStreamCreateWithFlags(&dc.stream, hipStreamNonBlocking));
             HIP_TRY(ctx, hipEventCreate(&dc.ev0));
             HIP_TRY(ctx, hipEventCreate(&dc.ev1));
+            HIP_TRY(ctx, hipEventCreate(&dc.ev_p0));
+            HIP_TRY(ctx, hipEventCreate(&dc.ev_p1));
             HIP_TRY(ctx, hipEventCreateWithFlags(&dc.ev_last, hipEventDisableTiming));
             HIP_TRY(ctx, hipEventRecord(dc.ev_last, dc.stream));
             HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dc.d_ctrl), 512));
@@ -701,9 +741,9 @@ int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* w
     HIP_TRY(ctx, hipSetDevice(dc.device));
     const bool own_stream = (hip_stream == nullptr) && !(flags & BRT_FLAG_CALLER_STREAM);
     hipStream_t stream = own_stream ? dc.stream : static_cast<hipStream_t>(hip_stream);
-    double prepass_ms = 0.0;
+    bool prepass_ran = false;
     if (own_stream) {
-        rc = prepass_order(ctx, dc, fp, d_raster_rgba, d_raster_depth, d_out_tile, stream, flags, &prepass_ms);
+        rc = prepass_order(ctx, dc, fp, d_raster_rgba, d_raster_depth, d_out_tile, stream, flags, &prepass_ran);
         if (rc != BRT_OK) return rc;
     }
     rc = attach_tile_order(ctx, dc, fp, stream, own_stream);
@@ -731,7 +771,8 @@ int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* w
             stats->rays = tmp.rays; stats->node_pops = tmp.node_pops; stats->interior_visits = tmp.interior_visits;
             stats->sphere_tests = tmp.sphere_tests; stats->hits = tmp.hits;
             stats->kernel_ms = ms;
-            stats->prepass_ms = prepass_ms;
+            rc = prepass_elapsed(ctx, dc, prepass_ran, &stats->prepass_ms);
+            if (rc != BRT_OK) return rc;
             stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
     }
@@ -772,6 +813,7 @@ int32_t render_frame(brt_ctx* ctx, const void* camera80, const void* window16, u
     brt_stats st{};
     LaunchPlan lp{};
     double prepass_ms = 0.0;
+    std::vector<char> prepass_ran(n_parts, 0);
     const bool direct = is_pinned(ctx, out_rgba, frame_px * 16);
 
     // launch every device, then collect: the devices trace their strips concurrently
@@ -801,10 +843,10 @@ int32_t render_frame(brt_ctx* ctx, const void* camera80, const void* window16, u
             HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&dc.h_stage), tile_bytes, hipHostMallocDefault));
             dc.stage_cap = tile_bytes;
         }
-        double pp_ms = 0.0;
-        rc = prepass_order(ctx, dc, fps[p], d_rgba, d_depth, dc.d_tile, dc.stream, flags, &pp_ms);
+        bool ran = false;
+        rc = prepass_order(ctx, dc, fps[p], d_rgba, d_depth, dc.d_tile, dc.stream, flags, &ran);
         if (rc != BRT_OK) return rc;
-        if (pp_ms > prepass_ms) prepass_ms = pp_ms;
+        prepass_ran[p] = ran;
         rc = attach_tile_order(ctx, dc, fps[p], dc.stream, true);
         if (rc != BRT_OK) return rc;
         rc = launch_part(ctx, dc, fps[p], d_rgba, d_depth, dc.d_tile, dc.stream, flags, true, &lp);
@@ -835,6 +877,10 @@ int32_t render_frame(brt_ctx* ctx, const void* camera80, const void* window16, u
         float ms = 0.0f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, dc.ev0, dc.ev1));
         if (ms > kernel_ms) kernel_ms = ms;
+        double pp_ms = 0.0;
+        rc = prepass_elapsed(ctx, dc, prepass_ran[p] != 0, &pp_ms);
+        if (rc != BRT_OK) return rc;
+        if (pp_ms > prepass_ms) prepass_ms = pp_ms;
         rc = update_tile_order(ctx, dc, fps[p], dc.stream);
         if (rc != BRT_OK) return rc;
         const auto g0 = std::chrono::steady_clock::now();
@@ -912,6 +958,38 @@ int32_t brt_debug_profile(brt_ctx* ctx, uint64_t* out64) {
     HIP_TRY(ctx, hipSetDevice(dc.device));
     HIP_TRY(ctx, hipMemcpy(out64, dc.d_ctrl, 512, hipMemcpyDeviceToHost));
     return BRT_OK;
+}
+
+int32_t brt_debug_tile_order(brt_ctx* ctx, const uint32_t* ray_sum, const uint32_t* longest_pixel, uint32_t n_tiles,
+                             uint32_t sample_count, uint64_t grid_lanes, uint32_t* out_order, uint32_t* out_info2) {
+    if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (!ray_sum || !longest_pixel || !out_order || !out_info2 || n_tiles == 0) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "null buffer / no tiles");
+    DeviceCtx& dc = ctx->devs[0];
+    HIP_TRY(ctx, hipSetDevice(dc.device));
+    uint32_t* d_cost = nullptr;
+    uint32_t* d_order = nullptr;
+    uint32_t* d_meta = nullptr;
+    char* d_scratch = nullptr;
+    auto body = [&]() -> int32_t {
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_cost), (size_t)n_tiles * 8));
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_order), (size_t)n_tiles * 4));
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_meta), 256));
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_scratch), order_scratch_bytes(n_tiles)));
+        HIP_TRY(ctx, hipMemcpyAsync(d_cost, ray_sum, (size_t)n_tiles * 4, hipMemcpyHostToDevice, dc.stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_cost + n_tiles, longest_pixel, (size_t)n_tiles * 4, hipMemcpyHostToDevice, dc.stream));
+        const uint64_t sky_cost = (uint64_t)64 * sample_count * (1000 + 20) / 1000;
+        HIP_TRY(ctx, launch_build_order(d_cost, d_cost + n_tiles, n_tiles, sky_cost, grid_lanes, d_order, d_meta, d_scratch, dc.stream));
+        HIP_TRY(ctx, hipMemcpyAsync(out_order, d_order, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, dc.stream));
+        HIP_TRY(ctx, hipMemcpyAsync(out_info2, d_meta, 8, hipMemcpyDeviceToHost, dc.stream));
+        HIP_TRY(ctx, hipStreamSynchronize(dc.stream));
+        return BRT_OK;
+    };
+    const int32_t rc = body();
+    if (d_cost) (void)hipFree(d_cost);
+    if (d_order) (void)hipFree(d_order);
+    if (d_meta) (void)hipFree(d_meta);
+    if (d_scratch) (void)hipFree(d_scratch);
+    return rc;
 }
 
 int32_t brt_debug_eval(brt_ctx* ctx, uint32_t op, const float* in16, float* out8, uint32_t n) {

@@ -201,6 +201,7 @@ struct FrameParams {
     // of each finished pixel, tile_cost[n_tiles + tile] = max of them.  Either may be null.
     const uint32_t* tile_order;
     uint32_t* tile_cost;
+    const uint32_t* order_meta;      // order built on the GPU (brt_order.hip): [0] = critical tiles at its front (replaces crit_end)
     uint32_t tunable;                // 1: some knob above differs from its default -> the TUNABLE kernel instantiation
     uint32_t policy_flags;           // TUNABLE only; bit 0: `||` of raytrace.wgsl:269 short-circuits (alternative policy)
 };

@@ -233,6 +233,8 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     const uint32_t leaf_vote = TUNABLE ? fp.leaf_vote : kLeafVote;
     const uint32_t drain_donate = TUNABLE ? fp.drain_donate : kDrainDonate;
     const uint32_t pool_adopt = TUNABLE ? fp.pool_adopt : kPoolAdopt;
+    // queue slots [crit_begin, crit_end) hold the CRITICAL tiles; when the order was built on the GPU its count lives there too
+    const uint32_t crit_end = fp.order_meta ? fp.order_meta[0] * 64u : fp.crit_end;
 
     PixelState ps;
     ps.sample = 0; ps.rng = 0; ps.out_index = 0; ps.frame_index = 0; ps.tile = 0; ps.rays_begin = 0;
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         const PixelCoord c = slot_to_pixel<TUNABLE>(fp, q, tile);
         if (c.inside) {
             pixel_begin(fp, c, ps);
-            crit = q >= fp.crit_begin && q < fp.crit_end;
+            crit = q >= fp.crit_begin && q < crit_end;
             ps.rays_begin = n_rays;
             if (fp.sample_count == 0) {
                 // 0/0 per channel.  The sums are compile-time zeros here; keep them opaque: hipcc 7.2
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         // A wave that carries one of the frame's CRITICAL pixels (FrameParams::crit_*) issues ahead of its SIMD
         // mates and takes no new pixels: its rounds get shorter as its other pixels end, and the frame cannot
         // end before that chain has.
-        if (fp.crit_end != 0u) {
+        if (crit_end != 0u) {
             const bool wc = __ballot(active && crit) != 0ull;
             if (wc != wave_crit) {
                 wave_crit = wc;
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                     batch = batch > wgq_batch ? wgq_batch : (batch < 64u ? 64u : batch);
                     // single tiles until the queue is past the CRITICAL tiles: the waves that carry them run at raised
                     // priority and should sit on different CUs, not eight to a workgroup
-                    if (bbase < fp.crit_end) batch = 64u;
+                    if (bbase < crit_end) batch = 64u;
                     uint32_t b = 0;
                     if (lane == 0) b = atomicAdd(queue_counter, batch);
                     b = (uint32_t)__shfl((int)b, 0, 64);

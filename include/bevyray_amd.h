@@ -197,6 +197,12 @@ int32_t brt_debug_eval(brt_ctx* ctx, uint32_t op, const float* in16, float* out8
  * walk begin, [44] rejection-sampler loop.  out64 must hold 64 words. */
 int32_t brt_debug_profile(brt_ctx* ctx, uint64_t* out64);
 
+/* Diagnostic: the dispatch order as the GPU builds it (bevyray_amd/csrc/brt_order.hip, used behind every measuring
+ * frame with default settings) for given per-tile ray counts: out_order as brt_host_tile_order's, out_info2 =
+ * {critical tiles at the front, longest pixel}.  Tests compare it with brt_host_tile_order.  Host pointers, synchronous. */
+int32_t brt_debug_tile_order(brt_ctx* ctx, const uint32_t* ray_sum, const uint32_t* longest_pixel, uint32_t n_tiles,
+                             uint32_t sample_count, uint64_t grid_lanes, uint32_t* out_order, uint32_t* out_info2);
+
 /* ---- host-only helpers (no GPU needed) --------------------------------------------- */
 
 /* The dispatch order brt_render derives from one frame's per-tile ray counts (sum and longest pixel of each

@@ -897,3 +897,43 @@ def test_shared_reciprocal_division_is_the_compilers_division_in_the_plain_range
     assert_frames_equal(out[:, 1], n / d)
     assert_frames_equal(out[:, 2], np.float32(1.0) / d)
     assert_frames_equal(out[:, 3], np.float32(1.0) / d)
+
+
+# ---- the dispatch order built on the GPU (brt_order.hip) against the host statement of the rule (brt_host.cpp) ----------
+
+def test_gpu_tile_order_equals_host_tile_order(plugin):
+    import ctypes as C
+    from bevyray_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(17)
+    for n, spp, lanes in [(1, 64, 262144), (200, 64, 262144), (32400, 64, 262144), (129600, 1024, 262144), (5000, 8, 1000),
+                          (777, 64, 40), (4096, 256, 262144)]:
+        for flavour in range(3):
+            longest = rng.integers(spp, spp * 9 + 1, n).astype(np.uint32)
+            ray_sum = (64 * spp + 200 + longest.astype(np.uint64) * 30).astype(np.uint32)
+            sky = rng.random(n) < (0.0, 0.3, 1.0)[flavour]
+            longest[sky], ray_sum[sky] = spp, 64 * spp
+            if flavour == 1 and n > 10:
+                k = len(longest[1::5])
+                longest[0:5 * k:5] = longest[1::5]           # ties: raster order among equals
+            want = np.zeros(n, np.uint32); info3 = np.zeros(3, np.uint32)
+            _lib.check(lib.brt_host_tile_order(ray_sum.ctypes.data, longest.ctypes.data, n, spp, lanes, 1, 0, want.ctypes.data, info3.ctypes.data))
+            got = np.zeros(n, np.uint32); info2 = np.zeros(2, np.uint32)
+            _lib.check(lib.brt_debug_tile_order(plugin._ctx, ray_sum.ctypes.data, longest.ctypes.data, n, spp, lanes, got.ctypes.data,
+                                                info2.ctypes.data), plugin._ctx)
+            assert np.array_equal(got, want), (n, spp, flavour)
+            assert int(info2[0]) == int(info3[1]) and int(info2[1]) == int(info3[2]), (n, spp, flavour, info2, info3)
+
+
+def test_order_built_on_host_and_on_gpu_render_the_same_frames(oracle, monkeypatch):
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    w, h = 320, 180
+    lvl, cam, win = brt.cover_camera(w, h, 32, 8)
+    want, cnt = oracle.render(b, lvl, cam, win, w, h)
+    for host in ("0", "1"):
+        monkeypatch.setenv("BRT_ORDER_ON_HOST", host)
+        with brt.RaytracePlugin([0]) as p:
+            for _ in range(3):      # pre-pass + frame, then frames in the order measured by the one before
+                got = p.node.run(lvl, cam, win, w, h, buffers=b, flags=brt.FLAG_COUNTERS)
+                assert_frames_equal(got, want)
+                assert {k: p.node.last_stats[k] for k in COUNTER_KEYS} == cnt
