@@ -92,7 +92,7 @@ def self_launch(args):
 
 
 def load_tracer():
-    """(plugin, node, device, backend).  The product tracer needs an MI355X; BRT_BENCH_TRACER=module:factory
+    """None, or the factory of a stand-in tracer.  The product tracer needs an MI355X; BRT_BENCH_TRACER=module:factory
     swaps in a stand-in (tests/stub_tracer.py: CPU tensors over gloo) so that the launch / gather / reporting
     logic of this file can be tested without a GPU.  A stub run says so in its JSON line (`data`)."""
     hook = os.environ.get("BRT_BENCH_TRACER")
