@@ -55,6 +55,8 @@ struct DeviceCtx {
     char* d_order_scratch = nullptr;
     size_t order_scratch_cap = 0;
     bool order_on_device = false;                        // d_tile_order / d_order_meta were written by brt_order.hip
+    uint64_t view_rays = 0;                              // rays of the last completed frame of the view `view_key` (0: unknown)
+    uint32_t view_key[6] = {0, 0, 0, 0, 0, 0};
     bool order_valid = false;
     uint32_t order_age = 0;                       // frames since the costs were last measured
     uint32_t order_key[6] = {0, 0, 0, 0, 0, 0};   // width, height, part, n_parts, scene epoch, n_tiles
@@ -402,6 +404,19 @@ int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const fl
             lp.grid = (fp.queue_size + 255u) / 256u;
         } else {
             lp = plan_launch(dc, fp);
+            // LEAN instantiation (brt_trace.h): Pure level, not a measuring frame, and no critical tile possible -- a tile is
+            // critical only if its longest pixel needs at least half a lane's share of the frame's rays (build_tile_order),
+            // and no pixel needs more than sample_count * (bounce_count + 1); the frame's rays are those of the last
+            // completed frame of this view.  (A wrong guess would only cost speed: critical tiles are a scheduling hint.)
+            {
+                uint32_t key[6];
+                order_key_of(ctx, fp, key);
+                const bool known = dc.view_rays != 0 && std::memcmp(key, dc.view_key, sizeof key) == 0;
+                const uint64_t per_lane = known ? dc.view_rays / ((uint64_t)dc.num_cus * BRT_BLOCK) : 0;
+                const uint64_t longest_bound = (uint64_t)fp.sample_count * ((uint64_t)fp.bounce_count + 1u);
+                tl.lean = known && !tl.frame.tunable && fp.level == 3u && fp.tile_cost == nullptr && !tl.counters_on &&
+                          longest_bound < per_lane / 2 && env_u32("BRT_NO_LEAN", 0) == 0u;
+            }
             tl.scene_mode = lp.scene_mode;
             tl.scene.lds_pairs = lp.lds_pairs;
             tl.grid = lp.grid;
@@ -763,6 +778,8 @@ int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* w
         brt_stats tmp{};
         rc = read_counters(ctx, dc, stream, &tmp);  // synchronises
         if (rc != BRT_OK) return rc;
+        dc.view_rays = tmp.rays;
+        order_key_of(ctx, fp, dc.view_key);
         float ms = 0.0f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, dc.ev0, dc.ev1));
         rc = update_tile_order(ctx, dc, fp, stream);
@@ -872,8 +889,11 @@ int32_t render_frame(brt_ctx* ctx, const void* camera80, const void* window16, u
     for (uint32_t p = 0; p < n_parts; p++) {
         DeviceCtx& dc = ctx->devs[p];
         HIP_TRY(ctx, hipSetDevice(dc.device));
+        const uint64_t rays_before = st.rays;
         int32_t rc = read_counters(ctx, dc, dc.stream, &st);  // synchronises the stream
         if (rc != BRT_OK) return rc;
+        dc.view_rays = st.rays - rays_before;
+        order_key_of(ctx, fps[p], dc.view_key);
         float ms = 0.0f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, dc.ev0, dc.ev1));
         if (ms > kernel_ms) kernel_ms = ms;

@@ -23,6 +23,7 @@ struct TraceLaunch {
     unsigned long long* counters;       // 5 x u64, zeroed by the caller
     int scene_mode;                     // SceneMode (brt_layout.h)
     bool counters_on;
+    bool lean;                          // level 3, no tile-cost measurement, no critical tiles possible: the LEAN instantiation
     uint32_t grid, block;
     size_t lds_bytes;
     hipStream_t stream;

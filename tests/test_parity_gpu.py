@@ -937,3 +937,32 @@ def test_order_built_on_host_and_on_gpu_render_the_same_frames(oracle, monkeypat
                 got = p.node.run(lvl, cam, win, w, h, buffers=b, flags=brt.FLAG_COUNTERS)
                 assert_frames_equal(got, want)
                 assert {k: p.node.last_stats[k] for k in COUNTER_KEYS} == cnt
+
+
+def test_lean_steady_state_kernel_renders_the_same_pixels(oracle, monkeypatch):
+    """From the second frame of a Pure-level view on, frames that do not measure tile costs run the LEAN instantiation
+    (no raster inputs, no depth average, no critical-tile logic) when the host can rule critical tiles out: the cover
+    frame at 64 spp x 9 segments qualifies at this size too.  Same pixels and ray count as the oracle, frame after
+    frame, with and without it (BRT_NO_LEAN=1), and at levels 1 / 2, which never use it."""
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    w, h = 480, 270
+    lvl, cam, win = brt.cover_camera(w, h, 16, 2)        # 16 spp x 3 segments = 48 < half a lane's share (~69)
+    want, cnt = oracle.render(b, lvl, cam, win, w, h)
+    for no_lean in ("0", "1"):
+        monkeypatch.setenv("BRT_NO_LEAN", no_lean)
+        with brt.RaytracePlugin([0]) as p:
+            for frame in range(5):
+                got = p.node.run(lvl, cam, win, w, h, buffers=b)
+                assert_frames_equal(got, want)
+                assert p.node.last_stats["rays"] == cnt["rays"], (no_lean, frame)
+    monkeypatch.delenv("BRT_NO_LEAN")
+    rng = np.random.default_rng(1)
+    raster = rng.random((h, w, 4), dtype=np.float32)
+    depth = rng.random((h, w), dtype=np.float32) * np.float32(0.05)
+    for level in (brt.Raytracing.FallbackRaster, brt.Raytracing.FallbackRaytraced):
+        lvl, cam, win = brt.cover_camera(w, h, 16, 2, level)
+        want, cnt = oracle.render(b, lvl, cam, win, w, h, raster_rgba=raster, raster_depth=depth)
+        with brt.RaytracePlugin([0]) as p:
+            for frame in range(3):
+                got = p.node.run(lvl, cam, win, w, h, buffers=b, raster_rgba=raster, raster_depth=depth)
+                assert_frames_equal(got, want)
