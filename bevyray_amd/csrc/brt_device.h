@@ -84,6 +84,15 @@ BRT_DEV bool all_within(f3 v, float lo, float hi) {
     return min_f(min_f(ax, ay), az) >= lo && max_f(max_f(ax, ay), az) <= hi;
 }
 BRT_DEV bool wave_all(bool p) { return __ballot(!p) == 0ull; }   // over the lanes that are active at the call
+// Number of active lanes for which p holds, as a 32-bit SCALAR.  The empty asm pins the count to an SGPR as a 32-bit
+// value: otherwise LLVM folds the truncation of the 64-bit popcount into the comparison that follows, and a 64-bit
+// compare of a scalar only exists on the vector ALU (v_cmp_gt_u64 on an SGPR pair -- one VALU instruction per
+// iteration of the walk loop).
+BRT_DEV uint32_t wave_count(bool p) {
+    uint32_t n = (uint32_t)__popcll(__ballot(p));
+    asm volatile("" : "+s"(n));
+    return n;
+}
 
 // The correctly rounded sqrt likewise: hipcc emits v_sqrt_f32 (1 ulp) and picks the best of {s - 1 ulp, s, s + 1 ulp} by
 // the sign of two exact residuals, wrapped in a 2^32 pre-scale for tiny arguments and a class test for 0 / inf / NaN
@@ -430,15 +439,13 @@ BRT_DEV void walk_loop_wave(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, ui
             const bool interior = DS::is_interior(cur) && (SIMPLE_TREE || n < 31u);
             if (__ballot(interior) == 0ull) break;
             if (interior) walk_interior_step<64, COUNTERS, FIX, D16, MODE>(sc, o, inv, ox, oy, oz, below, cur, sp, n, hc);
-            const uint32_t want_leaf = (uint32_t)__popcll(__ballot(DS::is_leaf(cur) && (SIMPLE_TREE || n < 31u)));
-            if (want_leaf >= vote) break;
+            if (wave_count(DS::is_leaf(cur) && (SIMPLE_TREE || n < 31u)) >= vote) break;
         }
         if (DS::is_leaf(cur) && (SIMPLE_TREE || n < 31u)) {
             walk_leaf_step<64, COUNTERS, D16, SIMPLE_TREE>(sc, o, d, a, closest, closest_idx, cur, sp, n, hc);
             below = float_below(closest);
         }
-        const uint32_t n_walking = (uint32_t)__popcll(__ballot(cur != DS::DONE && (SIMPLE_TREE || n < 31u)));
-        if (n_walking <= exit_at) break;
+        if (wave_count(cur != DS::DONE && (SIMPLE_TREE || n < 31u)) <= exit_at) break;
     }
 }
 
@@ -469,7 +476,7 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, f3
         // descriptor form (brt_layout.h) a finished lane fails both body tests by itself.
         // The loop exists twice: without and with the min/max repair of the near/far reads
         // (walk_interior_step); the wave takes the second one only when one of its rays needs it.
-        const uint32_t n_walking = (uint32_t)__popcll(__ballot(pending));
+        const uint32_t n_walking = wave_count(pending);
         uint32_t exit_at = n_walking >> 1;
         exit_at = exit_at < exit_lanes ? exit_at : exit_lanes;
         const uint32_t vote = leaf_vote < 1u ? 1u : leaf_vote;
