@@ -446,9 +446,10 @@ int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const fl
 // The first frame of a view has no measured dispatch order (raster order: 16.0 instead of 13.3 ms on the headline
 // frame).  A pre-pass of the same view at BRT_PREPASS_SPP samples per pixel (default 2; 0 = off) measures the tile
 // costs first -- pixels are sequential chains of samples, so k samples predict the chain lengths of the full frame
-// -- and the frame itself then runs in that order (and measures again, for the frames that follow).  Only on the
-// synchronous paths (the order is built on the host), only when the frame is at least 16x the pre-pass.  The
-// pre-pass renders into the frame's own tile buffer; the frame overwrites every pixel of it afterwards.
+// -- and the frame itself then runs in that order (and measures again, for the frames that follow).  Enqueued on the
+// context's own stream ahead of the frame (the order is built on the GPU behind it: no host round trip); only on the
+// entry points that own their stream, only when the frame is at least 16x the pre-pass.  The pre-pass renders into the
+// frame's own tile buffer; the frame overwrites every pixel of it afterwards.
 int32_t prepass_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const float* d_raster_rgba,
                       const float* d_raster_depth, float* d_out_tile, hipStream_t stream, uint32_t flags, bool* ran) {
     *ran = false;
