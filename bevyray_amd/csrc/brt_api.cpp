@@ -414,8 +414,9 @@ int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const fl
                 const bool known = dc.view_rays != 0 && std::memcmp(key, dc.view_key, sizeof key) == 0;
                 const uint64_t per_lane = known ? dc.view_rays / ((uint64_t)dc.num_cus * BRT_BLOCK) : 0;
                 const uint64_t longest_bound = (uint64_t)fp.sample_count * ((uint64_t)fp.bounce_count + 1u);
-                tl.lean = known && !tl.frame.tunable && fp.level == 3u && fp.tile_cost == nullptr && !tl.counters_on &&
-                          longest_bound < per_lane / 2 && env_u32("BRT_NO_LEAN", 0) == 0u;
+                const bool lean1 = !tl.frame.tunable && fp.level == 3u && fp.tile_cost == nullptr && !tl.counters_on &&
+                                   env_u32("BRT_NO_LEAN", 0) == 0u;
+                tl.lean = !lean1 ? 0 : ((known && longest_bound < per_lane / 2) ? 2 : 1);
             }
             tl.scene_mode = lp.scene_mode;
             tl.scene.lds_pairs = lp.lds_pairs;

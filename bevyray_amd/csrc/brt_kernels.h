@@ -23,7 +23,7 @@ struct TraceLaunch {
     unsigned long long* counters;       // 5 x u64, zeroed by the caller
     int scene_mode;                     // SceneMode (brt_layout.h)
     bool counters_on;
-    bool lean;                          // level 3, no tile-cost measurement, no critical tiles possible: the LEAN instantiation
+    int lean;                           // LEAN instantiation (brt_trace.h): 0 general; 1 level 3 + no tile-cost measurement; 2 + no critical tile possible
     uint32_t grid, block;
     size_t lds_bytes;
     hipStream_t stream;

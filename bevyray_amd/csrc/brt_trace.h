@@ -155,10 +155,11 @@ BRT_DEV uint32_t pool_peek(const uint32_t* ctl, int i) { return __atomic_load_n(
 // happen -- are staged in LDS, deeper records and the spheres come from global memory (L2).  SCENE_GLOBAL: no
 // staging.  D16: 16-bit descriptors and u16 stack entries (always with the LDS modes).  SIMPLE: see raycast
 // (brt_device.h).  TUNABLE: tuning knobs live (FrameParams) instead of folded to their defaults, lane queue built in.
-// LEAN: what the steady-state frame of a Pure-level view needs and nothing else -- level 3 (no raster inputs, no depth
-// average), no tile-cost measurement (15 of 16 frames), no critical tiles (the host can rule them out: launch_part) --
-// so that their checks, registers and kernel arguments leave the round loop.  Same box: 12.87 -> 12.59 ms (-2.2 %).
-template <int MODE, bool D16, bool SIMPLE, bool COUNTERS, bool TUNABLE, bool LEAN>
+// LEAN: what the steady-state frame of a Pure-level view needs and nothing else, so that the other checks, registers
+// and kernel arguments leave the round loop.  1: level 3 (no raster inputs, no depth average) and no tile-cost
+// measurement (15 of 16 frames); 2: also no critical tiles (the host can rule them out: launch_part).  Same box,
+// headline frame: 12.87 (0) -> 12.73 (1) -> 12.59 ms (2).
+template <int MODE, bool D16, bool SIMPLE, bool COUNTERS, bool TUNABLE, int LEAN>
 __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView sv, FrameParams fp,
                                                                 uint32_t* __restrict__ queue_counter,
                                                                 float* __restrict__ out_tile,
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     const uint32_t drain_donate = TUNABLE ? fp.drain_donate : kDrainDonate;
     const uint32_t pool_adopt = TUNABLE ? fp.pool_adopt : kPoolAdopt;
     // queue slots [crit_begin, crit_end) hold the CRITICAL tiles; when the order was built on the GPU its count lives there too
-    const uint32_t crit_end = LEAN ? 0u : (fp.order_meta ? fp.order_meta[0] * 64u : fp.crit_end);
+    const uint32_t crit_end = LEAN == 2 ? 0u : (fp.order_meta ? fp.order_meta[0] * 64u : fp.crit_end);
 
     PixelState ps;
     ps.sample = 0; ps.rng = 0; ps.out_index = 0; ps.frame_index = 0; ps.tile = 0; ps.rays_begin = 0;
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                 // otherwise folds the four divisions into one and then drops two channels of the
                 // level-1/2 result (found by scripts/fuzz_parity.py; tests: sample_count 0).
                 asm volatile("" : "+v"(ps.sum.x), "+v"(ps.sum.y), "+v"(ps.sum.z), "+v"(ps.dsum));
-                pixel_finish<LEAN>(fp, ps, out_tile, raster_rgba, raster_depth);
+                pixel_finish<LEAN != 0>(fp, ps, out_tile, raster_rgba, raster_depth);
             } else { active = true; bounce = 0; }
         }
     };
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                 ps.sample++;
                 bounce = 0;
                 if (ps.sample == fp.sample_count) {
-                    pixel_finish<LEAN>(fp, ps, out_tile, raster_rgba, raster_depth);
+                    pixel_finish<LEAN != 0>(fp, ps, out_tile, raster_rgba, raster_depth);
                     if (!LEAN && fp.tile_cost) {
                         atomicAdd(&fp.tile_cost[ps.tile], n_rays - ps.rays_begin);
                         atomicMax(&fp.tile_cost[fp.local_strips * fp.tiles_x + ps.tile], n_rays - ps.rays_begin);
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
 }
 
 
-template <int MODE, bool D, bool S, bool C, bool T, bool LEAN = false>
+template <int MODE, bool D, bool S, bool C, bool T, int LEAN = 0>
 static hipError_t launch_persistent_t(const TraceLaunch& tl) {
     auto kern = k_trace_persistent<MODE, D, S, C, T, LEAN>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -539,7 +540,8 @@ template <int MODE, bool D, bool T>
 static hipError_t launch_persistent_md(const TraceLaunch& tl) {
     // LEAN instantiations only where they matter: the production timing kernel on a simple (PLOC-shaped) tree staged in LDS
     if (!T && MODE != SCENE_GLOBAL && tl.lean && tl.scene.simple_tree && !tl.counters_on)
-        return launch_persistent_t<MODE, D, true, false, false, (!T && MODE != SCENE_GLOBAL)>(tl);
+        return tl.lean == 2 ? launch_persistent_t<MODE, D, true, false, false, (!T && MODE != SCENE_GLOBAL) ? 2 : 0>(tl)
+                            : launch_persistent_t<MODE, D, true, false, false, (!T && MODE != SCENE_GLOBAL) ? 1 : 0>(tl);
     if (tl.scene.simple_tree)
         return tl.counters_on ? launch_persistent_t<MODE, D, true, true, T>(tl) : launch_persistent_t<MODE, D, true, false, T>(tl);
     return tl.counters_on ? launch_persistent_t<MODE, D, false, true, T>(tl) : launch_persistent_t<MODE, D, false, false, T>(tl);
