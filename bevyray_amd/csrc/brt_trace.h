@@ -378,7 +378,8 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         bool finish_walks = false;    // this round runs every walk to its end so that the wave can hand over next round
         if (fp.pool_cap != 0u && __ballot(exhausted) != 0ull && !wave_crit) {
             const uint64_t am = __ballot(active);
-            const uint32_t live = (uint32_t)__popcll(am);
+            uint32_t live = (uint32_t)__popcll(am);
+            asm volatile("" : "+s"(live));   // a 32-bit scalar (see wave_count, brt_device.h)
             const bool quiet = __ballot(in_flight) == 0ull;              // no suspended walk: every live path is between two rays
             const bool thin = live != 0u && live <= drain_donate;
             bool leave = false;
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                 pool_unlock(pool_ctl, lane);
             }
             if (leave) break;
-            finish_walks = (uint32_t)__popcll(__ballot(active)) <= drain_donate;
+            finish_walks = wave_count(active) <= drain_donate;
         } else if (__ballot(active) == 0 && (queue_lane == fp.queue_size || tiles_done || __ballot(!exhausted) != 0ull)) {
             break;
         }
