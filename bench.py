@@ -121,6 +121,8 @@ def main():
     if stub is None:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: no HIP device (there is no CPU path)")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py --gpus {args.gpus}: rank {rank} has no GPU (this node shows {torch.cuda.device_count()})")
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
         backend = "nccl"
