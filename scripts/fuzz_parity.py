@@ -186,9 +186,13 @@ def main():
     t_start = time.time()
     fails, done, pixels, rays, ploc_checked, rejected = 0, 0, 0, 0, 0, 0
     lines = []
+    t_progress = time.time()
     for case in range(args.cases):
         if time.time() - t_start > args.seconds:
             break
+        if time.time() - t_progress > 60:      # a line a minute: the GPU boxes take a silent command for a hung one
+            t_progress = time.time()
+            print(f"... {done} cases so far, {fails} failed, {time.time() - t_start:.0f} s", flush=True)
         c = random_case(rng)
         b = c["buffers"]
         # kernel variant of this case: default plan, top-of-tree tile of a few records, everything from L2, knobs live
