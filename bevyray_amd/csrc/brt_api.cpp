@@ -245,21 +245,23 @@ LaunchPlan plan_launch(const DeviceCtx& dc, const FrameParams& fp) {
         }
     }
     if (lp.scene_mode != SCENE_LDS && !force_global && dc.view.desc16) {
-        // top of the tree in LDS: one workgroup per CU, everything that is left of the LDS for pair records
+        // top of the tree in LDS: everything that is left of a workgroup's LDS share for pair records
         DeviceSceneView v = dc.view;
         v.lds_pairs = 0;
         const uint32_t block = block_env ? block_env : BRT_BLOCK;
-        const uint32_t pool = pool_of(block) < 192u ? pool_of(block) : 192u;   // half the pool: the tile is worth more
+        const uint32_t per_cu = wg_env ? wg_env : 1u;
+        const size_t share = dc.max_lds / per_cu;
+        const uint32_t pool = pool_of(block) < 192u / per_cu ? pool_of(block) : 192u / per_cu;   // half the pool: the tile is worth more
         const size_t fixed = trace_lds_bytes(v, SCENE_LDS_TOP, block, pool);
-        if (fixed + 64 * PAIR_BYTES <= dc.max_lds) {
-            uint32_t k = (uint32_t)((dc.max_lds - fixed) / PAIR_BYTES);
+        if (fixed + 64 * PAIR_BYTES <= share && per_cu * (block / 64u) <= max_waves_cu) {
+            uint32_t k = (uint32_t)((share - fixed) / PAIR_BYTES);
             if (k > v.n_pairs) k = v.n_pairs;
             if (force_top && force_top < k) k = force_top;
             v.lds_pairs = k;
             lp.scene_mode = SCENE_LDS_TOP;
             lp.lds_pairs = k;
             lp.block = block;
-            lp.wg_per_cu = 1;
+            lp.wg_per_cu = per_cu;
             lp.pool_cap = pool;
             lp.lds_bytes = trace_lds_bytes(v, SCENE_LDS_TOP, block, pool);
         }
