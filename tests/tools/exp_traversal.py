@@ -34,7 +34,27 @@ COST_INT = {2: 64, 4: 135, 8: 260}     # wave instructions per interior-body exe
 COST_LEAF = 75
 
 
+def policy_grid(n=60):
+    """Leaf-vote x walk-exit thresholds of the width-2 walk: total wave instructions per ray (1060 non-walk per round)."""
+    W, H, spp, bounces = 1920, 1080, 64, 8
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    lvl, cam, win = brt.cover_camera(W, H, spp, bounces)
+    rng = np.random.default_rng(5)
+    tiles = np.stack([rng.integers(0, W // 8, n), rng.integers(0, H // 8, n)], 1)
+    exits = (4, 8, 12, 16, 24)
+    print("rows: leaf vote; columns: exit lanes " + ", ".join(map(str, exits)) + "; cell: walk instr per round / instr per ray")
+    for vote in (6, 8, 12, 16, 24, 32, 64):
+        row = []
+        for ex in exits:
+            r = run(b, cam, win, W, H, tiles, vote=vote, exit_lanes=ex)
+            walk = r["int_exec"] * COST_INT[2] + r["leaf_exec"] * COST_LEAF
+            row.append(f"{walk / r['rounds']:6.0f}/{(walk + r['rounds'] * 1060) / r['rays']:5.1f}")
+        print(f"vote {vote:2d}: " + "  ".join(row), flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--policy-grid":
+        return policy_grid(int(sys.argv[2]) if len(sys.argv) > 2 else 60)
     scene = int(sys.argv[1]) if len(sys.argv) > 1 else brt.SCENE_COVER
     W, H, spp, bounces = 1920, 1080, 64, 8
     b = brt.generate_scene(scene, 1)
