@@ -164,6 +164,17 @@ static void step_leaf(const Scene* s, Walk* w, const Variant* v, SimCnt* c) {
     pop(w, v, c);
 }
 
+/* ---- study of the top-of-tree LDS tile (SCENE_LDS_TOP): nodes whose breadth-first rank is < g_tile_k are "near"
+ * (LDS), the others "far" (L2).  g_split = 0: the kernel's loop (one interior step for near and far lanes alike; a
+ * step that contains a far lane waits for L2).  g_split = 1: near lanes and far lanes step separately; far lanes
+ * wait (their loads in flight) until no near lane is left or g_far_vote of them have gathered. ---- */
+static int g_tile_k = 0, g_split = 0, g_far_vote = 64;
+static int* g_rank = NULL;
+static uint64_t g_far[8];   /* 0 mixed steps containing a far lane, 1 far lanes in them, 2 near steps, 3 near lanes, 4 far steps, 5 far lanes */
+void exp_set_far(int tile_k, int split, int far_vote) { g_tile_k = tile_k; g_split = split; g_far_vote = far_vote; }
+void exp_get_far(uint64_t* out8) { memcpy(out8, g_far, sizeof g_far); }
+static inline int is_far(int c) { return g_tile_k > 0 && c >= 0 && g_rank[c] >= g_tile_k; }
+
 typedef struct {
     int active, in_flight;
     uint32_t rng, sample, bounce;
@@ -207,11 +218,22 @@ static void sim_tile(const Scene* s, const WTree* t, const Variant* v, uint32_t 
         int exit_at = n_walking >> 1; if (exit_at > v->exit_lanes) exit_at = v->exit_lanes;
         for (;;) {
             for (;;) {
-                int ni = 0;
-                for (int l = 0; l < 64; l++) if (L[l].active && is_int(L[l].w.cur)) ni++;
+                int ni = 0, nf = 0;
+                for (int l = 0; l < 64; l++) if (L[l].active && is_int(L[l].w.cur)) { ni++; nf += is_far(L[l].w.cur); }
                 if (!ni) break;
-                c->int_exec++; c->int_lanes += (uint64_t)ni;
-                for (int l = 0; l < 64; l++) if (L[l].active && is_int(L[l].w.cur)) step_interior(s, t, &L[l].w, v, c);
+                c->int_exec++;
+                if (g_split && g_tile_k > 0) {
+                    const int far_step = nf > 0 && (nf == ni || nf >= g_far_vote);
+                    const int n = far_step ? nf : ni - nf;
+                    c->int_lanes += (uint64_t)n;
+                    g_far[far_step ? 4 : 2]++; g_far[far_step ? 5 : 3] += (uint64_t)n;
+                    for (int l = 0; l < 64; l++)
+                        if (L[l].active && is_int(L[l].w.cur) && is_far(L[l].w.cur) == far_step) step_interior(s, t, &L[l].w, v, c);
+                } else {
+                    c->int_lanes += (uint64_t)ni;
+                    if (nf) { g_far[0]++; g_far[1] += (uint64_t)nf; }
+                    for (int l = 0; l < 64; l++) if (L[l].active && is_int(L[l].w.cur)) step_interior(s, t, &L[l].w, v, c);
+                }
                 int nl = 0;
                 for (int l = 0; l < 64; l++) if (L[l].active && is_leaf(L[l].w.cur)) nl++;
                 if (nl >= v->vote) break;
@@ -397,6 +419,14 @@ int exp_run(const void* models, uint32_t n_models, const void* materials, uint32
     WTree t; t.nodes = (WNode*)calloc(n_models + 1, sizeof(WNode)); t.n_nodes = 0;
     t.root_is_leaf = b[0].model_count > 0; t.root_leaf = (int)b[0].index;
     if (!t.root_is_leaf) collapse(b, 0, width, &t);
+    /* breadth-first rank of every wide node (the device layout puts the top levels first) */
+    free(g_rank); g_rank = (int*)calloc((size_t)t.n_nodes + 1, sizeof(int));
+    if (!t.root_is_leaf) {
+        int* q = (int*)malloc(sizeof(int) * (size_t)t.n_nodes); int qh = 0, qt = 0; q[qt++] = 0;
+        while (qh < qt) { int id = q[qh]; g_rank[id] = qh++; for (int i = 0; i < t.nodes[id].n; i++) if (t.nodes[id].child[i] >= 0) q[qt++] = t.nodes[id].child[i]; }
+        free(q);
+    }
+    memset(g_far, 0, sizeof g_far);
     Variant v = {width, near_first, pop_cull, leaf_in_parent, vote, exit_lanes};
     SimCnt c; memset(&c, 0, sizeof c);
     for (uint32_t i = 0; i < n_tiles; i++) {

@@ -34,6 +34,30 @@ COST_INT = {2: 64, 4: 135, 8: 260}     # wave instructions per interior-body exe
 COST_LEAF = 75
 
 
+def far_study(n=40):
+    """Config 5 (10 004 spheres, top 879 records in LDS): would stepping near (LDS) and far (L2) lanes separately pay?"""
+    W, H, spp, bounces = 1920, 1080, 64, 8
+    b = brt.generate_scene(brt.SCENE_STRESS_GRID, 1)
+    lvl, cam, win = brt.cover_camera(W, H, spp, bounces)
+    rng = np.random.default_rng(5)
+    tiles = np.stack([rng.integers(0, W // 8, n), rng.integers(0, H // 8, n)], 1)
+    lib.exp_set_far.argtypes = [I, I, I]
+    lib.exp_get_far.argtypes = [VP]
+    far = np.zeros(8, np.uint64)
+    print(f"{'policy':40s} {'int exec/rnd':>12s} {'lanes':>6s} {'far-containing':>14s} {'near steps':>10s} {'lanes':>6s} {'far steps':>9s} {'lanes':>6s} {'leaf/rnd':>8s}")
+    for name, k, split, fv in [("kernel (one step for all), tile 879", 879, 0, 64), ("split, far when no near lane", 879, 1, 64),
+                               ("split, far vote 32", 879, 1, 32), ("split, far vote 16", 879, 1, 16), ("split, far vote 8", 879, 1, 8),
+                               ("kernel, tile 300", 300, 0, 64), ("split vote 16, tile 300", 300, 1, 16)]:
+        lib.exp_set_far(k, split, fv)
+        r = run(b, cam, win, W, H, tiles)
+        lib.exp_get_far(far.ctypes.data)
+        f = [int(x) for x in far]
+        R = r["rounds"]
+        print(f"{name:40s} {r['int_exec']/R:12.2f} {r['int_lanes']/max(1,r['int_exec']):6.1f} {f[0]/R:14.2f} {f[2]/R:10.2f} {f[3]/max(1,f[2]):6.1f} "
+              f"{f[4]/R:9.2f} {f[5]/max(1,f[4]):6.1f} {r['leaf_exec']/R:8.2f}", flush=True)
+    lib.exp_set_far(0, 0, 64)
+
+
 def policy_grid(n=60):
     """Leaf-vote x walk-exit thresholds of the width-2 walk: total wave instructions per ray (1060 non-walk per round)."""
     W, H, spp, bounces = 1920, 1080, 64, 8
@@ -53,6 +77,8 @@ def policy_grid(n=60):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--far-study":
+        return far_study(int(sys.argv[2]) if len(sys.argv) > 2 else 40)
     if len(sys.argv) > 1 and sys.argv[1] == "--policy-grid":
         return policy_grid(int(sys.argv[2]) if len(sys.argv) > 2 else 60)
     scene = int(sys.argv[1]) if len(sys.argv) > 1 else brt.SCENE_COVER
