@@ -84,14 +84,12 @@ BRT_DEV bool all_within(f3 v, float lo, float hi) {
     return min_f(min_f(ax, ay), az) >= lo && max_f(max_f(ax, ay), az) <= hi;
 }
 BRT_DEV bool wave_all(bool p) { return __ballot(!p) == 0ull; }   // over the lanes that are active at the call
-// Number of active lanes for which p holds, as a 32-bit SCALAR.  The empty asm pins the count to an SGPR as a 32-bit
-// value: otherwise LLVM folds the truncation of the 64-bit popcount into the comparison that follows, and a 64-bit
-// compare of a scalar only exists on the vector ALU (v_cmp_gt_u64 on an SGPR pair -- one VALU instruction per
-// iteration of the walk loop).
+// Number of active lanes for which p holds, as a 32-bit wave-uniform SCALAR (readfirstlane of the already scalar popcount
+// folds away and leaves an i32 that the compiler knows is uniform: compares and loop exits on it stay on the scalar
+// unit; without it LLVM folds the truncation of the 64-bit popcount into the comparison that follows, and a 64-bit
+// compare of a scalar only exists on the vector ALU).
 BRT_DEV uint32_t wave_count(bool p) {
-    uint32_t n = (uint32_t)__popcll(__ballot(p));
-    asm volatile("" : "+s"(n));
-    return n;
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(p)));
 }
 
 // The correctly rounded sqrt likewise: hipcc emits v_sqrt_f32 (1 ulp) and picks the best of {s - 1 ulp, s, s + 1 ulp} by
@@ -202,7 +200,8 @@ struct ScenePtrs {
     // tree in breadth-first order), `pairs_far` the whole array in global memory
     const char* pairs_far;
     uint32_t near_bytes;
-    uint32_t near_base;      // LDS byte address of the tile
+    uint32_t near_base;      // LDS byte address of the tile (SCENE_LDS: of the pair records)
+    uint32_t sph_base;       // SCENE_LDS: LDS byte address of the spheres
     bool boxes_ordered;      // every child box finite with min <= max (decided at upload)
     const float4* spheres;
     const uint32_t* sphere_material;
@@ -449,6 +448,135 @@ BRT_DEV void walk_loop_wave(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, ui
     }
 }
 
+// ---- the walk loop of an LDS-resident simple tree, written against the MEASURED issue costs of gfx950 --------------------
+// tests/tools/issue_bench.hip (profiles/r03/issue_bench.txt), cycles of a SIMD per wave64 instruction with >= 2 waves resident:
+//   2   v_add/sub/mul/fma/fmac_f32, v_mov, v_and/xor, v_add_u32, v_lshrrev (the two VALU decoders co-execute these)
+//   4   v_min/max (f32, i32, u32), v_min3/max3/med3, every v_cmp, v_cndmask, v_cvt, v_mul_lo_u32, v_mul/mad_u32_u24,
+//       v_lshl_add, v_add3, v_bfe, v_and_or, v_div_scale/fmas/fixup        8   v_rcp, v_sqrt
+//   SALU: 4 on the scalar unit, hidden while that unit has spare time; s_cbranch not taken ~5, taken ~12 -- and those
+//   ADD to the SIMD's time (the issue stalls), they do not hide behind other waves' VALU work.
+// The compiler's version of the interior step (walk_interior_step under `if (interior)` in walk_loop_wave) spends, per
+// step and SIMD: 48 cycles on the 24 sub/mul, 32 on the 8 min/max, 8 on the two compares -- and 24 on six v_cndmask /
+// v_lshl_add that move the results into `cur` and the stack pointer, 14 on the record address, 8 on two compares for the
+// loop control and ~27 on four branch instructions (one taken): ~160.  Here the selects become v_mov / v_add_u32 under
+// EXEC masks built on the scalar unit (11 cycles instead of 24), the loop has ONE branch per iteration (the taken
+// back edge) and one compare: ~134.  Same per-lane steps in the same order as walk_loop_wave: pixels and counters do
+// not change.  (Only for SIMPLE trees, without COUNTERS, for waves without unsafe rays; everything else takes walk_loop_wave.)
+#ifndef BRT_WALK_FAST
+#define BRT_WALK_FAST 1
+#endif
+// Interior steps for every lane whose `cur` is a pair record, repeated while more than `thresh` lanes are at one.
+// spa: LDS byte address of the lane's stack top (16-bit entries, 128 bytes apart); base: LDS byte address of the pair
+// records; gofs: the ray's granule offsets {x, y, z} inside a record.  The caller guarantees count(interior) > thresh.
+BRT_DEV void walk_interior_run_lds(uint32_t& cur, uint32_t& spa, uint32_t base, uint32_t gofs_x, uint32_t gofs_y, uint32_t gofs_z,
+                                   f3 o, f3 inv, float below, uint32_t thresh) {
+    // The record lives in FIXED registers v[100:113] (x, y, z granules, descriptors): inline asm cannot name the single
+    // registers of a 128-bit operand, and the slab arithmetic works on them in place.
+    uint32_t t0, tx, ty, tz, pop, cnt;
+    uint64_t s_all, s_take, s_p2, s_any, s_both;
+    const uint32_t rec_bytes = PAIR_BYTES;
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n"                                // nothing of the compiler's in flight: the counted waits below are exact
+        "s_mov_b64 %[s_all], exec\n"
+        "v_cmp_lt_i32_e32 vcc, -1, %[cur]\n"                    // take: interior descriptors are >= 0
+        "1:\n"
+        "s_mov_b64 %[s_take], vcc\n"
+        "s_mov_b64 exec, vcc\n"
+        // record address and the five reads: {near L, near R, far L, far R} per axis, the two descriptors, the would-be pop
+        "v_mul_lo_u32 %[t0], %[cur], %[rec_bytes]\n"
+        "v_add_u32_e32 %[t0], %[base], %[t0]\n"
+        "v_add_u32_e32 %[tx], %[t0], %[gofs_x]\n"
+        "v_add_u32_e32 %[ty], %[t0], %[gofs_y]\n"
+        "v_add_u32_e32 %[tz], %[t0], %[gofs_z]\n"
+        "ds_read_b128 v[100:103], %[tx]\n"
+        "ds_read_b128 v[104:107], %[ty]\n"
+        "ds_read_b128 v[108:111], %[tz]\n"
+        "ds_read_b64 v[112:113], %[t0] offset:96\n"
+        "ds_read_i16 %[pop], %[spa]\n"
+        // (b - o) * (1/d), raytrace.wgsl:388-390
+        "s_waitcnt lgkmcnt(4)\n"
+        "v_sub_f32_e32 v100, v100, %[ox]\n v_sub_f32_e32 v101, v101, %[ox]\n v_sub_f32_e32 v102, v102, %[ox]\n v_sub_f32_e32 v103, v103, %[ox]\n"
+        "v_mul_f32_e32 v100, v100, %[ix]\n v_mul_f32_e32 v101, v101, %[ix]\n v_mul_f32_e32 v102, v102, %[ix]\n v_mul_f32_e32 v103, v103, %[ix]\n"
+        "s_waitcnt lgkmcnt(3)\n"
+        "v_sub_f32_e32 v104, v104, %[oy]\n v_sub_f32_e32 v105, v105, %[oy]\n v_sub_f32_e32 v106, v106, %[oy]\n v_sub_f32_e32 v107, v107, %[oy]\n"
+        "v_mul_f32_e32 v104, v104, %[iy]\n v_mul_f32_e32 v105, v105, %[iy]\n v_mul_f32_e32 v106, v106, %[iy]\n v_mul_f32_e32 v107, v107, %[iy]\n"
+        "s_waitcnt lgkmcnt(2)\n"
+        "v_sub_f32_e32 v108, v108, %[oz]\n v_sub_f32_e32 v109, v109, %[oz]\n v_sub_f32_e32 v110, v110, %[oz]\n v_sub_f32_e32 v111, v111, %[oz]\n"
+        "v_mul_f32_e32 v108, v108, %[iz]\n v_mul_f32_e32 v109, v109, %[iz]\n v_mul_f32_e32 v110, v110, %[iz]\n v_mul_f32_e32 v111, v111, %[iz]\n"
+        // t_near = max(near x, near y, near z, denorm_min), t_far = min(far x, far y, far z, below(closest)) per child
+        "v_max_f32_e32 v100, v100, v104\n"
+        "v_max_f32_e32 v101, v101, v105\n"
+        "v_min_f32_e32 v102, v102, v106\n"
+        "v_min_f32_e32 v103, v103, v107\n"
+        "v_max3_f32 v100, v100, v108, 1\n"
+        "v_max3_f32 v101, v101, v109, 1\n"
+        "v_min3_f32 v102, v102, v110, %[below]\n"
+        "v_min3_f32 v103, v103, v111, %[below]\n"
+        "s_waitcnt lgkmcnt(1)\n"                                // descriptors are here (the pop may still be on its way)
+        "ds_write_b16 %[spa], v112 offset:128\n"               // child L above the top: dead unless both are pushed
+        "v_cmp_le_f32_e32 vcc, v100, v102\n"                // p1: child L is pushed (raytrace.wgsl:331)
+        "v_cmp_le_f32_e64 %[s_p2], v101, v103\n"            // p2: child R is pushed (raytrace.wgsl:338)
+        "s_or_b64 %[s_any], vcc, %[s_p2]\n"
+        "s_and_b64 %[s_both], vcc, %[s_p2]\n"
+        "s_waitcnt lgkmcnt(1)\n"                                // the pop is here (the store may still be on its way)
+        "s_andn2_b64 exec, %[s_take], %[s_any]\n"               // no child pushed: pop
+        "v_mov_b32_e32 %[cur], %[pop]\n"
+        "v_add_u32_e32 %[spa], 0xffffff80, %[spa]\n"
+        "s_andn2_b64 exec, vcc, %[s_p2]\n"                      // only L
+        "v_mov_b32_e32 %[cur], v112\n"
+        "s_mov_b64 exec, %[s_p2]\n"                             // R (pushed last, popped first)
+        "v_mov_b32_e32 %[cur], v113\n"
+        "s_mov_b64 exec, %[s_both]\n"                           // both: L stays on the stack
+        "v_add_u32_e32 %[spa], 0x80, %[spa]\n"
+        "s_mov_b64 exec, %[s_all]\n"
+        "v_cmp_lt_i32_e32 vcc, -1, %[cur]\n"
+        "s_bcnt1_i32_b64 %[cnt], vcc\n"
+        "s_cmp_gt_u32 %[cnt], %[thresh]\n"
+        "s_cbranch_scc1 1b\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        : [cur] "+v"(cur), [spa] "+v"(spa), [t0] "=&v"(t0), [tx] "=&v"(tx),
+          [ty] "=&v"(ty), [tz] "=&v"(tz), [pop] "=&v"(pop), [cnt] "=&s"(cnt), [s_all] "=&s"(s_all), [s_take] "=&s"(s_take), [s_p2] "=&s"(s_p2),
+          [s_any] "=&s"(s_any), [s_both] "=&s"(s_both)
+        : [base] "s"(base), [gofs_x] "v"(gofs_x), [gofs_y] "v"(gofs_y), [gofs_z] "v"(gofs_z), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z),
+          [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [below] "v"(below), [thresh] "s"(thresh), [rec_bytes] "s"(rec_bytes)
+        : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113");
+}
+
+template <bool D16, bool SIMPLE_TREE, typename StackT>
+BRT_DEV void walk_loop_wave_lds(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, uint32_t ox, uint32_t oy, uint32_t oz,
+                                float& closest, uint32_t& closest_idx, uint32_t& cur, StackT*& sp, uint32_t& n,
+                                uint32_t exit_at, uint32_t vote, HitCounters& hc) {
+    using DS = Desc<D16>;
+    static_assert(D16 && SIMPLE_TREE && sizeof(StackT) == 2, "LDS-resident simple tree: 16-bit descriptors, no overflow rule, no leaf table");
+    typedef __attribute__((address_space(3))) StackT lds_stack;
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) vf4 lds_f4;
+    uint32_t spa = (uint32_t)(uintptr_t)(lds_stack*)sp;
+    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.near_base);
+    const uint32_t sph = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.sph_base);
+    float below = float_below(closest);
+    for (;;) {
+        const uint32_t n_walk = wave_count(cur != DS::DONE);
+        if (n_walk <= exit_at) break;
+        // Interior steps until at least `vote` of the walking lanes wait at a leaf, i.e. while more than n_walk - vote
+        // lanes are at interior nodes (or, when fewer than `vote` lanes walk, until none is).  walk_loop_wave counts the
+        // leaf lanes instead; the rules differ only when a lane ends its walk inside the run, and only in when the leaf
+        // step runs.
+        const uint32_t thresh = (uint32_t)__builtin_amdgcn_readfirstlane((int)((n_walk > vote ? n_walk : vote) - vote));
+        if (wave_count(DS::is_interior(cur)) > thresh) walk_interior_run_lds(cur, spa, base, ox, oy, oz, o, inv, below, thresh);
+        if (DS::is_leaf(cur)) {                            // raytrace.wgsl:325-326, 348-362: the leaf's sphere, then pop
+            const uint32_t first = cur & DS::INDEX_MASK;
+            const vf4 sv = *reinterpret_cast<lds_f4*>((uintptr_t)(sph + first * 16u));
+            const float4 s = make_float4(sv.x, sv.y, sv.z, sv.w);
+            cur = (uint32_t)(int32_t)*reinterpret_cast<lds_stack*>((uintptr_t)spa);
+            spa -= 128u;
+            sphere_test(o, d, a, s, first, closest, closest_idx);
+            below = float_below(closest);
+        }
+    }
+    sp = (StackT*)reinterpret_cast<lds_stack*>((uintptr_t)spa);
+}
+
 template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, int MODE, typename StackT>
 BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, f3 o, f3 d,
                       uint32_t exit_lanes, uint32_t leaf_vote, HitCounters& hc) {
@@ -477,13 +605,20 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, f3
         // The loop exists twice: without and with the min/max repair of the near/far reads
         // (walk_interior_step); the wave takes the second one only when one of its rays needs it.
         const uint32_t n_walking = wave_count(pending);
+        // (readfirstlane: both thresholds are wave-uniform by construction, but the compiler cannot see that through the
+        //  drain logic they come from, and a loop exit on a "divergent" value is compiled with exec-mask bookkeeping)
         uint32_t exit_at = n_walking >> 1;
         exit_at = exit_at < exit_lanes ? exit_at : exit_lanes;
-        const uint32_t vote = leaf_vote < 1u ? 1u : leaf_vote;
+        exit_at = (uint32_t)__builtin_amdgcn_readfirstlane((int)exit_at);
+        const uint32_t vote = (uint32_t)__builtin_amdgcn_readfirstlane((int)(leaf_vote < 1u ? 1u : leaf_vote));
         if (n_walking > exit_at) {
-            if (__ballot(unsafe) == 0ull)
-                walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, false, MODE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp,
-                                                                        n, exit_at, vote, hc);
+            if (__ballot(unsafe) == 0ull) {
+                if constexpr (BRT_WALK_FAST && MODE == SCENE_LDS && !COUNTERS && SIMPLE_TREE && D16)
+                    walk_loop_wave_lds<D16, SIMPLE_TREE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp, n, exit_at, vote, hc);
+                else
+                    walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, false, MODE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp,
+                                                                            n, exit_at, vote, hc);
+            }
             else
                 walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, true, MODE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp,
                                                                        n, exit_at, vote, hc);

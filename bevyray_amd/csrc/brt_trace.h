@@ -177,6 +177,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     sc.pairs_far = reinterpret_cast<const char*>(sv.pairs);
     sc.near_bytes = 0u;
     sc.near_base = 0u;
+    sc.sph_base = 0u;
     if (MODE == SCENE_LDS) {
         // carve: pair records | spheres | leaf_table | sphere_material | stacks
         const uint32_t pair_granules = (uint32_t)(pair_array_bytes(sv.n_pairs) / 16);
@@ -195,6 +196,8 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         for (uint32_t i = threadIdx.x; i < sv.n_models; i += blockDim.x) { l_sp[i] = g_sp[i]; l_sm[i] = sv.sphere_material[i]; }
         for (uint32_t i = threadIdx.x; i < sv.n_leaf_table; i += blockDim.x) l_lt[i] = g_lt[i];
         sc.pairs = reinterpret_cast<const char*>(l_pairs);
+        sc.near_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(l_pairs);   // LDS byte address (walk_loop_wave_lds)
+        sc.sph_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(l_sp);
         sc.spheres = l_sp; sc.sphere_material = l_sm; sc.leaf_table = l_lt;
     } else {
         sc.spheres = reinterpret_cast<const float4*>(sv.spheres);

@@ -20,7 +20,7 @@ def main():
         ref = None
         for rnd in range(2):          # two passes over the settings: the second is the one to read (clocks warm)
             for st in settings:
-                env = dict(kv.split("=") for kv in st.split()) if st else {}
+                env = dict(kv.split("=", 1) for kv in st.split()) if st else {}
                 old = {k: os.environ.get(k) for k in env}
                 os.environ.update(env)
                 try:
