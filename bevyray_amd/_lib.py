@@ -62,12 +62,16 @@ _PROTOTYPES = {
     "brt_last_error": (C.c_char_p, [_VP]),
     "brt_create": (_I32, [C.POINTER(_I32), _I32, C.POINTER(_VP)]),
     "brt_destroy": (_I32, [_VP]),
+    "brt_set_policy": (_I32, [_VP, _U32]),
+    "brt_set_tuning": (_I32, [_VP, C.c_char_p, _U32]),
+    "brt_get_tuning": (_I32, [_VP, C.c_char_p, C.POINTER(_U32), C.POINTER(_U32)]),
     "brt_upload_scene": (_I32, [_VP, _VP, _U32, _VP, _U32, _VP, _U32]),
     "brt_render": (_I32, [_VP, _VP, _VP, _U32, _U32, _U32, _VP, _VP, _VP, _U32, C.POINTER(BrtStats)]),
     "brt_host_alloc": (_I32, [_VP, C.c_uint64, C.POINTER(_VP)]),
     "brt_host_free": (_I32, [_VP, _VP]),
     "brt_render_part_device": (_I32, [_VP, _VP, _VP, _U32, _U32, _U32, _U32, _U32, _VP, _VP, _VP, _VP, _U32,
                                       C.POINTER(BrtStats)]),
+    "brt_render_device": (_I32, [_VP, _VP, _VP, _U32, _U32, _U32, _VP, _VP, _VP, _VP, _U32, C.POINTER(BrtStats)]),
     "brt_tile_rows": (_U32, [_U32, _U32]),
     "brt_deinterleave_device": (_I32, [_VP, _VP, _U32, _U32, _U32, _VP, _VP, _U32]),
     "brt_debug_eval": (_I32, [_VP, _U32, _VP, _VP, _U32]),
@@ -112,7 +116,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.brt_abi_version() != 2:
+    if lib.brt_abi_version() != 3:
         raise RuntimeError("libbevyray_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -41,6 +41,12 @@ struct DeviceCtx {
     size_t raster_rgba_cap = 0;
     float* d_raster_depth = nullptr;
     size_t raster_depth_cap = 0;
+    float* d_gather = nullptr;   // first device only: the tiles of all devices back to back (brt_render_device)
+    size_t gather_cap = 0;
+    hipEvent_t ev_copy = nullptr;   // this device's tile has arrived in the first device's gather buffer
+    hipEvent_t ev_asm = nullptr;    // first device: the frame of the last brt_render_device call is assembled (the gather buffer is free)
+    hipEvent_t ev_in = nullptr;     // first device: the caller's stream at the start of a brt_render_device call
+    hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr;   // first device: around waiting for the tiles + de-interleave
     float* h_stage = nullptr;  // pinned
     size_t stage_cap = 0;
     // longest-first dispatch (see plan_tile_order): this frame's per-tile ray counts and the
@@ -56,7 +62,7 @@ struct DeviceCtx {
     size_t order_scratch_cap = 0;
     bool order_on_device = false;                        // d_tile_order / d_order_meta were written by brt_order.hip
     uint64_t view_rays = 0;                              // rays of the last completed frame of the view `view_key` (0: unknown)
-    uint32_t view_key[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t view_key[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // order key + sample_count, bounce_count
     bool order_valid = false;
     uint32_t order_age = 0;                       // frames since the costs were last measured
     uint32_t order_key[6] = {0, 0, 0, 0, 0, 0};   // width, height, part, n_parts, scene epoch, n_tiles
@@ -69,16 +75,43 @@ struct DeviceCtx {
     size_t bvh_models_cap = 0;
 };
 
+
+// ---- tuning knobs -----------------------------------------------------------------------------------------------------
+// Scheduling / launch-shape knobs of the trace path.  None of them changes a pixel (every one has a test that says so).
+// They live in the context: brt_set_tuning(ctx, name, value) sets one; brt_create reads the environment variables of the
+// same names ONCE, and only when BRT_ENABLE_TUNING=1 is set -- nothing reads the environment per frame, and the one
+// switch that does change pixels (the reading of `||` in raytrace.wgsl:269) is not a knob at all: brt_set_policy.
+enum Knob : int {
+    K_BOTTOM_UP, K_REFILL_MIN, K_WALK_EXIT, K_LEAF_VOTE, K_DRAIN_DONATE, K_POOL_ADOPT, K_WGQ_BATCH, K_LPT_LANE_PERMILLE, K_TUNABLE,
+    K_FORCE_GLOBAL_SCENE, K_FORCE_LDS_TOP, K_BLOCK_THREADS, K_WG_PER_CU, K_POOL_CAP, K_LPT, K_LPT_SORT, K_LPT_SKY_SLACK, K_CRIT,
+    K_ORDER_ON_HOST, K_NO_LEAN, K_PREPASS_SPP, K_NO_DIRTY_TRACKING, K_CPU_BVH, K_PLOC_ONE_BLOCK_MAX, K_BVH_QUALITY, K_COUNT
+};
+struct KnobDef { const char* name; uint32_t dflt; };
+constexpr KnobDef kKnobs[K_COUNT] = {
+    {"BRT_BOTTOM_UP", 0}, {"BRT_REFILL_MIN", kRefillMin}, {"BRT_WALK_EXIT", kWalkExitLanes}, {"BRT_LEAF_VOTE", kLeafVote},
+    {"BRT_DRAIN_DONATE", kDrainDonate}, {"BRT_POOL_ADOPT", kPoolAdopt}, {"BRT_WGQ_BATCH", 0}, {"BRT_LPT_LANE_PERMILLE", 0},
+    {"BRT_TUNABLE", 0}, {"BRT_FORCE_GLOBAL_SCENE", 0}, {"BRT_FORCE_LDS_TOP", 0}, {"BRT_BLOCK_THREADS", 0}, {"BRT_WG_PER_CU", 0},
+    {"BRT_POOL_CAP", 384}, {"BRT_LPT", 1}, {"BRT_LPT_SORT", 1}, {"BRT_LPT_SKY_SLACK", 20}, {"BRT_CRIT", 1}, {"BRT_ORDER_ON_HOST", 0},
+    {"BRT_NO_LEAN", 0}, {"BRT_PREPASS_SPP", 2}, {"BRT_NO_DIRTY_TRACKING", 0}, {"BRT_CPU_BVH", 0},
+    {"BRT_PLOC_ONE_BLOCK_MAX", kPlocOneBlockMax}, {"BRT_BVH_QUALITY", 1}};
+struct Knobs {
+    uint32_t v[K_COUNT];
+    Knobs() { for (int i = 0; i < K_COUNT; i++) v[i] = kKnobs[i].dflt; }
+    uint32_t operator[](Knob k) const { return v[k]; }
+};
+
 }  // namespace
 
 struct brt_ctx {
     std::vector<DeviceCtx> devs;
     EncodedScene enc;
     bool has_scene = false;
-    uint32_t scene_epoch = 0;   // bumped by every upload: invalidates the tile-cost history
+    uint32_t scene_epoch = 0;   // bumped by every upload
     std::vector<std::pair<char*, size_t>> pinned;   // brt_host_alloc blocks
     // bytes of the last successful upload (dirty tracking: an unchanged scene is not re-sent)
     std::vector<char> last_models, last_materials, last_bvh;
+    Knobs knobs;                // tuning knobs (brt_set_tuning; environment once at brt_create under BRT_ENABLE_TUNING=1)
+    uint32_t policy_flags = 0;  // brt_set_policy
     std::string last_error;
 };
 
@@ -165,27 +198,27 @@ int32_t make_frame_params(brt_ctx* ctx, const void* camera80, const void* window
     fp.local_strips = (strips + n_parts - 1u) / n_parts;
     fp.queue_size = fp.local_strips * fp.tiles_x * 64u;
     fp.queue_lane = 0u;              // whole tiles for idle waves; attach_tile_order may give the front of the order to the lane queue
-    fp.bottom_up = env_u32("BRT_BOTTOM_UP", 0);
-    fp.refill_min = env_u32("BRT_REFILL_MIN", 1);
+    fp.bottom_up = ctx->knobs[K_BOTTOM_UP];
+    fp.refill_min = ctx->knobs[K_REFILL_MIN];
     if (fp.refill_min < 1u) fp.refill_min = 1u;
     if (fp.refill_min > 64u) fp.refill_min = 64u;
-    fp.walk_exit_lanes = env_u32("BRT_WALK_EXIT", 12);
+    fp.walk_exit_lanes = ctx->knobs[K_WALK_EXIT];
     if (fp.walk_exit_lanes > 63u) fp.walk_exit_lanes = 63u;
-    fp.leaf_vote = env_u32("BRT_LEAF_VOTE", 12);
+    fp.leaf_vote = ctx->knobs[K_LEAF_VOTE];
     if (fp.leaf_vote > 64u) fp.leaf_vote = 64u;
-    fp.drain_donate = env_u32("BRT_DRAIN_DONATE", 40);
+    fp.drain_donate = ctx->knobs[K_DRAIN_DONATE];
     if (fp.drain_donate > 56u) fp.drain_donate = 56u;
     fp.pool_cap = 0;               // set by launch_part from the launch plan
-    fp.pool_adopt = env_u32("BRT_POOL_ADOPT", 56);
+    fp.pool_adopt = ctx->knobs[K_POOL_ADOPT];
     if (fp.pool_adopt > 63u) fp.pool_adopt = 63u;
     fp.crit_begin = fp.crit_end = 0;   // set by attach_tile_order
-    fp.wgq_batch = env_u32("BRT_WGQ_BATCH", 0) & ~63u;
+    fp.wgq_batch = ctx->knobs[K_WGQ_BATCH] & ~63u;
     if (fp.wgq_batch > 512u) fp.wgq_batch = 512u;
-    fp.policy_flags = env_u32("BRT_POLICY_OR_SHORT_CIRCUIT", 0) ? 1u : 0u;
+    fp.policy_flags = ctx->policy_flags & BRT_POLICY_OR_SHORT_CIRCUIT;
     // any knob off its default (or the lane queue asked for) -> the TUNABLE instantiation of the kernel
     fp.tunable = (fp.policy_flags != 0u || fp.bottom_up != 0u || fp.refill_min != kRefillMin || fp.walk_exit_lanes != kWalkExitLanes ||
                   fp.leaf_vote != kLeafVote || fp.drain_donate != kDrainDonate || fp.pool_adopt != kPoolAdopt ||
-                  fp.wgq_batch != 0u || env_u32("BRT_LPT_LANE_PERMILLE", 0) != 0u || env_u32("BRT_TUNABLE", 0) != 0u)
+                  fp.wgq_batch != 0u || ctx->knobs[K_LPT_LANE_PERMILLE] != 0u || ctx->knobs[K_TUNABLE] != 0u)
                      ? 1u : 0u;
     *out = fp;
     return BRT_OK;
@@ -207,19 +240,19 @@ struct LaunchPlan {
 //                  pool holds the top of the tree (pair records are in breadth-first order), the rest comes from L2;
 //   SCENE_GLOBAL   larger scenes: 256-thread workgroups, as many per CU as their stacks allow.
 // The 32-byte materials always stay in global memory (read once per hit; measured: no difference).
-// BRT_FORCE_GLOBAL_SCENE / BRT_FORCE_LDS_TOP=<records> / BRT_BLOCK_THREADS / BRT_WG_PER_CU override (tests, tuning).
-LaunchPlan plan_launch(const DeviceCtx& dc, const FrameParams& fp) {
+// The knobs BRT_FORCE_GLOBAL_SCENE / BRT_FORCE_LDS_TOP=<records> / BRT_BLOCK_THREADS / BRT_WG_PER_CU override (tests, tuning).
+LaunchPlan plan_launch(const Knobs& kn, const DeviceCtx& dc, const FrameParams& fp) {
     LaunchPlan lp{};
-    const bool force_global = env_u32("BRT_FORCE_GLOBAL_SCENE", 0) != 0;
-    const uint32_t force_top = env_u32("BRT_FORCE_LDS_TOP", 0);
-    const uint32_t block_env = env_u32("BRT_BLOCK_THREADS", 0);
-    const uint32_t wg_env = env_u32("BRT_WG_PER_CU", 0);
+    const bool force_global = kn[K_FORCE_GLOBAL_SCENE] != 0;
+    const uint32_t force_top = kn[K_FORCE_LDS_TOP];
+    const uint32_t block_env = kn[K_BLOCK_THREADS];
+    const uint32_t wg_env = kn[K_WG_PER_CU];
     const uint32_t max_waves_cu = 32;
     lp.scene_mode = SCENE_GLOBAL;
     // drain pool: every wave but one may hand over up to drain_donate paths, but the takers empty the pool
     // while the donors fill it: 384 records (36 KB) are enough in practice, and a donation that does not
     // fit is simply retried a round later
-    const uint32_t pool_max = env_u32("BRT_POOL_CAP", 384);
+    const uint32_t pool_max = kn[K_POOL_CAP];
     auto pool_of = [&](uint32_t block) {
         const uint32_t want = fp.drain_donate * (block / 64u - 1u);
         return want < pool_max ? want : pool_max;
@@ -297,12 +330,20 @@ bool is_pinned(const brt_ctx* ctx, const void* p, size_t bytes) {
 // view) and the next frames use the order built from that.  Pixels never change, only the queue order does.
 // BRT_LPT=0 disables (raster order); BRT_LPT_SORT, BRT_LPT_LANE_PERMILLE, BRT_LPT_SKY_SLACK, BRT_CRIT: see
 // update_tile_order.
-constexpr uint32_t kLptRefresh = 16;
-bool lpt_enabled() { return env_u32("BRT_LPT", 1) != 0; }
+constexpr uint32_t kLptRefresh = 16, kLptAfterUpload = 4;
+bool lpt_enabled(const brt_ctx* ctx) { return ctx->knobs[K_LPT] != 0; }
 
-void order_key_of(const brt_ctx* ctx, const FrameParams& fp, uint32_t key[6]) {
+// The dispatch order only depends on which tiles hold long pixels: it survives a scene upload (an animated scene
+// re-uploads every frame, extract.rs:299-336, and moves little between two frames) and is measured again soon after one
+// (brt_upload_scene ages it); it never affects pixels.  The ray count of a view (LEAN = 2: "no pixel chain can be
+// critical") additionally depends on sample and bounce counts; a wrong guess after a scene change only costs speed.
+void order_key_of(const brt_ctx*, const FrameParams& fp, uint32_t key[6]) {
     key[0] = fp.width; key[1] = fp.height; key[2] = fp.part; key[3] = fp.n_parts;
-    key[4] = ctx->scene_epoch; key[5] = fp.local_strips * fp.tiles_x;
+    key[4] = 0u; key[5] = fp.local_strips * fp.tiles_x;
+}
+void view_key_of(const brt_ctx* ctx, const FrameParams& fp, uint32_t key[8]) {
+    order_key_of(ctx, fp, key);
+    key[6] = fp.sample_count; key[7] = fp.bounce_count;
 }
 
 // before the launch: attach the order table if the history matches this view, and -- when the
@@ -310,7 +351,7 @@ void order_key_of(const brt_ctx* ctx, const FrameParams& fp, uint32_t key[6]) {
 int32_t attach_tile_order(brt_ctx* ctx, DeviceCtx& dc, FrameParams& fp, hipStream_t stream, bool may_measure) {
     fp.tile_order = nullptr;
     fp.tile_cost = nullptr;
-    if (!lpt_enabled() || fp.level == 0u) return BRT_OK;
+    if (!lpt_enabled(ctx) || fp.level == 0u) return BRT_OK;
     const uint32_t n_tiles = fp.local_strips * fp.tiles_x;
     uint32_t key[6];
     order_key_of(ctx, fp, key);
@@ -340,13 +381,13 @@ int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hi
     TileOrderParams tp{};
     tp.sample_count = fp.sample_count;
     tp.grid_lanes = (uint64_t)dc.num_cus * BRT_BLOCK;
-    tp.sorted = env_u32("BRT_LPT_SORT", 1);
-    tp.sky_slack_permille = env_u32("BRT_LPT_SKY_SLACK", 20);
-    tp.lane_permille = env_u32("BRT_LPT_LANE_PERMILLE", 0);
-    tp.critical = env_u32("BRT_CRIT", 1);
+    tp.sorted = ctx->knobs[K_LPT_SORT];
+    tp.sky_slack_permille = ctx->knobs[K_LPT_SKY_SLACK];
+    tp.lane_permille = ctx->knobs[K_LPT_LANE_PERMILLE];
+    tp.critical = ctx->knobs[K_CRIT];
     int32_t rc = ensure(ctx, &dc.d_tile_order, &dc.tile_order_cap, (size_t)n_tiles * 4);
     if (rc != BRT_OK) return rc;
-    const bool on_device = tp.sorted == 1u && tp.critical == 1u && tp.lane_permille == 0u && env_u32("BRT_ORDER_ON_HOST", 0) == 0u;
+    const bool on_device = tp.sorted == 1u && tp.critical == 1u && tp.lane_permille == 0u && ctx->knobs[K_ORDER_ON_HOST] == 0u;
     if (on_device) {
         if (!dc.d_order_meta) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dc.d_order_meta), 256));
         rc = ensure(ctx, &dc.d_order_scratch, &dc.order_scratch_cap, order_scratch_bytes(n_tiles));
@@ -405,19 +446,19 @@ int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const fl
             lp.block = 256;
             lp.grid = (fp.queue_size + 255u) / 256u;
         } else {
-            lp = plan_launch(dc, fp);
+            lp = plan_launch(ctx->knobs, dc, fp);
             // LEAN instantiation (brt_trace.h): Pure level, not a measuring frame, and no critical tile possible -- a tile is
             // critical only if its longest pixel needs at least half a lane's share of the frame's rays (build_tile_order),
             // and no pixel needs more than sample_count * (bounce_count + 1); the frame's rays are those of the last
             // completed frame of this view.  (A wrong guess would only cost speed: critical tiles are a scheduling hint.)
             {
-                uint32_t key[6];
-                order_key_of(ctx, fp, key);
+                uint32_t key[8];
+                view_key_of(ctx, fp, key);
                 const bool known = dc.view_rays != 0 && std::memcmp(key, dc.view_key, sizeof key) == 0;
                 const uint64_t per_lane = known ? dc.view_rays / ((uint64_t)dc.num_cus * BRT_BLOCK) : 0;
                 const uint64_t longest_bound = (uint64_t)fp.sample_count * ((uint64_t)fp.bounce_count + 1u);
                 const bool lean1 = !tl.frame.tunable && fp.level == 3u && fp.tile_cost == nullptr && !tl.counters_on &&
-                                   env_u32("BRT_NO_LEAN", 0) == 0u;
+                                   ctx->knobs[K_NO_LEAN] == 0u;
                 tl.lean = !lean1 ? 0 : ((known && longest_bound < per_lane / 2) ? 2 : 1);
             }
             tl.scene_mode = lp.scene_mode;
@@ -456,8 +497,8 @@ int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const fl
 int32_t prepass_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const float* d_raster_rgba,
                       const float* d_raster_depth, float* d_out_tile, hipStream_t stream, uint32_t flags, bool* ran) {
     *ran = false;
-    const uint32_t k = env_u32("BRT_PREPASS_SPP", 2);
-    if (k == 0u || !lpt_enabled() || fp.level == 0u || fp.sample_count < 16u * k || (flags & BRT_FLAG_KERNEL_SIMPLE)) return BRT_OK;
+    const uint32_t k = ctx->knobs[K_PREPASS_SPP];
+    if (k == 0u || !lpt_enabled(ctx) || fp.level == 0u || fp.sample_count < 16u * k || (flags & BRT_FLAG_KERNEL_SIMPLE)) return BRT_OK;
     uint32_t key[6];
     order_key_of(ctx, fp, key);
     if (dc.order_valid && std::memcmp(key, dc.order_key, sizeof key) == 0) return BRT_OK;   // history matches: nothing to do
@@ -523,6 +564,9 @@ void free_device(DeviceCtx& dc) {
     if (dc.d_scene) (void)hipFree(dc.d_scene);
     if (dc.d_ctrl) (void)hipFree(dc.d_ctrl);
     if (dc.d_tile) (void)hipFree(dc.d_tile);
+    if (dc.d_gather) (void)hipFree(dc.d_gather);
+    for (hipEvent_t e : {dc.ev_copy, dc.ev_asm, dc.ev_in, dc.ev_g0, dc.ev_g1})
+        if (e) (void)hipEventDestroy(e);
     if (dc.d_raster_rgba) (void)hipFree(dc.d_raster_rgba);
     if (dc.d_raster_depth) (void)hipFree(dc.d_raster_depth);
     if (dc.h_stage) (void)hipHostFree(dc.h_stage);
@@ -550,7 +594,7 @@ int32_t build_bvh_on_device(brt_ctx* ctx, const Model* models, uint32_t n, std::
     if (n > kMaxGpuBuildModels) return ctx_fail(ctx, BRT_ERR_UNSUPPORTED, "GPU BVH build supports up to 2^24 spheres");
     DeviceCtx& dc = ctx->devs[0];
     HIP_TRY(ctx, hipSetDevice(dc.device));
-    int32_t rc = ensure(ctx, &dc.d_bvh_scratch, &dc.bvh_scratch_cap, ploc_scratch_bytes(n, nullptr));
+    int32_t rc = ensure(ctx, &dc.d_bvh_scratch, &dc.bvh_scratch_cap, ploc_scratch_bytes(n, nullptr, ctx->knobs[K_PLOC_ONE_BLOCK_MAX]));
     if (rc != BRT_OK) return rc;
     rc = ensure(ctx, &dc.d_bvh_models, &dc.bvh_models_cap, (size_t)n * sizeof(Model));
     if (rc != BRT_OK) return rc;
@@ -558,7 +602,7 @@ int32_t build_bvh_on_device(brt_ctx* ctx, const Model* models, uint32_t n, std::
     BVHNode* d_out = nullptr;
     uint32_t* d_info = nullptr;
     HIP_TRY(ctx, hipEventRecord(dc.ev0, dc.stream));
-    HIP_TRY(ctx, launch_build_ploc(reinterpret_cast<const Model*>(dc.d_bvh_models), n, dc.d_bvh_scratch, &d_out, &d_info, dc.stream));
+    HIP_TRY(ctx, launch_build_ploc(reinterpret_cast<const Model*>(dc.d_bvh_models), n, dc.d_bvh_scratch, &d_out, &d_info, ctx->knobs[K_PLOC_ONE_BLOCK_MAX], dc.stream));
     HIP_TRY(ctx, hipEventRecord(dc.ev1, dc.stream));
     out->resize(2 * (size_t)n - 1);
     HIP_TRY(ctx, hipMemcpyAsync(out->data(), d_out, out->size() * sizeof(BVHNode), hipMemcpyDeviceToHost, dc.stream));
@@ -616,6 +660,12 @@ int32_t brt_create(const int32_t* device_ids, int32_t n_devices, brt_ctx** out_c
             HIP_TRY(ctx, hipEventCreate(&dc.ev_p0));
             HIP_TRY(ctx, hipEventCreate(&dc.ev_p1));
             HIP_TRY(ctx, hipEventCreateWithFlags(&dc.ev_last, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&dc.ev_copy, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&dc.ev_asm, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&dc.ev_in, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreate(&dc.ev_g0));
+            HIP_TRY(ctx, hipEventCreate(&dc.ev_g1));
+            HIP_TRY(ctx, hipEventRecord(dc.ev_asm, dc.stream));
             HIP_TRY(ctx, hipEventRecord(dc.ev_last, dc.stream));
             HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dc.d_ctrl), 512));
             return BRT_OK;
@@ -628,8 +678,42 @@ int32_t brt_create(const int32_t* device_ids, int32_t n_devices, brt_ctx** out_c
             return rc;
         }
     }
+    // tuning knobs from the environment: once, here, and only on request (BRT_ENABLE_TUNING=1)
+    if (env_u32("BRT_ENABLE_TUNING", 0) != 0u)
+        for (int k = 0; k < K_COUNT; k++) ctx->knobs.v[k] = env_u32(kKnobs[k].name, kKnobs[k].dflt);
     *out_ctx = ctx;
     return BRT_OK;
+}
+
+int32_t brt_set_policy(brt_ctx* ctx, uint32_t flags) {
+    if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (flags & ~(uint32_t)BRT_POLICY_OR_SHORT_CIRCUIT) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "unknown policy flag");
+    ctx->policy_flags = flags;
+    return BRT_OK;
+}
+
+int32_t brt_set_tuning(brt_ctx* ctx, const char* name, uint32_t value) {
+    if (!ctx || !name) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
+    for (int k = 0; k < K_COUNT; k++)
+        if (std::strcmp(name, kKnobs[k].name) == 0) {
+            ctx->knobs.v[k] = value;
+            // a knob may change how the dispatch order is built or used: forget the history of every view (the next frame of
+            // a view is a "first frame" again: pre-pass, measuring frame)
+            for (auto& dc : ctx->devs) { dc.order_valid = false; dc.view_rays = 0; }
+            return BRT_OK;
+        }
+    return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, std::string("unknown tuning knob ") + name);
+}
+
+int32_t brt_get_tuning(const brt_ctx* ctx, const char* name, uint32_t* out_value, uint32_t* out_default) {
+    if (!ctx || !name) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
+    for (int k = 0; k < K_COUNT; k++)
+        if (std::strcmp(name, kKnobs[k].name) == 0) {
+            if (out_value) *out_value = ctx->knobs.v[k];
+            if (out_default) *out_default = kKnobs[k].dflt;
+            return BRT_OK;
+        }
+    return fail(BRT_ERR_INVALID_ARGUMENT, std::string("unknown tuning knob ") + name);
 }
 
 int32_t brt_host_alloc(brt_ctx* ctx, uint64_t bytes, void** out_ptr) {
@@ -673,7 +757,7 @@ int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, co
     auto same = [](const std::vector<char>& v, const void* p, size_t n) {
         return v.size() == n && (n == 0 || (p && std::memcmp(v.data(), p, n) == 0));
     };
-    if (ctx->has_scene && env_u32("BRT_NO_DIRTY_TRACKING", 0) == 0 && same(ctx->last_models, models, mb) &&
+    if (ctx->has_scene && ctx->knobs[K_NO_DIRTY_TRACKING] == 0 && same(ctx->last_models, models, mb) &&
         same(ctx->last_materials, materials, tb) && same(ctx->last_bvh, bvh_nodes, bb))
         return BRT_OK;
     ctx->has_scene = false;
@@ -681,7 +765,7 @@ int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, co
     const BVHNode* nodes = static_cast<const BVHNode*>(bvh_nodes);
     if (n_models > 0 && models && (!bvh_nodes || n_nodes == 0)) {
         // no BVH from the caller: build it here -- on the GPU (same bytes as the CPU builder)
-        int32_t rc = (n_models <= kMaxGpuBuildModels && env_u32("BRT_CPU_BVH", 0) == 0)
+        int32_t rc = (n_models <= kMaxGpuBuildModels && ctx->knobs[K_CPU_BVH] == 0)
                          ? build_bvh_on_device(ctx, static_cast<const Model*>(models), n_models, &built, nullptr)
                          : build_bvh_ploc(static_cast<const Model*>(models), n_models, &built);
         if (rc != BRT_OK) return rc;
@@ -736,6 +820,10 @@ int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, co
     else ctx->last_bvh.clear();
     ctx->has_scene = true;
     ctx->scene_epoch++;
+    // the dispatch order of the views rendered so far stays in use as a hint, but is measured again within kLptAfterUpload
+    // frames (a scene that changes every frame: every kLptAfterUpload-th frame is a measuring frame)
+    for (auto& dc : ctx->devs)
+        if (dc.order_valid && dc.order_age + kLptAfterUpload < kLptRefresh) dc.order_age = kLptRefresh - kLptAfterUpload;
     return BRT_OK;
 }
 
@@ -745,13 +833,29 @@ uint32_t brt_tile_rows(uint32_t height, uint32_t n_parts) {
     return ((strips + n_parts - 1u) / n_parts) * BRT_STRIP_ROWS;
 }
 
-int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level, uint32_t width,
+}  // extern "C"
+
+namespace {
+
+// After a failure inside brt_render some devices may still be tracing, or copying into the caller's
+// (possibly page-locked) frame: wait for every stream of the context before the error is returned, so that
+// nothing of this call is in flight when the caller gets its buffers back.  The first error message stays.
+void drain_all_streams(brt_ctx* ctx) {
+    const std::string keep = ctx->last_error;
+    for (auto& dc : ctx->devs) {
+        if (!dc.stream) continue;
+        if (hipSetDevice(dc.device) != hipSuccess) continue;
+        (void)hipStreamSynchronize(dc.stream);
+    }
+    (void)hipGetLastError();
+    ctx->last_error = keep;
+    g_last_error = keep;
+}
+
+int32_t render_part_device(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level, uint32_t width,
                                uint32_t height, uint32_t part, uint32_t n_parts, const float* d_raster_rgba,
                                const float* d_raster_depth, float* d_out_tile, void* hip_stream, uint32_t flags,
                                brt_stats* stats) {
-    if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
-    if (!d_out_tile) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "d_out_tile is null");
-    if (!ctx->has_scene && level != 0u) return ctx_fail(ctx, BRT_ERR_NO_SCENE, "brt_upload_scene has not succeeded yet");
     const auto t0 = std::chrono::steady_clock::now();
     FrameParams fp;
     int32_t rc = make_frame_params(ctx, camera80, window16, level, width, height, part, n_parts, &fp);
@@ -779,15 +883,17 @@ int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* w
         stats->threads_per_workgroup = lp.block;
     }
     if (own_stream) {
+        // the order of the next frames is built on the same stream behind the frame, BEFORE the one synchronisation of this
+        // call (read_counters): nothing of this call is in flight when it returns
+        rc = update_tile_order(ctx, dc, fp, stream);
+        if (rc != BRT_OK) return rc;
         brt_stats tmp{};
         rc = read_counters(ctx, dc, stream, &tmp);  // synchronises
         if (rc != BRT_OK) return rc;
         dc.view_rays = tmp.rays;
-        order_key_of(ctx, fp, dc.view_key);
+        view_key_of(ctx, fp, dc.view_key);
         float ms = 0.0f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, dc.ev0, dc.ev1));
-        rc = update_tile_order(ctx, dc, fp, stream);
-        if (rc != BRT_OK) return rc;
         if (stats) {
             stats->rays = tmp.rays; stats->node_pops = tmp.node_pops; stats->interior_visits = tmp.interior_visits;
             stats->sphere_tests = tmp.sphere_tests; stats->hits = tmp.hits;
@@ -798,25 +904,6 @@ int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* w
         }
     }
     return BRT_OK;
-}
-
-}  // extern "C"
-
-namespace {
-
-// After a failure inside brt_render some devices may still be tracing, or copying into the caller's
-// (possibly page-locked) frame: wait for every stream of the context before the error is returned, so that
-// nothing of this call is in flight when the caller gets its buffers back.  The first error message stays.
-void drain_all_streams(brt_ctx* ctx) {
-    const std::string keep = ctx->last_error;
-    for (auto& dc : ctx->devs) {
-        if (!dc.stream) continue;
-        if (hipSetDevice(dc.device) != hipSuccess) continue;
-        (void)hipStreamSynchronize(dc.stream);
-    }
-    (void)hipGetLastError();
-    ctx->last_error = keep;
-    g_last_error = keep;
 }
 
 int32_t render_frame(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level, uint32_t width, uint32_t height,
@@ -894,10 +981,12 @@ int32_t render_frame(brt_ctx* ctx, const void* camera80, const void* window16, u
         DeviceCtx& dc = ctx->devs[p];
         HIP_TRY(ctx, hipSetDevice(dc.device));
         const uint64_t rays_before = st.rays;
-        int32_t rc = read_counters(ctx, dc, dc.stream, &st);  // synchronises the stream
+        int32_t rc = update_tile_order(ctx, dc, fps[p], dc.stream);   // behind the frame, ahead of the synchronisation
+        if (rc != BRT_OK) return rc;
+        rc = read_counters(ctx, dc, dc.stream, &st);  // synchronises the stream
         if (rc != BRT_OK) return rc;
         dc.view_rays = st.rays - rays_before;
-        order_key_of(ctx, fps[p], dc.view_key);
+        view_key_of(ctx, fps[p], dc.view_key);
         float ms = 0.0f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, dc.ev0, dc.ev1));
         if (ms > kernel_ms) kernel_ms = ms;
@@ -905,8 +994,6 @@ int32_t render_frame(brt_ctx* ctx, const void* camera80, const void* window16, u
         rc = prepass_elapsed(ctx, dc, prepass_ran[p] != 0, &pp_ms);
         if (rc != BRT_OK) return rc;
         if (pp_ms > prepass_ms) prepass_ms = pp_ms;
-        rc = update_tile_order(ctx, dc, fps[p], dc.stream);
-        if (rc != BRT_OK) return rc;
         const auto g0 = std::chrono::steady_clock::now();
         const uint32_t strips = direct ? 0u : (height + BRT_STRIP_ROWS - 1u) / BRT_STRIP_ROWS;
         for (uint32_t s = p, k = 0; s < strips; s += n_parts, k++) {
@@ -932,6 +1019,125 @@ int32_t render_frame(brt_ctx* ctx, const void* camera80, const void* window16, u
     return BRT_OK;
 }
 
+
+// The frame of an N-device context assembled on its FIRST device: every device traces its strips, the tiles of the
+// others travel to the first device's gather buffer by peer copy (xGMI between the GPUs of a node; a plain device copy
+// when an ordinal repeats), and k_deinterleave writes the frame -- what bevyray_amd/parallel.py does with one process per
+// GPU and an RCCL gather, for a single-process host (the Rust node).
+int32_t render_frame_device(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level, uint32_t width, uint32_t height,
+                            const float* d_raster_rgba, const float* d_raster_depth, float* d_frame, void* hip_stream, uint32_t flags,
+                            brt_stats* stats) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint32_t n_parts = (uint32_t)ctx->devs.size();
+    std::vector<FrameParams> fps(n_parts);
+    for (uint32_t p = 0; p < n_parts; p++) {
+        int32_t rc = make_frame_params(ctx, camera80, window16, level, width, height, p, n_parts, &fps[p]);
+        if (rc != BRT_OK) return rc;
+    }
+    const uint32_t tile_rows = brt_tile_rows(height, n_parts);
+    const size_t tile_floats = (size_t)tile_rows * width * 4, tile_bytes = tile_floats * 4;
+    const size_t frame_px = (size_t)width * height;
+    DeviceCtx& d0 = ctx->devs[0];
+    HIP_TRY(ctx, hipSetDevice(d0.device));
+    const bool own_stream = (hip_stream == nullptr) && !(flags & BRT_FLAG_CALLER_STREAM);
+    hipStream_t stream0 = own_stream ? d0.stream : static_cast<hipStream_t>(hip_stream);
+    int32_t rc = ensure(ctx, &d0.d_gather, &d0.gather_cap, tile_bytes * n_parts);
+    if (rc != BRT_OK) return rc;
+    // the other devices start behind whatever the caller enqueued before this call (its raster inputs)
+    HIP_TRY(ctx, hipEventRecord(d0.ev_in, stream0));
+    LaunchPlan lp{};
+    std::vector<char> prepass_ran(n_parts, 0);
+    for (uint32_t p = 0; p < n_parts; p++) {
+        DeviceCtx& dc = ctx->devs[p];
+        HIP_TRY(ctx, hipSetDevice(dc.device));
+        hipStream_t sp = p == 0 ? stream0 : dc.stream;
+        float* out = d0.d_gather + (size_t)p * tile_floats;
+        const float* d_rgba = d_raster_rgba;
+        const float* d_depth = d_raster_depth;
+        if (p != 0) {
+            rc = ensure(ctx, &dc.d_tile, &dc.tile_cap, tile_bytes);
+            if (rc != BRT_OK) return rc;
+            out = dc.d_tile;
+            HIP_TRY(ctx, hipStreamWaitEvent(sp, d0.ev_in, 0));
+            HIP_TRY(ctx, hipStreamWaitEvent(sp, d0.ev_asm, 0));     // the gather buffer is free again (previous frame assembled)
+            if (d_raster_rgba && level != 0u) {
+                rc = ensure(ctx, &dc.d_raster_rgba, &dc.raster_rgba_cap, frame_px * 16);
+                if (rc != BRT_OK) return rc;
+                HIP_TRY(ctx, hipMemcpyPeerAsync(dc.d_raster_rgba, dc.device, d_raster_rgba, d0.device, frame_px * 16, sp));
+                d_rgba = dc.d_raster_rgba;
+            }
+            if (d_raster_depth && level != 0u) {
+                rc = ensure(ctx, &dc.d_raster_depth, &dc.raster_depth_cap, frame_px * 4);
+                if (rc != BRT_OK) return rc;
+                HIP_TRY(ctx, hipMemcpyPeerAsync(dc.d_raster_depth, dc.device, d_raster_depth, d0.device, frame_px * 4, sp));
+                d_depth = dc.d_raster_depth;
+            }
+        } else {
+            HIP_TRY(ctx, hipStreamWaitEvent(sp, d0.ev_asm, 0));
+        }
+        if (own_stream) {
+            bool ran = false;
+            rc = prepass_order(ctx, dc, fps[p], d_rgba, d_depth, out, sp, flags, &ran);
+            if (rc != BRT_OK) return rc;
+            prepass_ran[p] = ran;
+        }
+        rc = attach_tile_order(ctx, dc, fps[p], sp, own_stream);
+        if (rc != BRT_OK) return rc;
+        rc = launch_part(ctx, dc, fps[p], level == 0u ? d_raster_rgba : d_rgba, d_depth, out, sp, flags, true, &lp);
+        if (rc != BRT_OK) return rc;
+        if (p != 0) {
+            HIP_TRY(ctx, hipMemcpyPeerAsync(d0.d_gather + (size_t)p * tile_floats, d0.device, dc.d_tile, dc.device, tile_bytes, sp));
+            HIP_TRY(ctx, hipEventRecord(dc.ev_copy, sp));
+            HIP_TRY(ctx, hipEventRecord(dc.ev_last, sp));
+        }
+    }
+    HIP_TRY(ctx, hipSetDevice(d0.device));
+    HIP_TRY(ctx, hipEventRecord(d0.ev_g0, stream0));
+    for (uint32_t p = 1; p < n_parts; p++) HIP_TRY(ctx, hipStreamWaitEvent(stream0, ctx->devs[p].ev_copy, 0));
+    HIP_TRY(ctx, launch_deinterleave(d0.d_gather, d_frame, width, height, n_parts, tile_rows, stream0));
+    HIP_TRY(ctx, hipEventRecord(d0.ev_g1, stream0));
+    HIP_TRY(ctx, hipEventRecord(d0.ev_asm, stream0));
+    HIP_TRY(ctx, hipEventRecord(d0.ev_last, stream0));
+    brt_stats st{};
+    for (uint32_t p = 0; p < n_parts; p++) st.paths += part_pixels(fps[p]) * (uint64_t)fps[p].sample_count;
+    if (own_stream) {
+        double kernel_ms = 0.0, prepass_ms = 0.0;
+        for (uint32_t p = 0; p < n_parts; p++) {
+            DeviceCtx& dc = ctx->devs[p];
+            HIP_TRY(ctx, hipSetDevice(dc.device));
+            hipStream_t sp = p == 0 ? stream0 : dc.stream;
+            rc = update_tile_order(ctx, dc, fps[p], sp);
+            if (rc != BRT_OK) return rc;
+            const uint64_t before = st.rays;
+            rc = read_counters(ctx, dc, sp, &st);       // synchronises this device's stream
+            if (rc != BRT_OK) return rc;
+            dc.view_rays = st.rays - before;
+            view_key_of(ctx, fps[p], dc.view_key);
+            float ms = 0.0f;
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, dc.ev0, dc.ev1));
+            if (ms > kernel_ms) kernel_ms = ms;
+            double pp = 0.0;
+            rc = prepass_elapsed(ctx, dc, prepass_ran[p] != 0, &pp);
+            if (rc != BRT_OK) return rc;
+            if (pp > prepass_ms) prepass_ms = pp;
+        }
+        float gms = 0.0f;
+        HIP_TRY(ctx, hipEventElapsedTime(&gms, d0.ev_g0, d0.ev_g1));
+        st.kernel_ms = kernel_ms;
+        st.prepass_ms = prepass_ms;
+        st.gather_ms = gms;        // from the end of the first device's trace to the assembled frame (waits for the slowest device)
+    }
+    if (stats) {
+        *stats = st;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        stats->lds_bytes = (uint32_t)lp.lds_bytes;
+        stats->scene_in_lds = lp.scene_mode == SCENE_LDS ? 1u : (lp.scene_mode == SCENE_LDS_TOP ? 2u : 0u);
+        stats->n_workgroups = lp.grid;
+        stats->threads_per_workgroup = lp.block;
+    }
+    return BRT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -942,6 +1148,33 @@ int32_t brt_render(brt_ctx* ctx, const void* camera80, const void* window16, uin
     if (!out_rgba) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "out_rgba is null");
     if (!ctx->has_scene && level != 0u) return ctx_fail(ctx, BRT_ERR_NO_SCENE, "brt_upload_scene has not succeeded yet");
     const int32_t rc = render_frame(ctx, camera80, window16, level, width, height, raster_rgba, raster_depth, out_rgba, flags, stats);
+    if (rc != BRT_OK) drain_all_streams(ctx);
+    return rc;
+}
+
+int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level, uint32_t width,
+                               uint32_t height, uint32_t part, uint32_t n_parts, const float* d_raster_rgba,
+                               const float* d_raster_depth, float* d_out_tile, void* hip_stream, uint32_t flags,
+                               brt_stats* stats) {
+    if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (!d_out_tile) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "d_out_tile is null");
+    if (!ctx->has_scene && level != 0u) return ctx_fail(ctx, BRT_ERR_NO_SCENE, "brt_upload_scene has not succeeded yet");
+    const int32_t rc = render_part_device(ctx, camera80, window16, level, width, height, part, n_parts, d_raster_rgba, d_raster_depth,
+                                          d_out_tile, hip_stream, flags, stats);
+    // a failed call leaves nothing in flight on the context's own streams (a caller's stream is the caller's to drain)
+    if (rc != BRT_OK) drain_all_streams(ctx);
+    return rc;
+}
+
+int32_t brt_render_device(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level, uint32_t width, uint32_t height,
+                          const float* d_raster_rgba, const float* d_raster_depth, float* d_frame, void* hip_stream, uint32_t flags,
+                          brt_stats* stats) {
+    if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (!d_frame) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "d_frame is null");
+    if (!ctx->has_scene && level != 0u) return ctx_fail(ctx, BRT_ERR_NO_SCENE, "brt_upload_scene has not succeeded yet");
+    if (flags & BRT_FLAG_KERNEL_SIMPLE) return ctx_fail(ctx, BRT_ERR_UNSUPPORTED, "brt_render_device runs the persistent kernel only");
+    const int32_t rc = render_frame_device(ctx, camera80, window16, level, width, height, d_raster_rgba, d_raster_depth, d_frame, hip_stream,
+                                           flags, stats);
     if (rc != BRT_OK) drain_all_streams(ctx);
     return rc;
 }

@@ -374,17 +374,12 @@ size_t radix_temp_bytes(uint32_t n) {
 
 }  // namespace
 
-uint32_t ploc_one_block_max() {
-    const char* v = std::getenv("BRT_PLOC_ONE_BLOCK_MAX");   // tests force the grid version on small scenes with 0
-    return (v && *v) ? (uint32_t)std::strtoul(v, nullptr, 10) : kPlocOneBlockMax;
-}
-
-size_t ploc_scratch_bytes(uint32_t n, uint32_t* n_pow2_out) {
+size_t ploc_scratch_bytes(uint32_t n, uint32_t* n_pow2_out, uint32_t one_block_max) {
     uint32_t p = 1;
     while (p < n) p <<= 1;
     if (n_pow2_out) *n_pow2_out = p;
     const size_t nodes = 2 * (size_t)n;
-    const bool grid = n > ploc_one_block_max();
+    const bool grid = n > one_block_max;
     const size_t keys = grid ? 2 * (size_t)n : (size_t)p;   // grid version: hipCUB sorts out of place
     size_t b = 0;
     b += nodes * sizeof(PlocBox) + 256;          // box
@@ -402,10 +397,10 @@ size_t ploc_scratch_bytes(uint32_t n, uint32_t* n_pow2_out) {
 }
 
 hipError_t launch_build_ploc(const Model* d_models, uint32_t n, char* d_scratch, BVHNode** d_out, uint32_t** d_info,
-                             hipStream_t stream) {
+                             uint32_t one_block_max, hipStream_t stream) {
     uint32_t p2 = 1;
-    (void)ploc_scratch_bytes(n, &p2);
-    const bool grid = n > ploc_one_block_max();
+    (void)ploc_scratch_bytes(n, &p2, one_block_max);
+    const bool grid = n > one_block_max;
     auto take = [&](size_t bytes) { char* r = d_scratch; d_scratch += (bytes + 255) & ~(size_t)255; return r; };
     const size_t nodes = 2 * (size_t)n;
     const size_t keys = grid ? 2 * (size_t)n : (size_t)p2;

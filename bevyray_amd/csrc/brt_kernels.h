@@ -48,9 +48,9 @@ hipError_t launch_build_order(const uint32_t* d_ray_sum, const uint32_t* d_longe
 // point into the scratch (nodes in the reference's 48-byte format; info[0] = node count,
 // info[1] = PLOC rounds)
 constexpr uint32_t kPlocOneBlockMax = 6000;    // up to here the one-workgroup build (no kernel boundaries) is faster; above: the grid version
-uint32_t ploc_one_block_max();                 // kPlocOneBlockMax, or BRT_PLOC_ONE_BLOCK_MAX (tests)
-size_t ploc_scratch_bytes(uint32_t n, uint32_t* n_pow2_out);
+// one_block_max: kPlocOneBlockMax, or the knob BRT_PLOC_ONE_BLOCK_MAX (tests force the grid version on small scenes with 0)
+size_t ploc_scratch_bytes(uint32_t n, uint32_t* n_pow2_out, uint32_t one_block_max);
 hipError_t launch_build_ploc(const Model* d_models, uint32_t n, char* d_scratch, BVHNode** d_out, uint32_t** d_info,
-                             hipStream_t stream);
+                             uint32_t one_block_max, hipStream_t stream);
 
 }  // namespace brt

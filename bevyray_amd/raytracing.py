@@ -47,6 +47,7 @@ LEVEL_DTYPE = np.dtype({"names": ["level"], "formats": ["<u4"], "offsets": [0], 
 STRIP_ROWS = 8
 FLAG_COUNTERS = 1
 FLAG_KERNEL_SIMPLE = 2
+POLICY_OR_SHORT_CIRCUIT = 1   # brt_set_policy: the WGSL-spec reading of `||` in raytrace.wgsl:269 (default: both operands evaluated)
 FLAG_CALLER_STREAM = 4   # device entry points: `stream` is the caller's stream even when its handle is 0
 
 SCENE_COVER, SCENE_RTIOW_FINAL, SCENE_STRESS_GRID = 0, 1, 2
@@ -271,6 +272,36 @@ class RaytracePlugin:
         except Exception:
             pass
 
+    def set_policy(self, flags: int) -> None:
+        """brt_set_policy: POLICY_OR_SHORT_CIRCUIT or 0 (the reading of `||` in raytrace.wgsl:269; changes pixels)."""
+        _lib.check(self._lib.brt_set_policy(self._ctx, flags), self._ctx)
+
+    def set_tuning(self, name: str, value: int) -> None:
+        """brt_set_tuning: a scheduling / launch-shape knob of this context (never changes a pixel)."""
+        _lib.check(self._lib.brt_set_tuning(self._ctx, name.encode(), int(value)), self._ctx)
+
+    def get_tuning(self, name: str):
+        """(value, default) of a knob."""
+        v, d = C.c_uint32(0), C.c_uint32(0)
+        _lib.check(self._lib.brt_get_tuning(self._ctx, name.encode(), C.byref(v), C.byref(d)), self._ctx)
+        return int(v.value), int(d.value)
+
+    def tuning(self, **knobs):
+        """Context manager: `with plugin.tuning(BRT_LEAF_VOTE=8): ...` sets knobs and restores the previous values."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            old = {k: self.get_tuning(k)[0] for k in knobs}
+            for k, v in knobs.items():
+                self.set_tuning(k, v)
+            try:
+                yield self
+            finally:
+                for k, v in old.items():
+                    self.set_tuning(k, v)
+        return cm()
+
     def alloc_frame(self, width: int, height: int) -> np.ndarray:
         """Page-locked (height, width, 4) f32 frame owned by the context (brt_host_alloc): passing it
         as `out` to RayTracingNode.run lets the library DMA straight into it."""
@@ -389,6 +420,21 @@ class RayTracingNode:
                                                  d_raster_depth or None, d_out_tile, stream or None, flags,
                                                  C.byref(stats)), p._ctx)
         return stats.as_dict()
+
+    def render_device(self, level, camera, window, width: int, height: int, d_frame: int, d_raster_rgba: int = 0,
+                      d_raster_depth: int = 0, stream: Optional[int] = None, flags: int = 0) -> dict:
+        """brt_render_device: the frame of an N-device context assembled on its first device (tiles by peer copy, then
+        the de-interleave kernel).  d_frame / d_raster_*: device pointers on the first device.  Stream rule as for
+        render_part_device."""
+        p = self._p
+        stats = BrtStats()
+        if stream is not None:
+            flags |= FLAG_CALLER_STREAM
+        _lib.check(p._lib.brt_render_device(p._ctx, camera.ctypes.data, window.ctypes.data, int(level["level"][0]), width, height,
+                                            d_raster_rgba or None, d_raster_depth or None, d_frame, stream or None, flags,
+                                            C.byref(stats)), p._ctx)
+        self.last_stats = stats.as_dict()
+        return self.last_stats
 
     def deinterleave_device(self, d_tiles: int, n_parts: int, width: int, height: int, d_frame: int,
                             stream: Optional[int] = None):

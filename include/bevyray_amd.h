@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define BRT_ABI_VERSION 2u
+#define BRT_ABI_VERSION 3u
 
 /* Rows per strip of the interleaved row tiling. */
 #define BRT_STRIP_ROWS 8u
@@ -112,6 +112,22 @@ const char* brt_last_error(const brt_ctx* ctx);
 int32_t brt_create(const int32_t* device_ids, int32_t n_devices, brt_ctx** out_ctx);
 int32_t brt_destroy(brt_ctx* ctx);
 
+/* The one reading of the shader that WGSL leaves to the implementation and that this library lets the caller choose
+ * (it changes pixels, so it is an API option, not an environment variable):
+ *   `if cannot_refract || reflectance(cos_theta, ri) > rngNextFloat(state)`     (raytrace.wgsl:269)
+ * Default (flags = 0): both operands are evaluated, the RNG draw always happens (what naga of the reference's era emits,
+ * from memory; unverifiable here).  BRT_POLICY_OR_SHORT_CIRCUIT: the WGSL-spec reading, no draw when cannot_refract.  The
+ * two only differ for glass with ior < 1.  Applies to the frames rendered after the call. */
+enum { BRT_POLICY_OR_SHORT_CIRCUIT = 1u };
+int32_t brt_set_policy(brt_ctx* ctx, uint32_t flags);
+
+/* Scheduling / launch-shape knobs of the trace path (names and meaning: DESIGN.md section 6, "Tuning aids").  None
+ * changes a pixel.  They live in the context; nothing reads the environment per frame.  brt_create takes initial values
+ * from the environment variables of the same names, once, and only when BRT_ENABLE_TUNING=1 is set.  No reference
+ * counterpart (the reference has one fullscreen draw and nothing to tune, pipeline.rs:206-217). */
+int32_t brt_set_tuning(brt_ctx* ctx, const char* name, uint32_t value);
+int32_t brt_get_tuning(const brt_ctx* ctx, const char* name, uint32_t* out_value, uint32_t* out_default);
+
 /* Replaces: model_buffer / material_buffer / bvh_buffer .write_buffer (pipeline.rs:136-138).
  * Takes the three CPU vectors that prepare_buffers builds (extract.rs:299-336), validates
  * them (indices in range, BVH reachable from node 0 without cycles) and copies them to
@@ -155,6 +171,21 @@ int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* w
                                const float* d_raster_rgba, const float* d_raster_depth,
                                float* d_out_tile, void* hip_stream, uint32_t flags,
                                brt_stats* stats_or_null);
+
+/* The whole frame of an N-device context (brt_create with N ordinals), assembled ON ITS FIRST DEVICE: every device traces its
+ * strips, the tiles of devices 1..N-1 travel to the first device by peer copy (hipMemcpyPeerAsync: xGMI inside a node) and a
+ * copy kernel de-interleaves them into d_frame (DEVICE pointer on the first device, width*height*4 floats) -- the single
+ * gather of tile buffers at frame end, for a single-process host.  Replaces, together with brt_upload_scene, the pass that
+ * RayTracingNode::run encodes on post_process.destination (pipeline.rs:191-217); the caller copies or maps d_frame into its
+ * colour target.  d_raster_rgba / d_raster_depth: optional full-frame DEVICE buffers on the first device (the callee forwards
+ * them to the other devices).  Stream rule as for brt_render_part_device: NULL without BRT_FLAG_CALLER_STREAM = the context's
+ * own stream, synchronous, every field of stats filled (gather_ms = from the end of the first device's trace to the
+ * assembled frame); otherwise the de-interleave is enqueued on `hip_stream` (a stream of the first device) behind the
+ * tiles' arrival and the call does not synchronise.  One frame per context in flight. */
+int32_t brt_render_device(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level,
+                          uint32_t width, uint32_t height,
+                          const float* d_raster_rgba, const float* d_raster_depth,
+                          float* d_frame, void* hip_stream, uint32_t flags, brt_stats* stats_or_null);
 
 /* Rows in the dense tile of `part` (same for every part: padded to whole strips). */
 uint32_t brt_tile_rows(uint32_t height, uint32_t n_parts);

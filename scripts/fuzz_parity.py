@@ -198,9 +198,9 @@ def main():
         # kernel variant of this case: default plan, top-of-tree tile of a few records, everything from L2, knobs live
         variant = [{}, {}, {"BRT_FORCE_LDS_TOP": str(int(rng.integers(1, 200)))}, {"BRT_FORCE_GLOBAL_SCENE": "1"},
                    {"BRT_TUNABLE": "1"}, {"BRT_FORCE_LDS_TOP": "100000", "BRT_TUNABLE": "1"}][int(rng.integers(0, 6))]
-        for k in ("BRT_FORCE_LDS_TOP", "BRT_FORCE_GLOBAL_SCENE", "BRT_TUNABLE"):
-            os.environ.pop(k, None)
-        os.environ.update(variant)
+        for pl in (plugin, multi):          # knobs live in the context (brt_set_tuning), not in the environment
+            for k in ("BRT_FORCE_LDS_TOP", "BRT_FORCE_GLOBAL_SCENE", "BRT_TUNABLE"):
+                pl.set_tuning(k, int(variant.get(k, 0)))
         try:
             if b.bvh is None:             # callee-built: GPU PLOC must equal the CPU builder byte for byte
                 cpu_nodes = brt.build_bvh(b.models)

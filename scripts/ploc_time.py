@@ -8,7 +8,7 @@ with brt.RaytracePlugin([0]) as p:
         m=np.zeros(n, brt.MODEL_DTYPE); m["position"]=rng.uniform(-50,50,(n,3)).astype(np.float32); m["radius"]=rng.uniform(0.05,0.6,n).astype(np.float32)
         res=[]
         for mode in ("100000000", "0"):
-            os.environ["BRT_PLOC_ONE_BLOCK_MAX"]=mode
+            p.set_tuning("BRT_PLOC_ONE_BLOCK_MAX", int(mode))
             p.build_bvh(m)
             best=min(p.build_bvh(m)[1] for _ in range(5))
             res.append(best)

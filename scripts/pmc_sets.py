@@ -21,6 +21,8 @@ def main():
             env[k] = v
     sets = argv[1:] if argv else []
     os.environ.update(env)
+    if env:
+        os.environ["BRT_ENABLE_TUNING"] = "1"      # knobs come from the environment once, at brt_create, on request
     bench.PMC_PASSES = sets or bench.PMC_PASSES
     got, why = bench.live_pmc(timeout_s=600.0)
     print(json.dumps({"env": env, "counters": got, "note": why}, indent=1), flush=True)

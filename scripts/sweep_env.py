@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of environment knobs in ONE process (they are read per call): for every setting, a few frames of one
+"""A/B of tuning knobs in ONE process (brt_set_tuning; names are those of the BRT_* variables): for every setting, a few frames of one
 workload, the best and the median kernel time.  usage: sweep_env.py <scene> <w> <h> <spp> <bounces> "K=V K2=V2" ..."""
 import os
 import sys
@@ -21,20 +21,12 @@ def main():
         for rnd in range(2):          # two passes over the settings: the second is the one to read (clocks warm)
             for st in settings:
                 env = dict(kv.split("=", 1) for kv in st.split()) if st else {}
-                old = {k: os.environ.get(k) for k in env}
-                os.environ.update(env)
-                try:
+                with p.tuning(**{k: int(v) for k, v in env.items()}):
                     ks = []
                     for i in range(reps):
                         p.node.run(lvl, cam, win, w, h, out=out)
                         ks.append(p.node.last_stats["kernel_ms"])
                     s = p.node.last_stats
-                finally:
-                    for k, v in old.items():
-                        if v is None:
-                            os.environ.pop(k, None)
-                        else:
-                            os.environ[k] = v
                 if ref is None:
                     ref = out.copy()
                 same = bool(np.array_equal(ref.view(np.uint32), out.view(np.uint32)))

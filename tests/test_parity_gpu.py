@@ -350,6 +350,63 @@ def test_multi_device_context_on_one_gpu(oracle):
         assert {k: p3.node.last_stats[k] for k in COUNTER_KEYS} == cnt
 
 
+def _render_device_frames(device_ids, oracle):
+    """brt_render_device on a context over `device_ids`: frames with a new seed each (a stale tile or a gather buffer
+    reused too early would show), the synchronous form and the caller-stream form, level 3 and level 2 with device
+    raster inputs -- all against the oracle, bit for bit, counters included."""
+    import torch
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    w, h = 200, 117                                       # 15 strips, the last one 5 rows: ragged shares
+    rng = np.random.default_rng(3)
+    raster = rng.random((h, w, 4), dtype=np.float32)
+    depth = (rng.random((h, w), dtype=np.float32) * np.float32(0.05)).astype(np.float32)
+    with brt.RaytracePlugin(device_ids) as p:
+        p.node.write_buffers(b)
+        torch.cuda.set_device(device_ids[0])
+        frame = torch.full((h, w, 4), -1.0, dtype=torch.float32, device="cuda")
+        d_raster, d_depth = torch.from_numpy(raster).cuda(), torch.from_numpy(depth).cuda()
+        torch.cuda.synchronize()
+        for i in range(5):
+            lvl, cam, win = brt.cover_camera(w, h, 3, 5, seed=0.07 + 0.17 * i)
+            st = p.node.render_device(lvl, cam, win, w, h, frame.data_ptr(), flags=brt.FLAG_COUNTERS)
+            want, cnt = oracle.render(b, lvl, cam, win, w, h)
+            assert_frames_equal(frame.cpu().numpy(), want)
+            assert {k: st[k] for k in COUNTER_KEYS} == cnt and st["paths"] == w * h * 3
+        # asynchronous on torch's current stream (handle 0 = the default stream), a new seed per frame, no sync in between
+        stream = torch.cuda.current_stream().cuda_stream
+        wants = []
+        frames = [torch.empty_like(frame) for _ in range(4)]
+        for i, f in enumerate(frames):
+            lvl, cam, win = brt.cover_camera(w, h, 2, 4, seed=0.21 + 0.19 * i)
+            p.node.render_device(lvl, cam, win, w, h, f.data_ptr(), stream=stream)
+            wants.append(oracle.render(b, lvl, cam, win, w, h)[0])
+        torch.cuda.synchronize()
+        for f, want in zip(frames, wants):
+            assert_frames_equal(f.cpu().numpy(), want)
+        # depth blend with raster inputs on the first device (forwarded to the others), and the passthrough level
+        for level in (brt.Raytracing.FallbackRaytraced, brt.Raytracing.FallbackRaster, brt.Raytracing.Skip):
+            lvl, cam, win = brt.cover_camera(w, h, 2, 4, level)
+            p.node.render_device(lvl, cam, win, w, h, frame.data_ptr(), d_raster.data_ptr(), d_depth.data_ptr())
+            want, _ = oracle.render(b, lvl, cam, win, w, h, raster_rgba=raster, raster_depth=depth)
+            assert_frames_equal(frame.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("ids", [[0], [0, 0], [0, 0, 0, 0, 0]])
+def test_render_device_assembles_the_frame_on_the_first_device(oracle, ids):
+    """The library's own N-device path with the gather ON the device (include/bevyray_amd.h brt_render_device): on one
+    GPU with a repeated ordinal the peer copies degenerate to device copies; shares, gather buffer and de-interleave are
+    the N-GPU ones."""
+    _render_device_frames(ids, oracle)
+
+
+def test_render_device_over_two_gpus(oracle):
+    """The same over two real devices (tiles cross xGMI by hipMemcpyPeerAsync); skipped on the one-GPU boxes."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _render_device_frames([0, 1], oracle)
+
+
 # ---- BASELINE.json full size: size-independent properties + sampled rows --------------------------------------
 
 def test_config2_full_size_properties(plugin, oracle):
@@ -458,10 +515,15 @@ def test_gpu_ploc_grid_build_of_a_large_scene(plugin):
 
 
 @pytest.mark.parametrize("grid", [False, True])
-def test_gpu_ploc_build_is_byte_identical_to_cpu_build(plugin, oracle, grid, monkeypatch):
-    # grid: the multi-kernel version of the builder (used above 32 768 spheres) forced on every size
-    if grid:
-        monkeypatch.setenv("BRT_PLOC_ONE_BLOCK_MAX", "0")
+def test_gpu_ploc_build_is_byte_identical_to_cpu_build(oracle, grid):
+    # grid: the multi-kernel version of the builder (used above 6 000 spheres) forced on every size
+    with brt.RaytracePlugin([0]) as plugin:
+        if grid:
+            plugin.set_tuning("BRT_PLOC_ONE_BLOCK_MAX", 0)
+        _ploc_build_cases(plugin, oracle)
+
+
+def _ploc_build_cases(plugin, oracle):
     rng = np.random.default_rng(11)
     scenes = [brt.generate_scene(brt.SCENE_COVER, s).models for s in (1, 2, 3)]
     scenes += [brt.generate_scene(brt.SCENE_RTIOW_FINAL, 1).models, brt.generate_scene(brt.SCENE_STRESS_GRID, 1).models]
@@ -537,18 +599,10 @@ def test_sample_count_zero_is_zero_over_zero(plugin, oracle, level):
 def test_tuning_knobs_do_not_change_results(plugin, oracle, env):
     b = brt.generate_scene(brt.SCENE_COVER, 1)
     lvl, cam, win = brt.cover_camera(120, 68, 3, 6, brt.Raytracing.Pure, 0.25)
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
+    with plugin.tuning(**{k: int(v) for k, v in env.items()}):
         bb = brt.Buffers(b.models, b.materials, None) if "BRT_CPU_BVH" in env else b
         got = plugin.node.run(lvl, cam, win, 120, 68, buffers=bb, flags=brt.FLAG_COUNTERS)
         stats = dict(plugin.node.last_stats)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
     want, cnt = oracle.render(b, lvl, cam, win, 120, 68)
     assert_frames_equal(got, want)
     assert {k: stats[k] for k in COUNTER_KEYS} == cnt
@@ -590,10 +644,15 @@ def _random_case(rng):
 
 
 @pytest.mark.parametrize("lds_top", [None, "5"])
-def test_randomized_scenes_bit_exact(plugin, oracle, lds_top, monkeypatch):
+def test_randomized_scenes_bit_exact(oracle, lds_top):
     # lds_top: the same scenes through the SCENE_LDS_TOP kernel with a 5-record tile (most records then come from L2)
-    if lds_top:
-        monkeypatch.setenv("BRT_FORCE_LDS_TOP", lds_top)
+    with brt.RaytracePlugin([0]) as plugin:
+        if lds_top:
+            plugin.set_tuning("BRT_FORCE_LDS_TOP", int(lds_top))
+        _randomized_scenes(plugin, oracle)
+
+
+def _randomized_scenes(plugin, oracle):
     rng = np.random.default_rng(2024)
     for case in range(40):
         b, lvl, cam, win, w, h = _random_case(rng)
@@ -656,27 +715,18 @@ def test_expensive_first_dispatch_never_changes_pixels(plugin, oracle):
         got = plugin.node.run(lvl, cam, win, w, h, flags=brt.FLAG_COUNTERS)
         assert_frames_equal(got, want)
         assert {k: plugin.node.last_stats[k] for k in COUNTER_KEYS} == cnt, frame_no
-    os.environ["BRT_LPT"] = "0"
-    try:
+    with plugin.tuning(BRT_LPT=0):
         assert_frames_equal(plugin.node.run(lvl, cam, win, w, h), want)
-    finally:
-        del os.environ["BRT_LPT"]
     # the ingredients of the order one by one: ranking key, sky tiles first, critical pixels (waves at raised
     # priority that stop taking pixels -- on a frame this small nearly every ranked tile is critical)
     for env in ({"BRT_LPT_SORT": "0"}, {"BRT_LPT_LANE_PERMILLE": "100"}, {"BRT_LPT_LANE_PERMILLE": "1000"},
                 {"BRT_LPT_LANE_PERMILLE": "500", "BRT_DRAIN_DONATE": "0"}, {"BRT_CRIT": "0"}, {"BRT_DRAIN_DONATE": "0"},
                 {"BRT_LPT_LANE_PERMILLE": "1000", "BRT_DRAIN_DONATE": "56"}):
-        os.environ.update(env)
-        try:
-            plugin.node.write_buffers(brt.generate_scene(brt.SCENE_COVER, 5))    # forget the history ...
-            plugin.node.write_buffers(b)
+        with plugin.tuning(**{k: int(v) for k, v in env.items()}):                # (setting a knob forgets the history ...)
             for frame_no in range(3):                                              # ... measure, then use the order
                 got = plugin.node.run(lvl, cam, win, w, h, flags=brt.FLAG_COUNTERS)
                 assert_frames_equal(got, want)
                 assert {k: plugin.node.last_stats[k] for k in COUNTER_KEYS} == cnt, (env, frame_no)
-        finally:
-            for k in env:
-                del os.environ[k]
     # another view of the same scene reuses nothing wrongly (different size -> history key mismatch)
     lvl2, cam2, win2 = brt.cover_camera(96, 54, 2, 4)
     want2, _ = oracle.render(b, lvl2, cam2, win2, 96, 54)
@@ -799,18 +849,27 @@ def test_two_ranks_over_rccl_match_one_gpu(plugin, oracle, tmp_path):
         assert_frames_equal(plugin.node.run(lvl, cam, win, w, h, buffers=b), want)
 
 
-def test_short_circuit_policy_switch_matches_the_oracle_under_that_policy(plugin, oracle, monkeypatch):
-    """The alternative reading of `||` (raytrace.wgsl:269) exists in the kernel too (TUNABLE instantiation,
-    BRT_POLICY_OR_SHORT_CIRCUIT=1): on the ior < 1 fixture it must give the oracle's frame under that policy,
-    which differs from the default one."""
+def test_short_circuit_policy_switch_matches_the_oracle_under_that_policy(oracle, monkeypatch):
+    """The alternative reading of `||` (raytrace.wgsl:269) exists in the kernel too, chosen through the API
+    (brt_set_policy(BRT_POLICY_OR_SHORT_CIRCUIT)): on the ior < 1 fixture it must give the oracle's frame under that
+    policy, which differs from the default one.  The environment cannot switch it: BRT_POLICY_OR_SHORT_CIRCUIT set
+    before brt_create (with or without BRT_ENABLE_TUNING) or after it does not change a pixel."""
+    monkeypatch.setenv("BRT_POLICY_OR_SHORT_CIRCUIT", "1")
+    monkeypatch.setenv("BRT_ENABLE_TUNING", "1")
+    with brt.RaytracePlugin([0]) as plugin:
+        _short_circuit_policy_case(plugin, oracle, monkeypatch)
+
+
+def _short_circuit_policy_case(plugin, oracle, monkeypatch):
     z = np.load(os.path.join(GOLDEN, "policy_frames.npz"))
     g = lambda k: z[f"glass_tir.{k}"]
     b = brt.Buffers(g("models").view(brt.MODEL_DTYPE), g("materials").view(brt.MATERIAL_DTYPE), g("bvh").view(brt.BVH_NODE_DTYPE))
     lvl, cam, win = g("level").view(brt.LEVEL_DTYPE), g("camera").view(brt.CAMERA_DTYPE), g("window").view(brt.WINDOW_DTYPE)
     w, h = (int(x) for x in g("size"))
     got = plugin.node.run(lvl, cam, win, w, h, buffers=b)
-    assert_frames_equal(got, g("frame.default"))
-    monkeypatch.setenv("BRT_POLICY_OR_SHORT_CIRCUIT", "1")
+    assert_frames_equal(got, g("frame.default"))          # the environment variable (set before brt_create) is not the switch
+    monkeypatch.setenv("BRT_POLICY_OR_SHORT_CIRCUIT", "0")
+    plugin.set_policy(brt.POLICY_OR_SHORT_CIRCUIT)
     got = plugin.node.run(lvl, cam, win, w, h, buffers=b, flags=brt.FLAG_COUNTERS)
     assert_frames_equal(got, g("frame.or_short_circuit"))
     assert plugin.node.last_stats["rays"] == int(g("rays.or_short_circuit")[0])
@@ -819,6 +878,10 @@ def test_short_circuit_policy_switch_matches_the_oracle_under_that_policy(plugin
     assert_frames_equal(got, want)
     assert {k: plugin.node.last_stats[k] for k in COUNTER_KEYS} == cnt
     assert not np.array_equal(g("frame.default").view(np.uint32), g("frame.or_short_circuit").view(np.uint32))
+    plugin.set_policy(0)
+    assert_frames_equal(plugin.node.run(lvl, cam, win, w, h, buffers=b), g("frame.default"))
+    with pytest.raises(brt.BrtError):
+        plugin.set_policy(2)
 
 
 def test_first_frame_prepass_orders_tiles_without_changing_pixels(oracle, monkeypatch):
@@ -838,13 +901,25 @@ def test_first_frame_prepass_orders_tiles_without_changing_pixels(oracle, monkey
     assert_frames_equal(f2, want)
     assert {k: s1[k] for k in COUNTER_KEYS} == cnt and {k: s2[k] for k in COUNTER_KEYS} == cnt
     assert s1["prepass_ms"] > 0.0 and s2["prepass_ms"] == 0.0
-    monkeypatch.setenv("BRT_PREPASS_SPP", "0")
     with brt.RaytracePlugin([0]) as p:
+        p.set_tuning("BRT_PREPASS_SPP", 0)
         f3 = p.node.run(lvl, cam, win, w, h, buffers=b)
         assert p.node.last_stats["prepass_ms"] == 0.0
     assert_frames_equal(f3, want)
-    # frames of fewer than 16x the pre-pass samples run without one
+    # the environment is read once, at brt_create, and only under BRT_ENABLE_TUNING=1
+    monkeypatch.setenv("BRT_PREPASS_SPP", "0")
+    with brt.RaytracePlugin([0]) as p:
+        p.node.run(lvl, cam, win, w, h, buffers=b)
+        assert p.node.last_stats["prepass_ms"] > 0.0
+    monkeypatch.setenv("BRT_ENABLE_TUNING", "1")
+    with brt.RaytracePlugin([0]) as p:
+        assert p.get_tuning("BRT_PREPASS_SPP") == (0, 2)
+        monkeypatch.setenv("BRT_PREPASS_SPP", "2")          # after brt_create: ignored
+        p.node.run(lvl, cam, win, w, h, buffers=b)
+        assert p.node.last_stats["prepass_ms"] == 0.0
+    monkeypatch.delenv("BRT_ENABLE_TUNING")
     monkeypatch.delenv("BRT_PREPASS_SPP")
+    # frames of fewer than 16x the pre-pass samples run without one
     lvl, cam, win = brt.cover_camera(w, h, 8, 8)
     with brt.RaytracePlugin([0]) as p:
         p.node.run(lvl, cam, win, w, h, buffers=b)
@@ -930,9 +1005,9 @@ def test_order_built_on_host_and_on_gpu_render_the_same_frames(oracle, monkeypat
     w, h = 320, 180
     lvl, cam, win = brt.cover_camera(w, h, 32, 8)
     want, cnt = oracle.render(b, lvl, cam, win, w, h)
-    for host in ("0", "1"):
-        monkeypatch.setenv("BRT_ORDER_ON_HOST", host)
+    for host in (0, 1):
         with brt.RaytracePlugin([0]) as p:
+            p.set_tuning("BRT_ORDER_ON_HOST", host)
             for _ in range(3):      # pre-pass + frame, then frames in the order measured by the one before
                 got = p.node.run(lvl, cam, win, w, h, buffers=b, flags=brt.FLAG_COUNTERS)
                 assert_frames_equal(got, want)
@@ -948,14 +1023,13 @@ def test_lean_steady_state_kernel_renders_the_same_pixels(oracle, monkeypatch):
     w, h = 480, 270
     lvl, cam, win = brt.cover_camera(w, h, 16, 2)        # 16 spp x 3 segments = 48 < half a lane's share (~69)
     want, cnt = oracle.render(b, lvl, cam, win, w, h)
-    for no_lean in ("0", "1"):
-        monkeypatch.setenv("BRT_NO_LEAN", no_lean)
+    for no_lean in (0, 1):
         with brt.RaytracePlugin([0]) as p:
+            p.set_tuning("BRT_NO_LEAN", no_lean)
             for frame in range(5):
                 got = p.node.run(lvl, cam, win, w, h, buffers=b)
                 assert_frames_equal(got, want)
                 assert p.node.last_stats["rays"] == cnt["rays"], (no_lean, frame)
-    monkeypatch.delenv("BRT_NO_LEAN")
     rng = np.random.default_rng(1)
     raster = rng.random((h, w, 4), dtype=np.float32)
     depth = rng.random((h, w), dtype=np.float32) * np.float32(0.05)
