@@ -20,8 +20,11 @@ profiles/pmc_summary.json, only if it was taken on the same device code), the ke
 HIP events on the kernel's own stream inside the timed steps.  The SURVEY.md 8(d) algorithmic
 bytes and the measured HBM bytes are carried as secondary keys: the scene lives in LDS and ray
 state in registers, so HBM is idle and is not the bound.
+For N > 1 the same block is filled from the counters of the WHOLE frame on one GPU (its useful lane-operations do not
+depend on how the rows are dealt out): achieved = those lane-ops / the slowest rank's kernel time, peak = N x one GPU's.
+`config4` (BASELINE.json's own multi-GPU config, N > 1 only) carries its own block from a config-4 counter pass.
 `cpu_baseline` = the C oracle (a port, not the reference: the reference cannot be built here)
-on this host's cores over a bounded, evenly spread row sample of the same frame.
+on rank 0's host cores over a bounded, evenly spread row sample of the same frame, for every N.
 """
 import argparse
 import json
@@ -41,6 +44,7 @@ VALU_PEAK_TLANEOPS = N_CUS * SIMDS_PER_CU * SIMD_LANES * CLOCK_HZ / 1e12   # 78.
 WORKLOAD = dict(width=1920, height=1080, spp=64, bounces=8, scene_seed=1, random_seed=0.5)
 WORKLOAD4 = dict(width=3840, height=2160, spp=1024, bounces=8, scene_seed=1, random_seed=0.5)   # BASELINE.json configs[3]
 PMC_WORKLOAD_TAG = "cover_1920x1080_64spp_8b"
+PMC_WORKLOAD4_TAG = "rtiow_3840x2160_1024spp_8b"
 
 
 def bytes_alg(stats, width, rows):
@@ -228,10 +232,8 @@ def main():
             w2 = brt.WindowExtract.extract_component(H, 0.05 + 0.11 * i)
             ks.append(step(window=w2)[0]["kernel_ms"])
         extras["reseeded_ms"] = [round(all_max(k), 3) for k in ks]
-        # (b) the first frame of a view: new scene epoch -> no history
-        other = brt.generate_scene(brt.SCENE_COVER, 2)
-        node.write_buffers(other)
-        node.write_buffers(head["buffers"])
+        # (b) the first frame of a view: no history (setting a knob -- to its own value -- forgets it)
+        plugin.set_tuning("BRT_LPT", plugin.get_tuning("BRT_LPT")[0])
         st1 = step()[0]
         second = step()[0]["kernel_ms"]
         # kernel time of the first frame of a view = its dispatch-order pre-pass (2 spp) + the frame in that order
@@ -239,6 +241,20 @@ def main():
         extras["first_frame_prepass_ms"] = round(all_max(st1.get("prepass_ms", 0.0)), 3)
         extras["first_frame_call_wall_ms"] = round(all_max(st1["total_ms"]), 3)   # host wall time of that call (incl. building the order)
         extras["second_frame_ms"] = round(all_max(second), 3)
+        # (c) an animated scene: the reference re-extracts and re-uploads every frame (extract.rs:299-336, README.md:17);
+        #     one sphere moves a little per frame, the caller's BVH is rebuilt by the callee (NULL BVH upload)
+        import copy
+        moving = copy.deepcopy(head["buffers"])
+        ks, ups = [], []
+        for i in range(12):
+            moving.models["position"][7, 0] += np.float32(0.002)
+            t0 = time.perf_counter()
+            node.write_buffers(brt.Buffers(moving.models, moving.materials, None))
+            ups.append((time.perf_counter() - t0) * 1e3)
+            ks.append(step()[0]["kernel_ms"])
+        extras["animated_scene_ms"] = [round(all_max(k), 3) for k in ks[4:]]
+        extras["animated_scene_upload_wall_ms"] = round(float(np.median(ups)), 3)
+        node.write_buffers(head["buffers"])
     cfg4 = None
     if not args.no_extras and world > 1:
         # config 2's longest pixel chains take ~5 ms whatever N is; BASELINE.json's own
@@ -252,8 +268,8 @@ def main():
         counted = head["counted"]
         my_rows = int((frame_rows_of_part(H, 0, world) >= 0).sum())
         alg = bytes_alg(counted, W, my_rows)
-        kernel_ms = head["kernel_ms"]
-        roof = roofline_block(args, world, stub is not None, kernel_ms, alg)
+        kernel_ms = max(head["kernel_ms_per_rank"])          # the slowest rank's kernel bounds the frame
+        roof = roofline_block(args, world, stub is not None, kernel_ms, alg, PMC_WORKLOAD_TAG)
         out = {
             "metric": "Mrays/s at 1920x1080, 64 spp, 8 bounces", "value": head["total_rays"] / head["elapsed"] / 1e6,
             "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -274,10 +290,11 @@ def main():
         }
         out.update(extras)
         if cfg4 is not None:
+            cfg4["roofline"] = roofline_block(args, world, stub is not None, max(cfg4["kernel_ms_per_rank"]), None, PMC_WORKLOAD4_TAG)
             out["config4"] = cfg4
-        if world == 1 and not args.no_cpu_baseline and stub is None:
+        if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(head["buffers"], head["lvl"], head["cam"], head["win"], W, H, head["frame"],
-                                               args.cpu_seconds)
+                                               args.cpu_seconds, is_stub=stub is not None)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -294,8 +311,17 @@ PMC_PASSES = [
 ]
 
 
-def live_pmc(timeout_s=150.0):
-    """rocprofv3 --pmc over scripts/pmc_frame.py (the headline workload, torch-free), one child process per
+def under_a_profiler():
+    """True when this process already runs under rocprofv3 / rocprof (its tool library is preloaded and its ROCP* /
+    ROCPROF* variables are set): a nested counter pass would inherit them -- conflicting tool libraries at worst, a
+    confusing note at best -- so the live pass is skipped and the committed, hash-checked summary is used."""
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ):
+        return True
+    return any(t in os.environ.get(v, "") for v in ("LD_PRELOAD", "HSA_TOOLS_LIB") for t in ("rocprofiler", "roctracer", "rocprof"))
+
+
+def live_pmc(timeout_s=90.0, workload=PMC_WORKLOAD_TAG, passes=None):
+    """rocprofv3 --pmc over scripts/pmc_frame.py (the workload named by `workload`, torch-free), one child process per
     counter set (SQ: 8 slots; FETCH_SIZE and WRITE_SIZE do not fit one TCC pass).  Returns {counter: value of
     the LAST dispatch of the production kernel} or None.  The program comes directly after `--` (no shell, no
     env wrapper: the profiler has initialised the GPU by then)."""
@@ -306,12 +332,18 @@ def live_pmc(timeout_s=150.0):
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return None, "rocprofv3 not found"
+    if under_a_profiler():
+        return None, "this run is itself under a profiler: no nested counter pass"
     tmp = tempfile.mkdtemp(prefix="brt_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp", BRT_NO_TORCH="1")
+    env = {k: v for k, v in os.environ.items()
+           if not k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) and k not in ("LD_PRELOAD", "HSA_TOOLS_LIB", "BRT_BENCH_TRACER")}
+    env.update(TMPDIR="/tmp", BRT_NO_TORCH="1", BRT_PMC_WORKLOAD=workload)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):     # the child is a one-GPU program, whatever launched this rank
+        env.pop(k, None)
     got = {}
     t_end = time.time() + timeout_s
     try:
-        for i, counters in enumerate(PMC_PASSES):
+        for i, counters in enumerate(passes or PMC_PASSES):
             left = t_end - time.time()
             if left < 10:
                 return (got or None), "time budget of the PMC passes used up"
@@ -340,45 +372,53 @@ def live_pmc(timeout_s=150.0):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def roofline_block(args, world, is_stub, kernel_ms, alg):
+def roofline_block(args, world, is_stub, kernel_ms, alg, workload):
+    """The roofline object of one workload.  kernel_ms: the slowest rank's mean kernel time.  Counters: of the WHOLE frame
+    on ONE GPU (a live rocprofv3 --pmc pass made now by rank 0 in a one-GPU child process, or the committed summary taken on
+    the same device code); for N > 1 the frame's lane-operations are set against N GPUs' peak."""
     from bevyray_amd import _lib
     code_hash = None if is_stub else _lib.kernel_code_hash()
     pmc, source, why = None, None, None
-    if world == 1 and not is_stub and not args.no_pmc:
-        pmc, why = live_pmc()
+    head = workload == PMC_WORKLOAD_TAG
+    if not is_stub and not args.no_pmc:
+        # (config 4 renders for seconds per pass: its SQ set only)
+        pmc, why = live_pmc(workload=workload, passes=None if head else PMC_PASSES[:1], timeout_s=90.0 if head else 60.0)
         if pmc and "SQ_INSTS_VALU" in pmc:
-            source = "live: rocprofv3 --pmc passes made by this run after the timed region (scripts/pmc_frame.py, last dispatch)"
+            source = "live: rocprofv3 --pmc passes made by this run after the timed region (scripts/pmc_frame.py, one GPU, last dispatch)"
         else:
             pmc = None
-    if pmc is None and world == 1 and not is_stub:
-        path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if pmc is None and not is_stub:
+        path = os.path.join(ROOT, "profiles", "pmc_summary.json" if head else "pmc_summary_config4.json")
         try:
             rec = json.load(open(path))
-            if rec.get("workload") == PMC_WORKLOAD_TAG and rec.get("kernel_code_hash") == code_hash:
+            if rec.get("workload") == workload and rec.get("kernel_code_hash") == code_hash:
                 pmc = rec["counters"]
-                source = f"profiles/pmc_summary.json (same device code {code_hash})"
+                source = f"{os.path.relpath(path, ROOT)} (same device code {code_hash})"
             else:
-                why = (why + "; " if why else "") + f"profiles/pmc_summary.json was taken on device code {rec.get('kernel_code_hash')}, this is {code_hash}"
+                why = (why + "; " if why else "") + f"{os.path.relpath(path, ROOT)} was taken on device code {rec.get('kernel_code_hash')}, this is {code_hash}"
         except Exception as e:   # noqa: BLE001
-            why = (why + "; " if why else "") + f"profiles/pmc_summary.json: {e}"
+            why = (why + "; " if why else "") + f"{os.path.relpath(path, ROOT)}: {e}"
     secs = kernel_ms * 1e-3
-    roof = {"bound": "valu", "achieved": None, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "frac": None, "traffic": None,
-            "kernel": "k_trace_persistent", "kernel_ms": kernel_ms, "kernel_code_hash": code_hash,
-            "algorithmic_bytes_per_launch": alg, "algorithmic_GBs": alg / secs / 1e9 if secs > 0 else None,
-            "hbm_peak_GBs": HBM_PEAK_GBS, "hbm_frac_measured": None,
-            "note": "bound = f32 vector pipes: achieved = VALU instructions x mean active lanes / kernel time; peak = 256 CUs x 4 SIMDs "
-                    "x 32 lanes x 2.4 GHz (a wave64 VALU instruction issues over 2 cycles; v_sqrt/v_rcp/v_mul_lo_u32 over 8). The "
-                    "scene is LDS resident and ray state lives in registers, so HBM only sees the scene load per workgroup and "
-                    "one 16-B store per pixel: `traffic` (measured HBM bytes) / kernel time is `hbm_frac_measured` of the 8 TB/s "
-                    "peak; the SURVEY 8(d) algorithmic bytes are informational (they are served from LDS/registers)",
+    peak = VALU_PEAK_TLANEOPS * world
+    roof = {"bound": "valu", "achieved": None, "peak": peak, "unit": "Tlane-op/s", "frac": None, "traffic": None,
+            "kernel": "k_trace_persistent", "kernel_ms": kernel_ms, "kernel_code_hash": code_hash, "n_gpus": world,
+            "algorithmic_bytes_per_launch": alg, "algorithmic_GBs": alg / secs / 1e9 if (alg and secs > 0) else None,
+            "hbm_peak_GBs": HBM_PEAK_GBS * world, "hbm_frac_measured": None,
+            "note": "bound = f32 vector pipes: achieved = VALU instructions x mean active lanes of the whole frame (counted on one GPU) / "
+                    "the slowest rank's kernel time; peak = n_gpus x 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz (the guide's 2-cycle wave64 issue; "
+                    "tests/tools/issue_bench.hip measures 2.2-2.4 cycles for the f32 add/mul/fma group in a pure stream and 4 for min/max, "
+                    "compares, v_cndmask, conversions and integer multiplies, 8 for v_rcp/v_sqrt -- DESIGN.md section 5). The scene is LDS "
+                    "resident and ray state lives in registers, so HBM only sees the scene load per workgroup and one 16-B store per pixel: "
+                    "`traffic` (measured HBM bytes of the frame) / kernel time is `hbm_frac_measured` of the HBM peak; the SURVEY 8(d) "
+                    "algorithmic bytes are informational (they are served from LDS/registers)",
             "counter_source": source, "counter_note": why}
     if pmc:
         valu, act, thr = pmc.get("SQ_INSTS_VALU"), pmc.get("SQ_ACTIVE_INST_VALU"), pmc.get("SQ_THREAD_CYCLES_VALU")
         lanes = thr / act if act else None
         if valu and lanes and secs > 0:
             roof["achieved"] = valu * lanes / secs / 1e12
-            roof["frac"] = roof["achieved"] / VALU_PEAK_TLANEOPS
-            simd_cycles = secs * CLOCK_HZ * N_CUS * SIMDS_PER_CU
+            roof["frac"] = roof["achieved"] / peak
+            simd_cycles = secs * CLOCK_HZ * N_CUS * SIMDS_PER_CU * world
             n_inst = sum(pmc.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH"))
             roof["issue"] = {"valu_instructions_per_launch": valu, "instructions_per_launch": n_inst,
                              "active_lanes_per_valu": lanes, "valu_per_simd_cycle": valu / simd_cycles,
@@ -386,11 +426,11 @@ def roofline_block(args, world, is_stub, kernel_ms, alg):
         if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
             # rocprofv3 reports KB; on gfx950 FETCH_SIZE counts 64 B per 128-B request: doubled (MI355X_MICROARCH.md, HBM)
             roof["traffic"] = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
-            roof["hbm_frac_measured"] = roof["traffic"] / secs / 1e9 / HBM_PEAK_GBS if secs > 0 else None
+            roof["hbm_frac_measured"] = roof["traffic"] / secs / 1e9 / (HBM_PEAK_GBS * world) if secs > 0 else None
     return roof
 
 
-def cpu_baseline(buffers, lvl, cam, win, W, H, gpu_frame, target_seconds):
+def cpu_baseline(buffers, lvl, cam, win, W, H, gpu_frame, target_seconds, is_stub=False):
     """The C oracle on this host's cores over every `row_step`-th row of the same frame; also
     checks those rows of the GPU frame bit for bit (the oracle as checker, never as product)."""
     import numpy as np
@@ -410,7 +450,7 @@ def cpu_baseline(buffers, lvl, cam, win, W, H, gpu_frame, target_seconds):
     dt = time.perf_counter() - t0
     sampled = np.arange(0, H, row_step)
     g = gpu_frame.cpu().numpy()
-    exact = bool(np.array_equal(g[sampled].view(np.uint32), frame[sampled].view(np.uint32)))
+    exact = None if is_stub else bool(np.array_equal(g[sampled].view(np.uint32), frame[sampled].view(np.uint32)))
     return {"value": cnt["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": f"every {row_step}th row of the same 1920x1080x64spp frame ({len(sampled)} rows, {cnt['rays']} rays, "
                       f"{dt:.1f} s wall on {cores} threads = the CPUs granted to this process; {os.cpu_count()} logical CPUs on the host); "

@@ -12,11 +12,15 @@ import bevyray_amd as brt  # noqa: E402
 
 
 def main():
-    scene = int(os.environ.get("BRT_PMC_SCENE", str(brt.SCENE_COVER)))
-    w, h, spp, bounces = 1920, 1080, 64, 8
-    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    workload = os.environ.get("BRT_PMC_WORKLOAD", "cover_1920x1080_64spp_8b")
+    if workload == "rtiow_3840x2160_1024spp_8b":      # BASELINE.json configs[3], the whole frame on one GPU
+        scene, (w, h, spp, bounces), cam_fn, dflt_frames = brt.SCENE_RTIOW_FINAL, (3840, 2160, 1024, 8), brt.rtiow_camera, 2
+    else:
+        scene = int(os.environ.get("BRT_PMC_SCENE", str(brt.SCENE_COVER)))
+        (w, h, spp, bounces), cam_fn, dflt_frames = (1920, 1080, 64, 8), brt.cover_camera, 3
+    frames = int(sys.argv[1]) if len(sys.argv) > 1 else dflt_frames
     b = brt.generate_scene(scene, 1)
-    lvl, cam, win = brt.cover_camera(w, h, spp, bounces)
+    lvl, cam, win = cam_fn(w, h, spp, bounces)
     with brt.RaytracePlugin([0]) as p:
         p.node.write_buffers(b)
         out = p.alloc_frame(w, h)

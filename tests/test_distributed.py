@@ -92,7 +92,7 @@ def _run_bench(extra_env, *argv):
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it (the driver's command shape): the parent starts the
     two ranks itself (gloo + a stub tracer here), relays ONE JSON line and the line describes both ranks."""
-    out = _run_bench({}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    out = _run_bench({}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1")
     assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["steps"] == 2
     assert out["scaling"] == "strong" and out["unit"] == "Mrays/s"
     assert len(out["kernel_ms_per_rank"]) == 2 and out["kernel_ms_per_rank"] == [1.0, 2.0]
@@ -101,6 +101,15 @@ def test_bench_launches_its_own_ranks():
     assert out["rays_per_frame"] == 1920 * 1080 * 64
     assert "STUB" in out["data"] and out["roofline"]["frac"] is None
     assert out["config4"]["steps"] == 2 and len(out["config4"]["kernel_ms_per_rank"]) == 2
+    # an N > 1 line is gradeable: the roofline names its bound, unit and the N-GPU peak (the stub has no counters, so
+    # `achieved` stays null), config 4 carries its own block, and rank 0 reports the CPU baseline
+    for roof in (out["roofline"], out["config4"]["roofline"]):
+        assert roof["bound"] == "valu" and roof["unit"] == "Tlane-op/s" and roof["n_gpus"] == 2
+        assert abs(roof["peak"] - 2 * 256 * 4 * 32 * 2.4e9 / 1e12) < 1e-6
+        assert set(("achieved", "frac", "traffic", "kernel_ms")) <= set(roof)
+    assert out["roofline"]["kernel_ms"] == 2.0          # the slowest rank
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "Mrays/s" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
 
 
 def test_bench_single_rank_line_has_the_contract_keys():
