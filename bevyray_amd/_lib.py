@@ -78,6 +78,7 @@ _PROTOTYPES = {
     "brt_debug_profile": (_I32, [_VP, C.POINTER(C.c_uint64)]),
     "brt_debug_tile_order": (_I32, [_VP, _VP, _VP, _U32, _U32, C.c_uint64, _VP, _VP]),
     "brt_build_bvh": (_I32, [_VP, _U32, _VP, _U32, C.POINTER(_U32)]),
+    "brt_build_bvh_sah": (_I32, [_VP, _U32, _VP, _U32, C.POINTER(_U32)]),
     "brt_build_bvh_device": (_I32, [_VP, _VP, _U32, _VP, _U32, C.POINTER(_U32), C.POINTER(C.c_double)]),
     "brt_validate_scene": (_I32, [_VP, _U32, _VP, _U32, _VP, _U32, C.POINTER(_U32)]),
     "brt_scene_generate": (_I32, [_U32, C.c_uint64, _VP, _VP, _U32, C.POINTER(_U32)]),

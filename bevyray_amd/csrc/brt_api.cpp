@@ -107,6 +107,7 @@ struct brt_ctx {
     EncodedScene enc;
     bool has_scene = false;
     uint32_t scene_epoch = 0;   // bumped by every upload
+    uint32_t last_n_models = 0; // spheres of the last successful upload
     std::vector<std::pair<char*, size_t>> pinned;   // brt_host_alloc blocks
     // bytes of the last successful upload (dirty tracking: an unchanged scene is not re-sent)
     std::vector<char> last_models, last_materials, last_bvh;
@@ -585,6 +586,7 @@ void free_device(DeviceCtx& dc) {
     dc = DeviceCtx();
 }
 
+constexpr uint32_t kMaxSahModels = 1u << 16;         // host-side binned SAH for callee-built trees up to here
 constexpr uint32_t kMaxGpuBuildModels = 1u << 24;   // scratch ~ 250 B per sphere; the grid version of the builder has no structural limit
 
 // PLOC on the context's first device: models (host) -> nodes (host vector), build time in ms.
@@ -700,6 +702,8 @@ int32_t brt_set_tuning(brt_ctx* ctx, const char* name, uint32_t value) {
             // a knob may change how the dispatch order is built or used: forget the history of every view (the next frame of
             // a view is a "first frame" again: pre-pass, measuring frame)
             for (auto& dc : ctx->devs) { dc.order_valid = false; dc.view_rays = 0; }
+            // ... and a knob of the callee's BVH build changes what the same scene bytes upload to: no dirty-tracking shortcut
+            if (k == K_BVH_QUALITY || k == K_CPU_BVH || k == K_PLOC_ONE_BLOCK_MAX) ctx->last_models.clear();
             return BRT_OK;
         }
     return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, std::string("unknown tuning knob ") + name);
@@ -764,10 +768,16 @@ int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, co
     std::vector<BVHNode> built;
     const BVHNode* nodes = static_cast<const BVHNode*>(bvh_nodes);
     if (n_models > 0 && models && (!bvh_nodes || n_nodes == 0)) {
-        // no BVH from the caller: build it here -- on the GPU (same bytes as the CPU builder)
-        int32_t rc = (n_models <= kMaxGpuBuildModels && ctx->knobs[K_CPU_BVH] == 0)
-                         ? build_bvh_on_device(ctx, static_cast<const Model*>(models), n_models, &built, nullptr)
-                         : build_bvh_ploc(static_cast<const Model*>(models), n_models, &built);
+        // no BVH from the caller: build it here.  Default: binned SAH on the host up to kMaxSahModels spheres (fewer node
+        // visits per ray than PLOC: DESIGN.md section 9; 0.2 ms for the cover scene, ~4 ms for 10 004 spheres), PLOC on
+        // the GPU above that or with the knob BRT_BVH_QUALITY=0 (the same bytes as the CPU PLOC builder)
+        int32_t rc;
+        if (ctx->knobs[K_BVH_QUALITY] != 0u && n_models <= kMaxSahModels)
+            rc = build_bvh_sah(static_cast<const Model*>(models), n_models, &built);
+        else
+            rc = (n_models <= kMaxGpuBuildModels && ctx->knobs[K_CPU_BVH] == 0)
+                     ? build_bvh_on_device(ctx, static_cast<const Model*>(models), n_models, &built, nullptr)
+                     : build_bvh_ploc(static_cast<const Model*>(models), n_models, &built);
         if (rc != BRT_OK) return rc;
         nodes = built.data();
         n_nodes = (uint32_t)built.size();
@@ -822,8 +832,14 @@ int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, co
     ctx->scene_epoch++;
     // the dispatch order of the views rendered so far stays in use as a hint, but is measured again within kLptAfterUpload
     // frames (a scene that changes every frame: every kLptAfterUpload-th frame is a measuring frame)
-    for (auto& dc : ctx->devs)
-        if (dc.order_valid && dc.order_age + kLptAfterUpload < kLptRefresh) dc.order_age = kLptRefresh - kLptAfterUpload;
+    // (a scene with a different number of spheres is a different scene, not the next frame of an animation: its views start
+    //  from scratch, with a pre-pass)
+    const bool same_shape = ctx->last_n_models == n_models;
+    ctx->last_n_models = n_models;
+    for (auto& dc : ctx->devs) {
+        if (!same_shape) { dc.order_valid = false; dc.view_rays = 0; }
+        else if (dc.order_valid && dc.order_age + kLptAfterUpload < kLptRefresh) dc.order_age = kLptRefresh - kLptAfterUpload;
+    }
     return BRT_OK;
 }
 

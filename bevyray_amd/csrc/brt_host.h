@@ -31,6 +31,7 @@ struct EncodedScene {
 int32_t validate_and_encode(const Model* models, uint32_t n_models, const Material* materials, uint32_t n_materials,
                             const BVHNode* nodes, uint32_t n_nodes, EncodedScene* out, std::string* err);
 int32_t build_bvh_ploc(const Model* models, uint32_t n_models, std::vector<BVHNode>* out);
+int32_t build_bvh_sah(const Model* models, uint32_t n_models, std::vector<BVHNode>* out);   // binned SAH, same node contract
 int32_t scene_generate(uint32_t kind, uint64_t seed, std::vector<Model>* models, std::vector<Material>* materials);
 float tan_half_fov(float fov);
 

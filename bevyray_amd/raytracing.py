@@ -172,6 +172,18 @@ def build_bvh(models: np.ndarray) -> np.ndarray:
     return _trim(nodes, out_n.value)
 
 
+def build_bvh_sah(models: np.ndarray) -> np.ndarray:
+    """The binned-SAH tree that brt_upload_scene builds when the caller passes no BVH (brt_build_bvh_sah)."""
+    lib = _lib.load()
+    models = np.ascontiguousarray(models, MODEL_DTYPE)
+    n = len(models)
+    cap = max(1, 2 * n)
+    nodes = np.zeros(cap, BVH_NODE_DTYPE)
+    out_n = C.c_uint32(0)
+    _lib.check(lib.brt_build_bvh_sah(models.ctypes.data, n, nodes.ctypes.data, cap, C.byref(out_n)))
+    return _trim(nodes, out_n.value)
+
+
 def validate_scene(models, materials, bvh) -> int:
     """Returns the maximum leaf depth; raises BrtError for what brt_upload_scene would reject."""
     lib = _lib.load()

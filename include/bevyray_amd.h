@@ -132,7 +132,8 @@ int32_t brt_get_tuning(const brt_ctx* ctx, const char* name, uint32_t* out_value
  * Takes the three CPU vectors that prepare_buffers builds (extract.rs:299-336), validates
  * them (indices in range, BVH reachable from node 0 without cycles) and copies them to
  * every device of the context.  If bvh_nodes == NULL / n_nodes == 0 the callee builds the
- * BVH itself with the native PLOC builder (see brt_build_bvh). */
+ * BVH itself (see brt_build_bvh_sah / brt_build_bvh_device): recommended, the ray loop runs faster in that tree than in
+ * the caller's PLOC tree and the caller saves its own per-frame build (extract.rs:315-332). */
 int32_t brt_upload_scene(brt_ctx* ctx,
                          const void* models, uint32_t n_models,
                          const void* materials, uint32_t n_materials,
@@ -253,6 +254,14 @@ int32_t brt_host_tile_order(const uint32_t* ray_sum, const uint32_t* longest_pix
  * then `index` addresses the model buffer directly.  2*n_models-1 nodes for n_models >= 1. */
 int32_t brt_build_bvh(const void* models, uint32_t n_models,
                       void* out_nodes, uint32_t capacity, uint32_t* out_n_nodes);
+
+/* A better tree for the same contract: top-down binned SAH (16 bins, single-sphere leaves, depth capped below the
+ * shader's 32-entry stack).  The reference rebuilds PLOC on the CPU every frame (extract.rs:315-321, "TODO" at
+ * extract.rs:264-267); the shader only needs the node contract above, and an SAH tree costs the ray loop fewer node
+ * visits (10 004-sphere grid: 23.6 -> 19.1 interior visits per ray).  This is what brt_upload_scene builds when the
+ * caller passes no BVH (up to 65 536 spheres; above that, or with the knob BRT_BVH_QUALITY=0: PLOC on the GPU). */
+int32_t brt_build_bvh_sah(const void* models, uint32_t n_models,
+                          void* out_nodes, uint32_t capacity, uint32_t* out_n_nodes);
 
 /* The same build on the GPU (PLOC in one workgroup, bevyray_amd/csrc/brt_bvh.hip): takes the
  * host model vector, returns byte-identical nodes to brt_build_bvh plus the kernel time.

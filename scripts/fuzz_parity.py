@@ -202,13 +202,19 @@ def main():
             for k in ("BRT_FORCE_LDS_TOP", "BRT_FORCE_GLOBAL_SCENE", "BRT_TUNABLE"):
                 pl.set_tuning(k, int(variant.get(k, 0)))
         try:
-            if b.bvh is None:             # callee-built: GPU PLOC must equal the CPU builder byte for byte
-                cpu_nodes = brt.build_bvh(b.models)
-                gpu_nodes, _ = plugin.build_bvh(b.models)
-                ploc_checked += 1
-                ob = brt.Buffers(b.models, b.materials, cpu_nodes)
-                if cpu_nodes.tobytes() != gpu_nodes.tobytes():
-                    raise AssertionError("GPU PLOC tree differs from the CPU builder's")
+            if b.bvh is None:             # callee-built: binned SAH (default) or PLOC on the GPU, which must equal the CPU builder byte for byte
+                quality = int(rng.integers(0, 2))
+                for pl in (plugin, multi):
+                    pl.set_tuning("BRT_BVH_QUALITY", quality)
+                if quality:
+                    ob = brt.Buffers(b.models, b.materials, brt.build_bvh_sah(b.models))
+                else:
+                    cpu_nodes = brt.build_bvh(b.models)
+                    gpu_nodes, _ = plugin.build_bvh(b.models)
+                    ploc_checked += 1
+                    ob = brt.Buffers(b.models, b.materials, cpu_nodes)
+                    if cpu_nodes.tobytes() != gpu_nodes.tobytes():
+                        raise AssertionError("GPU PLOC tree differs from the CPU builder's")
             else:
                 ob = b
             try:

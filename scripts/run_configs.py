@@ -19,6 +19,9 @@ CONFIGS = [
     ("3: RTIOW final 1920x1080 256spp 50b", brt.SCENE_RTIOW_FINAL, 1920, 1080, 256, 50, 1),
     ("4: RTIOW final 3840x2160 1024spp 8b, part 0 of 8", brt.SCENE_RTIOW_FINAL, 3840, 2160, 1024, 8, 8),
     ("5: 10k-sphere grid 1920x1080 64spp 8b", brt.SCENE_STRESS_GRID, 1920, 1080, 64, 8, 1),
+    # the same scene through the tree the callee builds when the caller passes no BVH (binned SAH)
+    ("5s: 10k-sphere grid 1920x1080 64spp 8b, callee-built SAH tree", brt.SCENE_STRESS_GRID, 1920, 1080, 64, 8, 1),
+    ("2s: cover 1920x1080 64spp 8b, callee-built SAH tree", brt.SCENE_COVER, 1920, 1080, 64, 8, 1),
 ]
 only = sys.argv[1:]
 oracle = oracle_loader.load()
@@ -27,6 +30,10 @@ with brt.RaytracePlugin([0]) as p:
         if only and name.split(":")[0] not in only:
             continue
         b = brt.generate_scene(kind, 1)
+        ob = b                                    # what the oracle walks
+        if "callee-built" in name:
+            ob = brt.Buffers(b.models, b.materials, brt.build_bvh_sah(b.models))
+            b = brt.Buffers(b.models, b.materials, None)
         # configs 3 and 4: the book's view (vfov 20 degrees), as in the parity tests; the others: the cover view
         cam_fn = brt.rtiow_camera if kind == brt.SCENE_RTIOW_FINAL else brt.cover_camera
         lvl, cam, win = cam_fn(w, h, spp, bounces)
@@ -44,7 +51,7 @@ with brt.RaytracePlugin([0]) as p:
         t0 = time.time(); ok = True
         for k in picks:
             y = int(fr[k])
-            want, _ = oracle.render(b, lvl, cam, win, w, h, rows=(y, y + 1))
+            want, _ = oracle.render(ob, lvl, cam, win, w, h, rows=(y, y + 1))
             ok &= bool(np.array_equal(t[k].view(np.uint32), want[y].view(np.uint32)))
         my_rows = int((fr >= 0).sum())
         alg = bytes_alg(cs, w, my_rows)

@@ -270,3 +270,47 @@ def test_dispatch_order_from_tile_costs():
     assert _tile_order(ray_sum, longest, spp, lanes, lane_permille=100)[1]["n_lane"] == (n - n_sky) // 10
     order3, info3 = _tile_order(ray_sum, longest, spp, lanes, sorted_=0)
     assert list(order3[:n - n_sky]) == sorted(order3[:n - n_sky]) and info3["n_critical"] == 0
+
+
+def test_sah_builder_contract_depth_cap_and_determinism():
+    """brt_build_bvh_sah: the reference's node contract (extract.rs:323-332: root 0, children adjacent, single-sphere
+    leaves that address the model buffer), every sphere exactly once, deterministic, depth below the shader's 32-entry
+    stack even where SAH alone would build a caterpillar, and it terminates on NaN / inf spheres."""
+    rng = np.random.default_rng(5)
+    cases = [brt.generate_scene(k, 1).models for k in (brt.SCENE_COVER, brt.SCENE_RTIOW_FINAL, brt.SCENE_STRESS_GRID)]
+    for n in (1, 2, 3, 7, 64, 1000):
+        m = np.zeros(n, brt.MODEL_DTYPE)
+        m["position"] = rng.uniform(-30, 30, (n, 3)).astype(np.float32)
+        m["radius"] = rng.uniform(0.05, 2.0, n).astype(np.float32)
+        cases.append(m)
+    geo = np.zeros(200, brt.MODEL_DTYPE)                       # centres at 1.3^k: every SAH split peels one sphere off
+    geo["position"][:, 0] = (1.3 ** np.arange(200)).astype(np.float32)
+    geo["radius"] = 0.1
+    dup = np.zeros(300, brt.MODEL_DTYPE); dup["position"] = (1.0, 2.0, 3.0); dup["radius"] = 0.5
+    bad = np.zeros(64, brt.MODEL_DTYPE)
+    bad["position"] = rng.uniform(-5, 5, (64, 3)).astype(np.float32); bad["radius"] = 0.3
+    bad["position"][::5, 1] = np.nan; bad["position"][3::7, 0] = np.inf; bad["radius"][1::9] = np.nan
+    cases += [geo, dup, bad]
+    for m in cases:
+        n = len(m)
+        nodes = brt.build_bvh_sah(m)
+        assert len(nodes) == 2 * n - 1
+        assert np.array_equal(nodes.view(np.uint8), brt.build_bvh_sah(m).view(np.uint8))      # deterministic
+        mats = np.zeros(max(1, int(m["material_id"].max()) + 1), brt.MATERIAL_DTYPE)
+        depth = brt.validate_scene(m, mats, nodes)
+        assert depth <= 28, (n, depth)
+        leaves = nodes[nodes["model_count"] > 0]
+        assert np.all(leaves["model_count"] == 1) and sorted(leaves["index"].tolist()) == list(range(n))
+        inner = nodes[nodes["model_count"] == 0]
+        assert len(inner) == n - 1 and np.all(inner["index"] % 2 == 1)                         # children at odd / even slot pairs
+    # finite scenes: every leaf box is Model::aabb (extract.rs:220-227) and every parent holds its children
+    m = cases[0]
+    nodes = brt.build_bvh_sah(m)
+    for nd in nodes:
+        if nd["model_count"]:
+            c, r = m[nd["index"]]["position"], m[nd["index"]]["radius"]
+            pad = np.float32(r) + np.float32(0.1)
+            assert np.array_equal(nd["bounds_min"], c - pad) and np.array_equal(nd["bounds_max"], c + pad)
+        else:
+            for ch in (nodes[nd["index"]], nodes[nd["index"] + 1]):
+                assert np.all(ch["bounds_min"] >= nd["bounds_min"]) and np.all(ch["bounds_max"] <= nd["bounds_max"])

@@ -187,9 +187,15 @@ def test_hand_made_bvh_topologies(plugin, oracle):
         bb = brt.Buffers(b.models, b.materials, bvh)
         got, _ = render_both(plugin, oracle, bb, lvl, cam, win, 64, 36)
         assert_frames_equal(got, ref)          # pixels do not depend on the topology
-    # callee-built BVH (bvh = None -> native PLOC inside brt_upload_scene)
-    got = plugin.node.run(lvl, cam, win, 64, 36, buffers=brt.Buffers(b.models, b.materials, None))
-    assert_frames_equal(got, ref)
+    # callee-built BVH (bvh = None): binned SAH inside brt_upload_scene, or PLOC on the GPU with the quality knob off --
+    # same pixels, and exactly the oracle's counters on the tree the library says it builds
+    for quality, tree in ((1, brt.build_bvh_sah(b.models)), (0, brt.build_bvh(b.models))):
+        with plugin.tuning(BRT_BVH_QUALITY=quality):
+            got = plugin.node.run(lvl, cam, win, 64, 36, buffers=brt.Buffers(b.models, b.materials, None), flags=brt.FLAG_COUNTERS)
+            stats = dict(plugin.node.last_stats)
+        assert_frames_equal(got, ref)
+        _, cnt = oracle.render(brt.Buffers(b.models, b.materials, tree), lvl, cam, win, 64, 36)
+        assert {k: stats[k] for k in COUNTER_KEYS} == cnt, quality
 
 
 def test_stack_overflow_rule(plugin, oracle):
@@ -490,6 +496,16 @@ def test_config5_10k_spheres_full_size(plugin, oracle):
     want, cnt = oracle.render(b, lvl, cam, win, w, h)
     assert s1["rays"] == cnt["rays"]
     assert_frames_equal(f1, want)
+    # the same frame through the tree the CALLEE builds when the caller passes none (binned SAH, what INTEGRATION.md
+    # recommends): same pixels -- the topology only matters through ties and overflow -- and exactly the oracle's
+    # counters on that tree, with fewer node visits than in the caller's PLOC tree
+    f3 = plugin.node.run(lvl, cam, win, w, h, buffers=brt.Buffers(b.models, b.materials, None), flags=brt.FLAG_COUNTERS)
+    s3 = dict(plugin.node.last_stats)
+    assert_frames_equal(f3, want)
+    want3, cnt3 = oracle.render(brt.Buffers(b.models, b.materials, brt.build_bvh_sah(b.models)), lvl, cam, win, w, h)
+    assert_frames_equal(want3, want)
+    assert {k: s3[k] for k in COUNTER_KEYS} == cnt3
+    assert cnt3["interior_visits"] < 0.85 * cnt["interior_visits"]
 
 
 # ---- GPU BVH build --------------------------------------------------------------------
@@ -599,7 +615,10 @@ def test_sample_count_zero_is_zero_over_zero(plugin, oracle, level):
 def test_tuning_knobs_do_not_change_results(plugin, oracle, env):
     b = brt.generate_scene(brt.SCENE_COVER, 1)
     lvl, cam, win = brt.cover_camera(120, 68, 3, 6, brt.Raytracing.Pure, 0.25)
-    with plugin.tuning(**{k: int(v) for k, v in env.items()}):
+    knobs = {k: int(v) for k, v in env.items()}
+    if "BRT_CPU_BVH" in env:
+        knobs["BRT_BVH_QUALITY"] = 0          # the PLOC builders (the callee's default tree is binned SAH)
+    with plugin.tuning(**knobs):
         bb = brt.Buffers(b.models, b.materials, None) if "BRT_CPU_BVH" in env else b
         got = plugin.node.run(lvl, cam, win, 120, 68, buffers=bb, flags=brt.FLAG_COUNTERS)
         stats = dict(plugin.node.last_stats)
