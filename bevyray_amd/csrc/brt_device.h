@@ -21,6 +21,10 @@ namespace brt {
 
 #define BRT_DEV __device__ __forceinline__
 
+#ifndef BRT_EXEC_MOVES
+#define BRT_EXEC_MOVES 0   // bit 0: sphere test, bit 1: ball loop -- `if` bodies of v_mov under EXEC instead of v_cndmask selects; measured: -0.0 ... +0.8 % (the compiler adds a branch per `if`), off
+#endif
+
 constexpr float kInf = 3.40282347e+38f;  // const.wgsl:2 (FLT_MAX, compared with ==)
 
 struct f3 {
@@ -184,8 +188,18 @@ BRT_DEV void sphere_test(f3 o, f3 d, float a, float4 s, uint32_t idx, float& clo
     const float disc = h * h - a * c;
     const float t = (h - __builtin_sqrtf(disc)) / a;
     const bool accept = (t > 0.001f) && (t < closest);
+#if BRT_EXEC_MOVES & 1
+    // two v_mov under EXEC instead of two v_cndmask (the empty asm keeps the compiler from turning the branch back into
+    // selects: on gfx950 a v_cndmask costs a SIMD 4 cycles, a v_mov 2 -- tests/tools/issue_bench.hip)
+    if (accept) {
+        closest = t;
+        closest_idx = idx;
+        asm volatile("" : "+v"(closest), "+v"(closest_idx));
+    }
+#else
     closest = accept ? t : closest;
     closest_idx = accept ? idx : closest_idx;
+#endif
 }
 
 // closest is INF (FLT_MAX) or an accepted t > 0.001: a positive normal float, whose predecessor is its
@@ -712,9 +726,18 @@ BRT_DEV bool scatter(const ScenePtrs& sc, f3& o, f3& d, float t, uint32_t idx, u
         const f3 p = mk3(px, py, pz);
         const bool ok = dot3(p, p) <= 1.0f;
         const f3 cand = acc + scale * p;
+#if BRT_EXEC_MOVES & 2
+        if (ok) {
+            acc = cand;
+            scale = m1.x;
+            need -= 1u;
+            asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(scale), "+v"(need));
+        }
+#else
         acc = mk3(ok ? cand.x : acc.x, ok ? cand.y : acc.y, ok ? cand.z : acc.z);
         scale = ok ? m1.x : scale;
         need -= ok ? 1u : 0u;
+#endif
     }
     if (COUNTERS) {   // booked by the first lane of the section, like prof_section
         const uint64_t m = __ballot(true);
