@@ -145,9 +145,11 @@ class RayTracingNode {
 public:
     explicit RayTracingNode(brt_ctx* ctx) : ctx_(ctx) {}
     // pipeline.rs:136-138
+    // (an empty b.bvh: the callee builds the tree itself -- binned SAH, the recommended path: include/bevyray_amd.h)
     void write_buffers(const Buffers& b) {
         check(brt_upload_scene(ctx_, b.models.data(), static_cast<uint32_t>(b.models.size()), b.materials.data(),
-                               static_cast<uint32_t>(b.materials.size()), b.bvh.data(), static_cast<uint32_t>(b.bvh.size())), ctx_);
+                               static_cast<uint32_t>(b.materials.size()), b.bvh.empty() ? nullptr : b.bvh.data(),
+                               static_cast<uint32_t>(b.bvh.size())), ctx_);
     }
     // Returns false when the pass is skipped the way the reference skips it (no camera extract,
     // empty buffers: pipeline.rs:82-151); throws Error for real failures.
@@ -165,6 +167,17 @@ public:
         destination.resize(static_cast<size_t>(width) * height * 4);
         check(brt_render(ctx_, &view->second, &window, view->first.level, width, height, raster_rgba, raster_depth,
                          destination.data(), flags, stats), ctx_);
+        return true;
+    }
+    // The same pass on an N-device context with the frame assembled ON THE FIRST DEVICE (brt_render_device: tiles by peer
+    // copy over xGMI, one de-interleave kernel): `d_destination` is a device pointer, e.g. the mapped colour target
+    // (pipeline.rs:191-203).  d_raster_* are optional device buffers on the first device.
+    bool run_device(const std::optional<std::pair<RaytraceLevelExtract, CameraExtract>>& view, const WindowExtract& window,
+                    uint32_t width, uint32_t height, const float* d_raster_rgba, const float* d_raster_depth, float* d_destination,
+                    void* hip_stream = nullptr, brt_stats* stats = nullptr, uint32_t flags = 0) {
+        if (!view) return false;
+        check(brt_render_device(ctx_, &view->second, &window, view->first.level, width, height, d_raster_rgba, d_raster_depth,
+                                d_destination, hip_stream, flags, stats), ctx_);
         return true;
     }
 private:
@@ -187,6 +200,9 @@ public:
         check(brt_host_alloc(ctx_, static_cast<uint64_t>(width) * height * 16, &p), ctx_);
         return static_cast<float*>(p);
     }
+    // the reading of `||` in raytrace.wgsl:269 (BRT_POLICY_OR_SHORT_CIRCUIT or 0); scheduling knobs (never change a pixel)
+    void set_policy(uint32_t flags) { check(brt_set_policy(ctx_, flags), ctx_); }
+    void set_tuning(const char* name, uint32_t value) { check(brt_set_tuning(ctx_, name, value), ctx_); }
     brt_ctx* context() { return ctx_; }
 private:
     brt_ctx* ctx_ = nullptr;

@@ -1,4 +1,4 @@
-//! UNVERIFIED SOURCE: written against `include/bevyray_amd.h` (BRT_ABI_VERSION 2), never compiled (no Rust
+//! UNVERIFIED SOURCE: written against `include/bevyray_amd.h` (BRT_ABI_VERSION 3), never compiled (no Rust
 //! toolchain in the build environment).  What IS compiled and tested against the same ABI: the ctypes binding
 //! `bevyray_amd/_lib.py` (every GPU test goes through it) and the C++ host `bevyray_amd/host/raytracing.hpp`.
 //!
@@ -6,7 +6,7 @@
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_void};
 
-pub const BRT_ABI_VERSION: u32 = 2;
+pub const BRT_ABI_VERSION: u32 = 3;
 pub const BRT_STRIP_ROWS: u32 = 8;
 
 pub const BRT_OK: i32 = 0;
@@ -24,6 +24,9 @@ pub const BRT_ERR_CAPACITY: i32 = -9;
 pub const BRT_FLAG_COUNTERS: u32 = 1;
 pub const BRT_FLAG_KERNEL_SIMPLE: u32 = 2;
 pub const BRT_FLAG_CALLER_STREAM: u32 = 4;
+
+/// brt_set_policy: the WGSL-spec (short-circuit) reading of `||` in raytrace.wgsl:269; default 0 = both operands evaluated
+pub const BRT_POLICY_OR_SHORT_CIRCUIT: u32 = 1;
 
 #[repr(C)]
 pub struct brt_ctx { _private: [u8; 0] }
@@ -44,6 +47,9 @@ extern "C" {
     /// replaces RaytracingPipeline::from_world (pipeline.rs:233-331)
     pub fn brt_create(device_ids: *const i32, n_devices: i32, out_ctx: *mut *mut brt_ctx) -> i32;
     pub fn brt_destroy(ctx: *mut brt_ctx) -> i32;
+    pub fn brt_set_policy(ctx: *mut brt_ctx, flags: u32) -> i32;
+    pub fn brt_set_tuning(ctx: *mut brt_ctx, name: *const c_char, value: u32) -> i32;
+    pub fn brt_get_tuning(ctx: *const brt_ctx, name: *const c_char, out_value: *mut u32, out_default: *mut u32) -> i32;
     /// replaces model_buffer / material_buffer / bvh_buffer .write_buffer (pipeline.rs:136-138)
     pub fn brt_upload_scene(ctx: *mut brt_ctx, models: *const c_void, n_models: u32, materials: *const c_void,
                             n_materials: u32, bvh_nodes: *const c_void, n_nodes: u32) -> i32;
@@ -58,12 +64,20 @@ extern "C" {
                                   width: u32, height: u32, part: u32, n_parts: u32, d_raster_rgba: *const f32,
                                   d_raster_depth: *const f32, d_out_tile: *mut f32, hip_stream: *mut c_void, flags: u32,
                                   stats_or_null: *mut brt_stats) -> i32;
+    /// the whole frame of an N-device context, assembled on its first device (peer copies over xGMI + one copy kernel);
+    /// replaces the pass on post_process.destination (pipeline.rs:191-217) for a single-process node
+    pub fn brt_render_device(ctx: *mut brt_ctx, camera80: *const c_void, window16: *const c_void, level: u32, width: u32,
+                             height: u32, d_raster_rgba: *const f32, d_raster_depth: *const f32, d_frame: *mut f32,
+                             hip_stream: *mut c_void, flags: u32, stats_or_null: *mut brt_stats) -> i32;
     pub fn brt_tile_rows(height: u32, n_parts: u32) -> u32;
     pub fn brt_deinterleave_device(ctx: *mut brt_ctx, d_tiles: *const f32, n_parts: u32, width: u32, height: u32,
                                    d_frame: *mut f32, hip_stream: *mut c_void, flags: u32) -> i32;
     /// replaces obvhs::ploc::build_ploc::<24> + flatten (extract.rs:315-332)
     pub fn brt_build_bvh(models: *const c_void, n_models: u32, out_nodes: *mut c_void, capacity: u32,
                          out_n_nodes: *mut u32) -> i32;
+    /// binned-SAH tree for the same node contract (what brt_upload_scene builds when bvh_nodes is null)
+    pub fn brt_build_bvh_sah(models: *const c_void, n_models: u32, out_nodes: *mut c_void, capacity: u32,
+                             out_n_nodes: *mut u32) -> i32;
     pub fn brt_build_bvh_device(ctx: *mut brt_ctx, models: *const c_void, n_models: u32, out_nodes: *mut c_void,
                                 capacity: u32, out_n_nodes: *mut u32, out_build_ms: *mut f64) -> i32;
     pub fn brt_validate_scene(models: *const c_void, n_models: u32, materials: *const c_void, n_materials: u32,

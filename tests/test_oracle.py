@@ -348,3 +348,36 @@ def test_short_circuit_policy_cannot_be_seen_on_the_benchmark_scenes(oracle):
         with oracle.policy(or_short_circuit=True):
             alt, c1 = oracle.render(b, lvl, cam, win, 240, 135)
         assert _moved(base, alt) == 0 and c0 == c1
+
+
+def test_compare_wgpu_frame_script_names_the_policy_of_a_dump(tmp_path):
+    """scripts/compare_wgpu_frame.py (the one-command wgpu comparison for a machine with a Rust toolchain, SURVEY 8(f)
+    rank 4) on dumps made from the ior < 1 policy fixture: a frame rendered under the short-circuit reading of `||` is
+    recognised as exactly that policy (f32 dump, bit for bit), a default-policy frame quantised to sRGB8 as the default."""
+    import subprocess
+    import sys
+    z = np.load(os.path.join(GOLDEN, "policy_frames.npz"))
+    g = lambda k: z[f"glass_tir.{k}"]
+    w, h = (int(x) for x in g("size"))
+    d = tmp_path / "dump"
+    d.mkdir()
+    for name, key in (("models.bin", "models"), ("materials.bin", "materials"), ("bvh.bin", "bvh"), ("camera.bin", "camera"),
+                      ("window.bin", "window"), ("level.bin", "level")):
+        g(key).tofile(str(d / name))
+    script = os.path.join(os.path.dirname(GOLDEN), "..", "scripts", "compare_wgpu_frame.py")
+    g("frame.or_short_circuit").astype(np.float32).tofile(str(d / "frame.bin"))
+    proc = subprocess.run([sys.executable, script, "--dir", str(d), "--width", str(w), "--height", str(h)], capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("MATCH")]
+    assert lines and all("short-circuits" in ln for ln in lines) and any("min/max = minnum, pow = mul" in ln for ln in lines)
+    assert any(ln.startswith("differs") and "default policy" in ln for ln in proc.stdout.splitlines())
+    # an 8-bit sRGB dump of the default frame
+    f = np.clip(np.nan_to_num(g("frame.default").astype(np.float64)), 0.0, 1.0)
+    enc = np.where(f <= 0.0031308, 12.92 * f, 1.055 * np.power(f, 1.0 / 2.4) - 0.055)
+    q = np.floor(enc * 255.0 + 0.5).astype(np.uint8)
+    q[..., 3] = 255
+    q.tofile(str(d / "frame8.bin"))
+    proc = subprocess.run([sys.executable, script, "--dir", str(d), "--width", str(w), "--height", str(h), "--frame", "frame8.bin",
+                           "--srgb8", "--tolerance", "0"], capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    assert any(ln.startswith("MATCH") and "default policy" in ln for ln in proc.stdout.splitlines())
