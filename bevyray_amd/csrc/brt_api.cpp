@@ -84,7 +84,7 @@ struct DeviceCtx {
 enum Knob : int {
     K_BOTTOM_UP, K_REFILL_MIN, K_WALK_EXIT, K_LEAF_VOTE, K_DRAIN_DONATE, K_POOL_ADOPT, K_WGQ_BATCH, K_LPT_LANE_PERMILLE, K_TUNABLE,
     K_FORCE_GLOBAL_SCENE, K_FORCE_LDS_TOP, K_BLOCK_THREADS, K_WG_PER_CU, K_POOL_CAP, K_LPT, K_LPT_SORT, K_LPT_SKY_SLACK, K_CRIT,
-    K_ORDER_ON_HOST, K_NO_LEAN, K_PREPASS_SPP, K_NO_DIRTY_TRACKING, K_CPU_BVH, K_PLOC_ONE_BLOCK_MAX, K_BVH_QUALITY, K_COOP_LANES, K_COUNT
+    K_ORDER_ON_HOST, K_NO_LEAN, K_PREPASS_SPP, K_NO_DIRTY_TRACKING, K_CPU_BVH, K_PLOC_ONE_BLOCK_MAX, K_BVH_QUALITY, K_COUNT
 };
 struct KnobDef { const char* name; uint32_t dflt; };
 constexpr KnobDef kKnobs[K_COUNT] = {
@@ -93,7 +93,7 @@ constexpr KnobDef kKnobs[K_COUNT] = {
     {"BRT_TUNABLE", 0}, {"BRT_FORCE_GLOBAL_SCENE", 0}, {"BRT_FORCE_LDS_TOP", 0}, {"BRT_BLOCK_THREADS", 0}, {"BRT_WG_PER_CU", 0},
     {"BRT_POOL_CAP", 384}, {"BRT_LPT", 1}, {"BRT_LPT_SORT", 1}, {"BRT_LPT_SKY_SLACK", 20}, {"BRT_CRIT", 1}, {"BRT_ORDER_ON_HOST", 0},
     {"BRT_NO_LEAN", 0}, {"BRT_PREPASS_SPP", 2}, {"BRT_NO_DIRTY_TRACKING", 0}, {"BRT_CPU_BVH", 0},
-    {"BRT_PLOC_ONE_BLOCK_MAX", kPlocOneBlockMax}, {"BRT_BVH_QUALITY", 1}, {"BRT_COOP_LANES", kCoopLanes}};
+    {"BRT_PLOC_ONE_BLOCK_MAX", kPlocOneBlockMax}, {"BRT_BVH_QUALITY", 1}};
 struct Knobs {
     uint32_t v[K_COUNT];
     Knobs() { for (int i = 0; i < K_COUNT; i++) v[i] = kKnobs[i].dflt; }
@@ -462,9 +462,6 @@ int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const fl
                                    ctx->knobs[K_NO_LEAN] == 0u;
                 tl.lean = !lean1 ? 0 : ((known && longest_bound < per_lane / 2) ? 2 : 1);
             }
-            // cooperative sweep for nearly empty waves (brt_trace.h coop_sweep): only on trees it is provably exact on
-            tl.frame.coop_lanes = dc.view.coop_spheres ? ctx->knobs[K_COOP_LANES] : 0u;
-            if (tl.frame.coop_lanes > 8u) tl.frame.coop_lanes = 8u;
             tl.scene_mode = lp.scene_mode;
             tl.scene.lds_pairs = lp.lds_pairs;
             tl.grid = lp.grid;
@@ -793,11 +790,10 @@ int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, co
 
     // one blob per device, sections 256-byte aligned
     struct Sec { const void* src; size_t bytes; size_t off; };
-    Sec secs[8] = {
+    Sec secs[5] = {
         {e.pairs.data(), e.pairs.size() * 4, 0}, {e.spheres.data(), e.spheres.size() * 4, 0},
         {e.sphere_material.data(), e.sphere_material.size() * 4, 0}, {e.materials.data(), e.materials.size() * 4, 0},
-        {e.leaf_table.data(), e.leaf_table.size() * 4, 0}, {e.coop_spheres.data(), e.coop_spheres.size() * 4, 0},
-        {e.coop_limit.data(), e.coop_limit.size() * 4, 0}, {e.coop_index.data(), e.coop_index.size() * 4, 0}};
+        {e.leaf_table.data(), e.leaf_table.size() * 4, 0}};
     size_t total = 0;
     for (auto& s : secs) { s.off = total; total += align256(s.bytes ? s.bytes : 16); }
 
@@ -822,9 +818,6 @@ int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, co
         v.desc16 = e.desc16 ? 1u : 0u;
         v.simple_tree = e.simple_tree ? 1u : 0u;
         v.boxes_ordered = e.boxes_ordered ? 1u : 0u;
-        v.coop_spheres = e.coop_ok ? reinterpret_cast<const float*>(dc.d_scene + secs[5].off) : nullptr;
-        v.coop_limit = e.coop_ok ? reinterpret_cast<const float*>(dc.d_scene + secs[6].off) : nullptr;
-        v.coop_index = e.coop_ok ? reinterpret_cast<const uint32_t*>(dc.d_scene + secs[7].off) : nullptr;
         dc.view = v;
     }
     for (auto& dc : ctx->devs) {

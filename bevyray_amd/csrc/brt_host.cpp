@@ -149,58 +149,6 @@ int32_t validate_and_encode(const Model* models, uint32_t n_models, const Materi
     e.stack_entries = std::min<uint32_t>(32u, max_leaf_depth + 1u);
     if (e.stack_entries < 2) e.stack_entries = 2;
     e.simple_tree = e.leaf_table.empty() && (max_leaf_depth + 1u < 31u);
-
-    // ---- cooperative sweep: is brute force over all spheres THE SAME FUNCTION as the reference's walk on this tree? ----
-    // The walk (raytrace.wgsl:313-362) returns the smallest accepted t, ties going to the leaf it reaches first; box tests
-    // only ever SKIP spheres.  So it equals "lexicographic minimum of (t, visit rank) over all spheres" exactly when no
-    // box test skips a sphere whose own test would have been accepted.  That holds in f32 arithmetic, with room to spare,
-    // when (a) every leaf box leaves a real gap `pad` around its sphere (the reference pads by 0.1, extract.rs:220-227;
-    // required here: >= 0.05) and every box encloses its children's boxes, and (b) the ray origin is close enough to
-    // every sphere that the rounding noise of the sphere test's discriminant (<= ~1.2e-6 |d|^2 |centre - origin|^2: three
-    // separately rounded dot products of magnitude |d|^2 |oc|^2) stays far below the gap: with m = (r + pad)^2 - r^2, a
-    // computed hit implies the true ray passes inside the (r + pad)-sphere the box encloses, and the computed t differs
-    // from the true entry by less than the distance between the two spheres along the ray, whenever noise < 0.17 m
-    // ("cooperative sweep").  (b) is checked per ray against coop_limit = m / 2e-5, i.e. noise <= 0.06 m.
-    e.coop_ok = false;
-    if (e.simple_tree && e.boxes_ordered && n_models <= 16384u) {
-        bool ok = true;
-        e.coop_spheres.clear(); e.coop_limit.clear(); e.coop_index.clear();
-        e.coop_spheres.reserve(4 * (size_t)n_models);
-        std::vector<uint32_t> st{0u};
-        while (!st.empty() && ok) {
-            const uint32_t n = st.back();
-            st.pop_back();
-            const BVHNode& nd = nodes[n];
-            if (nd.model_count > 0) {                      // simple tree: exactly one sphere
-                const Model& m = models[nd.index];
-                const double r = (double)m.radius;
-                double pad = 1e30;
-                for (int k = 0; k < 3; k++) {
-                    const double c = (double)m.position[k];
-                    if (!std::isfinite(c) || std::fabs(c) > 3e4) ok = false;
-                    pad = std::min(pad, std::min(c - r - (double)nd.bounds_min[k], (double)nd.bounds_max[k] - (c + r)));
-                }
-                if (!std::isfinite(r) || !(r > 1e-4) || r > 3e4 || !(pad >= 0.05)) ok = false;
-                if (!ok) break;
-                const double gap = (r + pad) * (r + pad) - r * r;
-                e.coop_spheres.push_back(m.position[0]); e.coop_spheres.push_back(m.position[1]); e.coop_spheres.push_back(m.position[2]);
-                e.coop_spheres.push_back(m.radius * m.radius);           // as e.spheres: raytrace.wgsl:375
-                e.coop_limit.push_back((float)(gap / 2e-5));
-                e.coop_index.push_back(nd.index);
-                continue;
-            }
-            const BVHNode& L = nodes[nd.index];
-            const BVHNode& R = nodes[nd.index + 1];
-            if (n != 0)                                     // the root's own box is never tested (raytrace.wgsl:316-322)
-                for (int k = 0; k < 3; k++)
-                    for (const BVHNode* c : {&L, &R})
-                        if (!(c->bounds_min[k] >= nd.bounds_min[k] && c->bounds_max[k] <= nd.bounds_max[k])) ok = false;
-            st.push_back(nd.index);                         // pushed first, reached last
-            st.push_back(nd.index + 1);
-        }
-        e.coop_ok = ok && e.coop_index.size() == n_models;
-    }
-    if (!e.coop_ok) { e.coop_spheres.clear(); e.coop_limit.clear(); e.coop_index.clear(); }
     return BRT_OK;
 }
 

@@ -26,13 +26,6 @@ struct EncodedScene {
     bool desc16 = false;                 // descriptors in the 16-bit form (brt_layout.h)
     bool simple_tree = false;            // single-sphere leaves only, depth below the stack-overflow rule
     bool boxes_ordered = false;          // every child box finite with min <= max
-    // cooperative sweep (brt_trace.h coop_sweep): spheres in the order in which the reference's walk would reach their leaves
-    // (right child first, raytrace.wgsl:329-341), the distance limit of each, and its model id; coop_ok: the tree is one the
-    // sweep is provably equivalent on (validate_and_encode)
-    std::vector<float> coop_spheres;     // 4 per sphere: centre, radius^2
-    std::vector<float> coop_limit;       // per sphere: largest |centre - ray origin|^2 for which the sweep may be used
-    std::vector<uint32_t> coop_index;    // per sphere: model id
-    bool coop_ok = false;
 };
 
 int32_t validate_and_encode(const Model* models, uint32_t n_models, const Material* materials, uint32_t n_materials,

@@ -151,18 +151,12 @@ struct DeviceSceneView {
     uint32_t simple_tree;    // 1: every leaf holds one sphere and max leaf depth + 1 < 31
     uint32_t boxes_ordered;  // 1: every child box is finite with min <= max
     uint32_t lds_pairs;      // SCENE_LDS_TOP: pair records [0, lds_pairs) are staged in LDS (set per launch)
-    // cooperative sweep (brt_trace.h): spheres in the reference walk's visit order, per-sphere distance limit, model ids;
-    // null when the tree does not qualify (brt_host.cpp validate_and_encode)
-    const float* coop_spheres;
-    const float* coop_limit;
-    const uint32_t* coop_index;
 };
 
 // Defaults of the tuning knobs in FrameParams.  The production kernel (TUNABLE = false) has them folded in as
 // constants and the lane queue compiled out; brt_api.cpp picks the TUNABLE instantiation when the environment
 // asks for anything else.
 constexpr uint32_t kRefillMin = 1, kWalkExitLanes = 12, kLeafVote = 12, kDrainDonate = 40, kPoolAdopt = 56;
-constexpr uint32_t kCoopLanes = 2;   // waves with at most this many rays to trace sweep all spheres cooperatively (FrameParams::coop_lanes)
 
 // Frame-uniform values, evaluated once on the host with the reference's expressions
 // (raytrace.wgsl:95,141-153,177-182).
@@ -210,8 +204,6 @@ struct FrameParams {
     const uint32_t* order_meta;      // order built on the GPU (brt_order.hip): [0] = critical tiles at its front (replaces crit_end)
     uint32_t tunable;                // 1: some knob above differs from its default -> the TUNABLE kernel instantiation
     uint32_t policy_flags;           // TUNABLE only; bit 0: `||` of raytrace.wgsl:269 short-circuits (alternative policy)
-    uint32_t coop_lanes;             // a wave with at most this many rays to trace sweeps all spheres with all 64 lanes instead of
-                                     // walking (0: never; set by launch_part when the scene qualifies)
 };
 
 }  // namespace brt

@@ -147,65 +147,6 @@ BRT_DEV void pool_unlock(uint32_t* ctl, uint32_t lane) {
 }
 BRT_DEV uint32_t pool_peek(const uint32_t* ctl, int i) { return __atomic_load_n(&ctl[i], __ATOMIC_RELAXED); }
 
-// ---- cooperative sweep ---------------------------------------------------------------------------------------------
-// A wave that has only one or two rays to trace (the last pixels of a frame, the longest pixel chains of config 3) still
-// pays ~60 instructions per node for each of the ~16 nodes of a walk, one node at a time.  On a tree that qualifies
-// (DeviceSceneView::coop_spheres != null: brt_host.cpp validate_and_encode has the argument) the walk is the same function
-// as "smallest accepted t over ALL spheres, ties to the sphere whose leaf the walk reaches first", so such a wave traces a
-// ray with all 64 lanes instead: lane l tests the spheres of visit ranks l, l + 64, ... with the shader's own arithmetic
-// (sphere_test, raytrace.wgsl:371-383 + 353-354), then the wave takes the lexicographic minimum of (t, rank).  Per ray it
-// checks what the equivalence needs of the ray: finite origin, finite non-zero 1/direction, dot(d, d) in [1e-20, 1e20],
-// and every sphere within its distance limit of the origin -- a ray that fails goes through the walk.
-// Returns true when the ray of lane `src` was traced (then that lane's WalkState holds the result, walk ended).
-template <bool D16, typename StackT>
-BRT_DEV bool coop_sweep(const DeviceSceneView& sv, uint32_t lane, uint32_t src, f3 o, f3 d, WalkState<StackT>& walk) {
-    auto bc = [&](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), (int)src)); };
-    const f3 ro = mk3(bc(o.x), bc(o.y), bc(o.z)), rd = mk3(bc(d.x), bc(d.y), bc(d.z));
-    const f3 rinv = mk3(bc(walk.inv.x), bc(walk.inv.y), bc(walk.inv.z));
-    const float ra = bc(walk.a);
-    bool ok = ray_is_safe(ro, rinv) && ra >= 1e-20f && ra <= 1e20f;
-    float best = kInf;
-    uint32_t best_rank = 0xffffffffu;
-    const float4* sph = reinterpret_cast<const float4*>(sv.coop_spheres);
-    const uint32_t last = sv.n_models - 1u;
-    for (uint32_t k0 = lane; k0 < sv.n_models; k0 += 256u) {
-        // four spheres per lane and trip: the eight loads (L2) go out together, ahead of the arithmetic
-        float4 s[4];
-        float lim[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t k = k0 + 64u * (uint32_t)j;
-            s[j] = sph[k < last ? k : last];
-            lim[j] = sv.coop_limit[k < last ? k : last];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t k = k0 + 64u * (uint32_t)j;
-            if (k <= last) {
-                const f3 oc = mk3(s[j].x - ro.x, s[j].y - ro.y, s[j].z - ro.z);
-                ok = ok && (dot3(oc, oc) <= lim[j]);
-                sphere_test(ro, rd, ra, s[j], k, best, best_rank);   // ranks ascend within a lane: strict `<` keeps the earliest
-            }
-        }
-    }
-    if (__ballot(!ok) != 0ull) return false;
-    float tmin = best;                                         // never NaN: kInf or an accepted t
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) tmin = min_f(tmin, __shfl_xor(tmin, off, 64));
-    uint32_t rmin = (best == tmin) ? best_rank : 0xffffffffu;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t other = (uint32_t)__shfl_xor((int)rmin, off, 64);
-        rmin = other < rmin ? other : rmin;
-    }
-    if (lane == src) {
-        walk.closest = tmin;
-        walk.closest_idx = tmin == kInf ? 0xffffffffu : sv.coop_index[rmin];
-        walk.cur = Desc<D16>::DONE;
-    }
-    return true;
-}
-
 // ---- persistent kernel -----------------------------------------------------------------------
 
 // MODE (brt_layout.h SceneMode): where pair records and spheres are read from.  SCENE_LDS: everything in LDS
@@ -509,22 +450,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         }
         if (fresh) walk_begin<D16>(walk, sc, sv.root_desc, stk, d);
         if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_pre += now - t_mark; t_mark = now; }
-        // a wave with one or two rays left sweeps the spheres with all its lanes instead of walking (coop_sweep above);
-        // every lane of the wave is here, also those without a pixel
-        bool swept_all = false;
-        if (!COUNTERS && SIMPLE && fp.coop_lanes != 0u) {
-            uint64_t todo = __ballot(active && walk_pending<D16, SIMPLE>(walk));
-            const uint32_t n_todo = (uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(todo));
-            if (n_todo != 0u && n_todo <= fp.coop_lanes) {
-                swept_all = true;
-                while (todo != 0ull) {
-                    const uint32_t src = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(todo));
-                    todo &= todo - 1ull;
-                    if (!coop_sweep<D16>(sv, lane, src, o, d, walk)) swept_all = false;
-                }
-            }
-        }
-        if (!swept_all && active) walk_run<64, COUNTERS, D16, SIMPLE, MODE>(sc, walk, stk, o, d, finish_walks ? 0u : walk_exit_lanes, leaf_vote, hc);
+        if (active) walk_run<64, COUNTERS, D16, SIMPLE, MODE>(sc, walk, stk, o, d, finish_walks ? 0u : walk_exit_lanes, leaf_vote, hc);
         in_flight = active && walk_pending<D16, SIMPLE>(walk);
         if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_walk += now - t_mark; t_mark = now; }
         const bool landed = active && !in_flight;      // walk finished: shade this segment now
