@@ -57,9 +57,7 @@ struct DeviceCtx {
     uint32_t order_lane = 0;                             // tiles of the lane queue; the rest of d_tile_order is the tile queue
     uint32_t order_crit = 0;                             // d_tile_order[0 .. crit) are the CRITICAL tiles
     size_t tile_order_cap = 0;
-    uint32_t* d_order_meta = nullptr;                    // order built on the GPU: [0] critical tiles, [1] longest pixel, [2] critical-pixel threshold
-    unsigned long long* d_crit_masks = nullptr;          // order built on the GPU: critical pixels of the i-th critical tile
-    size_t crit_masks_cap = 0;
+    uint32_t* d_order_meta = nullptr;                    // order built on the GPU: [0] critical tiles, [1] longest pixel
     char* d_order_scratch = nullptr;
     size_t order_scratch_cap = 0;
     bool order_on_device = false;                        // d_tile_order / d_order_meta were written by brt_order.hip
@@ -86,7 +84,7 @@ struct DeviceCtx {
 enum Knob : int {
     K_BOTTOM_UP, K_REFILL_MIN, K_WALK_EXIT, K_LEAF_VOTE, K_DRAIN_DONATE, K_POOL_ADOPT, K_WGQ_BATCH, K_LPT_LANE_PERMILLE, K_TUNABLE,
     K_FORCE_GLOBAL_SCENE, K_FORCE_LDS_TOP, K_BLOCK_THREADS, K_WG_PER_CU, K_POOL_CAP, K_LPT, K_LPT_SORT, K_LPT_SKY_SLACK, K_CRIT,
-    K_ORDER_ON_HOST, K_NO_LEAN, K_PREPASS_SPP, K_NO_DIRTY_TRACKING, K_CPU_BVH, K_PLOC_ONE_BLOCK_MAX, K_BVH_QUALITY, K_CRIT_SPLIT, K_COUNT
+    K_ORDER_ON_HOST, K_NO_LEAN, K_PREPASS_SPP, K_NO_DIRTY_TRACKING, K_CPU_BVH, K_PLOC_ONE_BLOCK_MAX, K_BVH_QUALITY, K_COUNT
 };
 struct KnobDef { const char* name; uint32_t dflt; };
 constexpr KnobDef kKnobs[K_COUNT] = {
@@ -95,7 +93,7 @@ constexpr KnobDef kKnobs[K_COUNT] = {
     {"BRT_TUNABLE", 0}, {"BRT_FORCE_GLOBAL_SCENE", 0}, {"BRT_FORCE_LDS_TOP", 0}, {"BRT_BLOCK_THREADS", 0}, {"BRT_WG_PER_CU", 0},
     {"BRT_POOL_CAP", 384}, {"BRT_LPT", 1}, {"BRT_LPT_SORT", 1}, {"BRT_LPT_SKY_SLACK", 20}, {"BRT_CRIT", 1}, {"BRT_ORDER_ON_HOST", 0},
     {"BRT_NO_LEAN", 0}, {"BRT_PREPASS_SPP", 2}, {"BRT_NO_DIRTY_TRACKING", 0}, {"BRT_CPU_BVH", 0},
-    {"BRT_PLOC_ONE_BLOCK_MAX", kPlocOneBlockMax}, {"BRT_BVH_QUALITY", 1}, {"BRT_CRIT_SPLIT", 1}};
+    {"BRT_PLOC_ONE_BLOCK_MAX", kPlocOneBlockMax}, {"BRT_BVH_QUALITY", 1}};
 struct Knobs {
     uint32_t v[K_COUNT];
     Knobs() { for (int i = 0; i < K_COUNT; i++) v[i] = kKnobs[i].dflt; }
@@ -334,7 +332,6 @@ bool is_pinned(const brt_ctx* ctx, const void* p, size_t bytes) {
 // BRT_LPT=0 disables (raster order); BRT_LPT_SORT, BRT_LPT_LANE_PERMILLE, BRT_LPT_SKY_SLACK, BRT_CRIT: see
 // update_tile_order.
 constexpr uint32_t kLptRefresh = 16, kLptAfterUpload = 4;
-constexpr size_t kTileCostWords = 2 + 64;   // per tile: ray sum, longest pixel, the rays of each of its 64 pixels
 bool lpt_enabled(const brt_ctx* ctx) { return ctx->knobs[K_LPT] != 0; }
 
 // The dispatch order only depends on which tiles hold long pixels: it survives a scene upload (an animated scene
@@ -355,8 +352,6 @@ void view_key_of(const brt_ctx* ctx, const FrameParams& fp, uint32_t key[8]) {
 int32_t attach_tile_order(brt_ctx* ctx, DeviceCtx& dc, FrameParams& fp, hipStream_t stream, bool may_measure) {
     fp.tile_order = nullptr;
     fp.tile_cost = nullptr;
-    fp.crit_masks = nullptr;
-    fp.pixel_cost = nullptr;
     if (!lpt_enabled(ctx) || fp.level == 0u) return BRT_OK;
     const uint32_t n_tiles = fp.local_strips * fp.tiles_x;
     uint32_t key[6];
@@ -368,14 +363,12 @@ int32_t attach_tile_order(brt_ctx* ctx, DeviceCtx& dc, FrameParams& fp, hipStrea
         fp.crit_begin = 0u;
         fp.crit_end = dc.order_crit * 64u;
         fp.order_meta = dc.order_on_device ? dc.d_order_meta : nullptr;   // then the kernel reads the critical count there
-        fp.crit_masks = (dc.order_on_device && ctx->knobs[K_CRIT_SPLIT] != 0u) ? dc.d_crit_masks : nullptr;
     }
     if (may_measure && (!match || ++dc.order_age >= kLptRefresh)) {
-        int32_t rc = ensure(ctx, &dc.d_tile_cost, &dc.tile_cost_cap, (size_t)n_tiles * kTileCostWords * 4);   // sums, maxima, 64 pixels per tile
+        int32_t rc = ensure(ctx, &dc.d_tile_cost, &dc.tile_cost_cap, (size_t)n_tiles * 8);   // sums, then maxima
         if (rc != BRT_OK) return rc;
-        HIP_TRY(ctx, hipMemsetAsync(dc.d_tile_cost, 0, (size_t)n_tiles * kTileCostWords * 4, stream));
+        HIP_TRY(ctx, hipMemsetAsync(dc.d_tile_cost, 0, (size_t)n_tiles * 8, stream));
         fp.tile_cost = dc.d_tile_cost;
-        fp.pixel_cost = dc.d_tile_cost + 2 * (size_t)n_tiles;
     }
     return BRT_OK;
 }
@@ -401,10 +394,8 @@ int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hi
         rc = ensure(ctx, &dc.d_order_scratch, &dc.order_scratch_cap, order_scratch_bytes(n_tiles));
         if (rc != BRT_OK) return rc;
         const uint64_t sky_cost = (uint64_t)64 * tp.sample_count * (1000 + tp.sky_slack_permille) / 1000;   // as build_tile_order
-        rc = ensure(ctx, &dc.d_crit_masks, &dc.crit_masks_cap, (size_t)n_tiles * 8);
-        if (rc != BRT_OK) return rc;
         HIP_TRY(ctx, launch_build_order(dc.d_tile_cost, dc.d_tile_cost + n_tiles, n_tiles, sky_cost, tp.grid_lanes, dc.d_tile_order,
-                                        dc.d_order_meta, dc.d_order_scratch, stream, fp.pixel_cost, dc.d_crit_masks));
+                                        dc.d_order_meta, dc.d_order_scratch, stream));
         HIP_TRY(ctx, hipEventRecord(dc.ev_last, stream));   // a later launch on another stream starts behind the order build
         dc.order_lane = 0;
         dc.order_crit = 0;
@@ -522,12 +513,10 @@ int32_t prepass_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const 
     pp.queue_lane = 0u;
     pp.crit_begin = pp.crit_end = 0u;
     const uint32_t n_tiles = pp.local_strips * pp.tiles_x;
-    int32_t rc = ensure(ctx, &dc.d_tile_cost, &dc.tile_cost_cap, (size_t)n_tiles * kTileCostWords * 4);
+    int32_t rc = ensure(ctx, &dc.d_tile_cost, &dc.tile_cost_cap, (size_t)n_tiles * 8);
     if (rc != BRT_OK) return rc;
-    HIP_TRY(ctx, hipMemsetAsync(dc.d_tile_cost, 0, (size_t)n_tiles * kTileCostWords * 4, stream));
+    HIP_TRY(ctx, hipMemsetAsync(dc.d_tile_cost, 0, (size_t)n_tiles * 8, stream));
     pp.tile_cost = dc.d_tile_cost;
-    pp.pixel_cost = dc.d_tile_cost + 2 * (size_t)n_tiles;
-    pp.crit_masks = nullptr;
     HIP_TRY(ctx, hipEventRecord(dc.ev_p0, stream));
     rc = launch_part(ctx, dc, pp, d_raster_rgba, d_raster_depth, d_out_tile, stream, flags & ~(uint32_t)BRT_FLAG_COUNTERS, false, nullptr);
     if (rc != BRT_OK) return rc;
@@ -586,7 +575,6 @@ void free_device(DeviceCtx& dc) {
     if (dc.d_tile_cost) (void)hipFree(dc.d_tile_cost);
     if (dc.d_tile_order) (void)hipFree(dc.d_tile_order);
     if (dc.d_order_meta) (void)hipFree(dc.d_order_meta);
-    if (dc.d_crit_masks) (void)hipFree(dc.d_crit_masks);
     if (dc.d_order_scratch) (void)hipFree(dc.d_order_scratch);
     if (dc.d_bvh_models) (void)hipFree(dc.d_bvh_models);
     if (dc.ev0) (void)hipEventDestroy(dc.ev0);
@@ -1242,15 +1230,6 @@ int32_t brt_debug_profile(brt_ctx* ctx, uint64_t* out64) {
     DeviceCtx& dc = ctx->devs[0];
     HIP_TRY(ctx, hipSetDevice(dc.device));
     HIP_TRY(ctx, hipMemcpy(out64, dc.d_ctrl, 512, hipMemcpyDeviceToHost));
-    // [40], [41]: critical tiles and longest pixel (rays) of the view's last MEASURED frame, when the order was built on the GPU
-    out64[40] = out64[41] = 0;
-    if (dc.order_valid && dc.order_on_device && dc.d_order_meta) {
-        uint32_t meta[2] = {0u, 0u};
-        HIP_TRY(ctx, hipStreamSynchronize(dc.stream));
-        HIP_TRY(ctx, hipMemcpy(meta, dc.d_order_meta, sizeof meta, hipMemcpyDeviceToHost));
-        out64[40] = meta[0];
-        out64[41] = meta[1];
-    }
     return BRT_OK;
 }
 

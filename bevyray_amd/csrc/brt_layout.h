@@ -202,12 +202,6 @@ struct FrameParams {
     const uint32_t* tile_order;
     uint32_t* tile_cost;
     const uint32_t* order_meta;      // order built on the GPU (brt_order.hip): [0] = critical tiles at its front (replaces crit_end)
-    // Critical PIXELS (orders built on the GPU): crit_masks[i] = the pixels of the i-th critical tile that are long chains
-    // themselves.  Such a tile is handed out twice -- queue slots [0, C) its critical pixels alone, [C, 2C) the others -- so
-    // that the frame's longest chains run in thin waves from the start.  pixel_cost (measuring frames): rays of every pixel,
-    // 64 per tile.  Either may be null.
-    const unsigned long long* crit_masks;
-    uint32_t* pixel_cost;
     uint32_t tunable;                // 1: some knob above differs from its default -> the TUNABLE kernel instantiation
     uint32_t policy_flags;           // TUNABLE only; bit 0: `||` of raytrace.wgsl:269 short-circuits (alternative policy)
 };

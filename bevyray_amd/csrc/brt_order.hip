@@ -56,26 +56,12 @@ __global__ __launch_bounds__(OB) void k_order_prepare(const uint32_t* __restrict
         if ((int)t < s) s_cnt[t] += s_cnt[t + s];
         __syncthreads();
     }
-    if (t == 0) { meta[0] = s_cnt[0]; meta[1] = longest_pixel; meta[2] = (uint32_t)(thr > 0xffffffffull ? 0xffffffffull : thr); }
+    if (t == 0) { meta[0] = s_cnt[0]; meta[1] = longest_pixel; }
 }
 
 __global__ void k_order_emit(const unsigned long long* __restrict__ keys_sorted, uint32_t n_tiles, uint32_t* __restrict__ order) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_tiles) order[i] = (uint32_t)(keys_sorted[i] & 0xffffffffull);
-}
-
-// Critical PIXELS.  order[0 .. meta[0]) are the critical tiles; of such a tile usually only a few pixels are the long
-// chains that make it critical.  masks[i] = the pixels of tile order[i] whose own ray count reached the threshold (bit =
-// slot inside the tile): the trace kernel hands such a tile out TWICE, once as the critical pixels alone (a thin wave
-// at raised priority: a lone lane needs ~4.3 us per ray, a full wave ~10-12 us per round) and once as the rest.
-__global__ __launch_bounds__(64) void k_order_masks(const uint32_t* __restrict__ order, const uint32_t* __restrict__ meta,
-                                                    const uint32_t* __restrict__ pixel_cost, unsigned long long* __restrict__ masks) {
-    const uint32_t i = blockIdx.x;
-    if (i >= meta[0]) return;
-    const uint32_t tile = order[i];
-    const bool crit = pixel_cost[(size_t)tile * 64u + threadIdx.x] >= meta[2] && meta[2] != 0u;
-    const unsigned long long m = __ballot(crit);
-    if (threadIdx.x == 0) masks[i] = m;
 }
 
 size_t order_temp_bytes(uint32_t n_tiles) {
@@ -89,8 +75,7 @@ size_t order_temp_bytes(uint32_t n_tiles) {
 size_t order_scratch_bytes(uint32_t n_tiles) { return 2 * ((size_t)n_tiles * 8 + 256) + order_temp_bytes(n_tiles) + 256; }
 
 hipError_t launch_build_order(const uint32_t* d_ray_sum, const uint32_t* d_longest, uint32_t n_tiles, uint64_t sky_cost,
-                              uint64_t grid_lanes, uint32_t* d_order, uint32_t* d_meta, char* d_scratch, hipStream_t stream,
-                              const uint32_t* d_pixel_cost, unsigned long long* d_masks) {
+                              uint64_t grid_lanes, uint32_t* d_order, uint32_t* d_meta, char* d_scratch, hipStream_t stream) {
     if (n_tiles == 0) return hipSuccess;
     auto take = [&](size_t bytes) { char* r = d_scratch; d_scratch += (bytes + 255) & ~(size_t)255; return r; };
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(take((size_t)n_tiles * 8));
@@ -102,8 +87,6 @@ hipError_t launch_build_order(const uint32_t* d_ray_sum, const uint32_t* d_longe
     hipError_t e = hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys, sorted, (int)n_tiles, 0, 64, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_order_emit, dim3((n_tiles + 255u) / 256u), dim3(256), 0, stream, sorted, n_tiles, d_order);
-    if (d_pixel_cost && d_masks)      // one 64-thread block per order slot; all but the first meta[0] return at once
-        hipLaunchKernelGGL(k_order_masks, dim3(n_tiles), dim3(64), 0, stream, d_order, d_meta, d_pixel_cost, d_masks);
     return hipGetLastError();
 }
 

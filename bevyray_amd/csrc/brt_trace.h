@@ -20,7 +20,6 @@ struct PixelCoord {
     uint32_t px, py;        // frame coordinates
     uint32_t local_row;     // row in the dense tile buffer
     uint32_t tile;          // tile id (strip * tiles_x + tx)
-    uint32_t slot;          // position inside the tile (row-major 8x8)
     bool inside;
 };
 BRT_DEV uint32_t slot_tile(const FrameParams& fp, uint32_t slot_tile_index) {
@@ -38,7 +37,6 @@ BRT_DEV PixelCoord slot_to_pixel(const FrameParams& fp, uint32_t q, uint32_t til
     c.local_row = strip * 8u + r;
     c.py = (strip * fp.n_parts + fp.part) * 8u + r;
     c.tile = tile;
-    c.slot = t;
     c.inside = (c.px < fp.width) && (c.py < fp.height);
     return c;
 }
@@ -63,7 +61,7 @@ struct PixelState {
     uint32_t sample;
     uint32_t out_index;     // pixel index in the tile buffer
     uint32_t frame_index;   // pixel index in the frame (raster inputs)
-    uint32_t tile;          // tile * 64 + slot inside the tile, for the cost measurement (per tile, per pixel)
+    uint32_t tile;          // for the per-tile cost measurement
     uint32_t rays_begin;    // lane's ray counter when the pixel started
 };
 
@@ -78,7 +76,7 @@ BRT_DEV void pixel_begin(const FrameParams& fp, const PixelCoord& c, PixelState&
     ps.sample = 0;
     ps.out_index = c.local_row * fp.width + c.px;
     ps.frame_index = c.py * fp.width + c.px;
-    ps.tile = c.tile * 64u + c.slot;
+    ps.tile = c.tile;
 }
 
 // PURE_LEVEL: the launch is known to be level 3 (Raytracing::Pure): no depth average, no raster inputs
@@ -251,9 +249,6 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     const uint32_t pool_adopt = TUNABLE ? fp.pool_adopt : kPoolAdopt;
     // queue slots [crit_begin, crit_end) hold the CRITICAL tiles; when the order was built on the GPU its count lives there too
     const uint32_t crit_end = LEAN == 2 ? 0u : (fp.order_meta ? fp.order_meta[0] * 64u : fp.crit_end);
-    // critical tiles that are handed out twice (FrameParams::crit_masks): slots [0, C) = their critical pixels, [C, 2C) = the rest
-    const uint32_t crit_dup = (LEAN != 2 && fp.crit_masks && fp.order_meta) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)fp.order_meta[0]) : 0u;
-    const uint32_t queue_total = fp.queue_size + crit_dup * 64u;
 
     PixelState ps;
     ps.sample = 0; ps.rng = 0; ps.out_index = 0; ps.frame_index = 0; ps.tile = 0; ps.rays_begin = 0;
@@ -280,11 +275,11 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
 
     bool tiles_done = false;          // the tile queue (slots FrameParams::queue_lane .. queue_size) is empty
     // lane takes queue slot q of `tile`
-    auto begin_pixel = [&](uint32_t q, uint32_t tile, bool is_crit) {
+    auto begin_pixel = [&](uint32_t q, uint32_t tile) {
         const PixelCoord c = slot_to_pixel<TUNABLE>(fp, q, tile);
         if (c.inside) {
             pixel_begin(fp, c, ps);
-            crit = is_crit;
+            crit = q >= fp.crit_begin && q < crit_end;
             ps.rays_begin = n_rays;
             if (fp.sample_count == 0) {
                 // 0/0 per channel.  The sums are compile-time zeros here; keep them opaque: hipcc 7.2
@@ -365,27 +360,18 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                     exhausted = true;
                     if (COUNTERS && t_empty == 0) t_empty = wall_clock64();
                 } else if (q != 0xffffffffu) {
-                    begin_pixel(q, tile, q >= fp.crit_begin && q < crit_end);
+                    begin_pixel(q, tile);
                 }
             }
         }
         // ---- nothing left to do (and the lane queue, if any, is empty): the next whole tile ----
-        if (queue_lane != queue_total && !tiles_done && !wave_crit && __ballot(active) == 0ull &&
+        if (queue_lane != fp.queue_size && !tiles_done && !wave_crit && __ballot(active) == 0ull &&
             __ballot(!exhausted) == 0ull) {
             uint32_t b = 0;
             if (lane == 0) b = atomicAdd(queue_counter + 1, 64u);
-            b = queue_lane + (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)b, 0, 64));
-            if (b < queue_total) {
-                uint32_t ti = b >> 6;                       // index into the dispatch order
-                unsigned long long mask = ~0ull;
-                bool crit_part = ti * 64u >= fp.crit_begin && ti * 64u < crit_end;
-                if (crit_dup != 0u) {
-                    if (ti < crit_dup) mask = fp.crit_masks[ti];                                        // the long chains of a critical tile
-                    else if (ti < 2u * crit_dup) { ti -= crit_dup; mask = ~fp.crit_masks[ti]; crit_part = false; }   // its other pixels
-                    else { ti -= crit_dup; crit_part = false; }
-                }
-                if ((mask >> lane) & 1ull) begin_pixel(ti * 64u + lane, slot_tile(fp, ti), crit_part);
-            } else {
+            b = queue_lane + (uint32_t)__shfl((int)b, 0, 64);
+            if (b < fp.queue_size) begin_pixel(b + lane, slot_tile(fp, b >> 6));
+            else {
                 tiles_done = true;
                 if (COUNTERS && t_empty == 0) t_empty = wall_clock64();
             }
@@ -417,7 +403,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                         active = false;
                     }
                     // (while the tile queue has tiles the wave stays: it takes one next round)
-                    const bool stay = queue_lane != queue_total && !tiles_done;
+                    const bool stay = queue_lane != fp.queue_size && !tiles_done;
                     if (lane == 0) { pool_ctl[1] = count + live; if (!stay) pool_ctl[2] = alive - 1u; }
                     leave = !stay;
                 } else if (count != 0u && live < 64u) {
@@ -438,7 +424,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                         active = true; in_flight = false; exhausted = true;
                     }
                     if (lane == 0) pool_ctl[1] = count - k;
-                } else if (live == 0u && count == 0u && (queue_lane == queue_total || tiles_done)) {
+                } else if (live == 0u && count == 0u && (queue_lane == fp.queue_size || tiles_done)) {
                     if (lane == 0) pool_ctl[2] = alive - 1u;
                     leave = true;
                 }
@@ -446,7 +432,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             }
             if (leave) break;
             finish_walks = wave_count(active) <= drain_donate;
-        } else if (__ballot(active) == 0 && (queue_lane == queue_total || tiles_done || __ballot(!exhausted) != 0ull)) {
+        } else if (__ballot(active) == 0 && (queue_lane == fp.queue_size || tiles_done || __ballot(!exhausted) != 0ull)) {
             break;
         }
         if (__ballot(active) == 0) continue;      // (pool on) nothing live but paths may still arrive
@@ -484,9 +470,8 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                 if (ps.sample == fp.sample_count) {
                     pixel_finish<LEAN != 0>(fp, ps, out_tile, raster_rgba, raster_depth);
                     if (!LEAN && fp.tile_cost) {
-                        atomicAdd(&fp.tile_cost[ps.tile >> 6], n_rays - ps.rays_begin);
-                        atomicMax(&fp.tile_cost[fp.local_strips * fp.tiles_x + (ps.tile >> 6)], n_rays - ps.rays_begin);
-                        if (fp.pixel_cost) fp.pixel_cost[ps.tile] = n_rays - ps.rays_begin;
+                        atomicAdd(&fp.tile_cost[ps.tile], n_rays - ps.rays_begin);
+                        atomicMax(&fp.tile_cost[fp.local_strips * fp.tiles_x + ps.tile], n_rays - ps.rays_begin);
                     }
                     active = false;
                 }
