@@ -1230,6 +1230,15 @@ int32_t brt_debug_profile(brt_ctx* ctx, uint64_t* out64) {
     DeviceCtx& dc = ctx->devs[0];
     HIP_TRY(ctx, hipSetDevice(dc.device));
     HIP_TRY(ctx, hipMemcpy(out64, dc.d_ctrl, 512, hipMemcpyDeviceToHost));
+    // [40], [41]: critical tiles and longest pixel (rays) of the view's last MEASURED frame, when the order was built on the GPU
+    out64[40] = out64[41] = 0;
+    if (dc.order_valid && dc.order_on_device && dc.d_order_meta) {
+        uint32_t meta[2] = {0u, 0u};
+        HIP_TRY(ctx, hipStreamSynchronize(dc.stream));
+        HIP_TRY(ctx, hipMemcpy(meta, dc.d_order_meta, sizeof meta, hipMemcpyDeviceToHost));
+        out64[40] = meta[0];
+        out64[41] = meta[1];
+    }
     return BRT_OK;
 }
 

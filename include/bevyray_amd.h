@@ -226,7 +226,8 @@ int32_t brt_debug_eval(brt_ctx* ctx, uint32_t op, const float* in16, float* out8
  * 7 ray round); wave timeline in 100 MHz ticks: [24] ~first start, [25] ~first / [26] last "lane queue empty",
  * [27] last end, [28] sum of (end - empty) over waves, [29] waves, [30]/[31] live lanes and rounds after "empty";
  * wave time summed over waves: [5] pixel refill, [6] walk loop, [7] shading, [43] drain logic + camera ray +
- * walk begin, [44] rejection-sampler loop.  out64 must hold 64 words. */
+ * walk begin, [44] rejection-sampler loop; [40] critical tiles and [41] longest pixel (rays) of the view's last measured frame.
+ * out64 must hold 64 words. */
 int32_t brt_debug_profile(brt_ctx* ctx, uint64_t* out64);
 
 /* Diagnostic: the dispatch order as the GPU builds it (bevyray_amd/csrc/brt_order.hip, used behind every measuring

@@ -15,9 +15,10 @@ ap.add_argument("--spp", type=int, default=64)
 ap.add_argument("--bounces", type=int, default=8)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--flags", type=int, default=0)
+ap.add_argument("--camera", default="cover")
 a = ap.parse_args()
 b = brt.generate_scene(a.scene, 1)
-lvl, cam, win = brt.cover_camera(a.w, a.h, a.spp, a.bounces)
+lvl, cam, win = (brt.rtiow_camera if a.camera == "rtiow" else brt.cover_camera)(a.w, a.h, a.spp, a.bounces)
 with brt.RaytracePlugin([0]) as p:
     p.node.write_buffers(b)
     for i in range(a.reps):
@@ -29,6 +30,7 @@ with brt.RaytracePlugin([0]) as p:
     print({k: v for k, v in p.node.last_stats.items()})
     prof = p.debug_profile()
     print("   timeline", getattr(p, "last_timeline", None))
+    print("   order", getattr(p, "last_order_meta", None))
     for k, (ex, ln) in prof.items():
         if ex:
             print(f"   section {k:9s} executions {ex:12d}  lanes {ln:14d}  avg lanes/exec {ln/ex:6.2f}")
