@@ -480,9 +480,9 @@ BRT_DEV void walk_loop_wave(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, ui
 #define BRT_WALK_FAST 1
 #endif
 // Interior steps for every lane whose `cur` is a pair record, repeated while more than `thresh` lanes are at one.
-// spa: LDS byte address of the lane's stack top (16-bit entries, 128 bytes apart); base: LDS byte address of the pair
-// records; gofs: the ray's granule offsets {x, y, z} inside a record.  The caller guarantees count(interior) > thresh.
-BRT_DEV void walk_interior_run_lds(uint32_t& cur, uint32_t& spa, uint32_t base, uint32_t gofs_x, uint32_t gofs_y, uint32_t gofs_z,
+// spa: LDS byte address of the lane's stack top (16-bit entries, 128 bytes apart); the pair records start at LDS address 0
+// (they are the first thing in the kernel's dynamic LDS; walk_run checks it and takes walk_loop_wave otherwise); gofs: the ray's granule offsets {x, y, z} inside a record.  The caller guarantees count(interior) > thresh.
+BRT_DEV void walk_interior_run_lds(uint32_t& cur, uint32_t& spa, uint32_t gofs_x, uint32_t gofs_y, uint32_t gofs_z,
                                    f3 o, f3 inv, float below, uint32_t thresh) {
     // The record lives in FIXED registers v[100:113] (x, y, z granules, descriptors): inline asm cannot name the single
     // registers of a 128-bit operand, and the slab arithmetic works on them in place.
@@ -498,7 +498,6 @@ BRT_DEV void walk_interior_run_lds(uint32_t& cur, uint32_t& spa, uint32_t base, 
         "s_mov_b64 exec, vcc\n"
         // record address and the five reads: {near L, near R, far L, far R} per axis, the two descriptors, the would-be pop
         "v_mul_lo_u32 %[t0], %[cur], %[rec_bytes]\n"
-        "v_add_u32_e32 %[t0], %[base], %[t0]\n"
         "v_add_u32_e32 %[tx], %[t0], %[gofs_x]\n"
         "v_add_u32_e32 %[ty], %[t0], %[gofs_y]\n"
         "v_add_u32_e32 %[tz], %[t0], %[gofs_z]\n"
@@ -551,7 +550,7 @@ BRT_DEV void walk_interior_run_lds(uint32_t& cur, uint32_t& spa, uint32_t base, 
         : [cur] "+v"(cur), [spa] "+v"(spa), [t0] "=&v"(t0), [tx] "=&v"(tx),
           [ty] "=&v"(ty), [tz] "=&v"(tz), [pop] "=&v"(pop), [cnt] "=&s"(cnt), [s_all] "=&s"(s_all), [s_take] "=&s"(s_take), [s_p2] "=&s"(s_p2),
           [s_any] "=&s"(s_any), [s_both] "=&s"(s_both)
-        : [base] "s"(base), [gofs_x] "v"(gofs_x), [gofs_y] "v"(gofs_y), [gofs_z] "v"(gofs_z), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z),
+        : [gofs_x] "v"(gofs_x), [gofs_y] "v"(gofs_y), [gofs_z] "v"(gofs_z), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z),
           [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [below] "v"(below), [thresh] "s"(thresh), [rec_bytes] "s"(rec_bytes)
         : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113");
 }
@@ -566,7 +565,6 @@ BRT_DEV void walk_loop_wave_lds(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv
     typedef float vf4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(3))) vf4 lds_f4;
     uint32_t spa = (uint32_t)(uintptr_t)(lds_stack*)sp;
-    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.near_base);
     const uint32_t sph = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.sph_base);
     float below = float_below(closest);
     for (;;) {
@@ -577,7 +575,7 @@ BRT_DEV void walk_loop_wave_lds(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv
         // leaf lanes instead; the rules differ only when a lane ends its walk inside the run, and only in when the leaf
         // step runs.
         const uint32_t thresh = (uint32_t)__builtin_amdgcn_readfirstlane((int)((n_walk > vote ? n_walk : vote) - vote));
-        if (wave_count(DS::is_interior(cur)) > thresh) walk_interior_run_lds(cur, spa, base, ox, oy, oz, o, inv, below, thresh);
+        if (wave_count(DS::is_interior(cur)) > thresh) walk_interior_run_lds(cur, spa, ox, oy, oz, o, inv, below, thresh);
         if (DS::is_leaf(cur)) {                            // raytrace.wgsl:325-326, 348-362: the leaf's sphere, then pop
             const uint32_t first = cur & DS::INDEX_MASK;
             const vf4 sv = *reinterpret_cast<lds_f4*>((uintptr_t)(sph + first * 16u));
@@ -627,9 +625,14 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, f3
         const uint32_t vote = (uint32_t)__builtin_amdgcn_readfirstlane((int)(leaf_vote < 1u ? 1u : leaf_vote));
         if (n_walking > exit_at) {
             if (__ballot(unsafe) == 0ull) {
-                if constexpr (BRT_WALK_FAST && MODE == SCENE_LDS && !COUNTERS && SIMPLE_TREE && D16)
-                    walk_loop_wave_lds<D16, SIMPLE_TREE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp, n, exit_at, vote, hc);
-                else
+                bool by_hand = false;
+                if constexpr (BRT_WALK_FAST && MODE == SCENE_LDS && !COUNTERS && SIMPLE_TREE && D16) {
+                    if (sc.near_base == 0u) {       // the records start at LDS address 0 (always, unless the kernel grows static LDS)
+                        by_hand = true;
+                        walk_loop_wave_lds<D16, SIMPLE_TREE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp, n, exit_at, vote, hc);
+                    }
+                }
+                if (!by_hand)
                     walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, false, MODE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp,
                                                                             n, exit_at, vote, hc);
             }
