@@ -479,34 +479,56 @@ BRT_DEV void walk_loop_wave(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, ui
 #ifndef BRT_WALK_FAST
 #define BRT_WALK_FAST 1
 #endif
-// Interior steps for every lane whose `cur` is a pair record, repeated while more than `thresh` lanes are at one.
-// spa: LDS byte address of the lane's stack top (16-bit entries, 128 bytes apart); the pair records start at LDS address 0
-// (they are the first thing in the kernel's dynamic LDS; walk_run checks it and takes walk_loop_wave otherwise); gofs: the ray's granule offsets {x, y, z} inside a record.  The caller guarantees count(interior) > thresh.
-BRT_DEV void walk_interior_run_lds(uint32_t& cur, uint32_t& spa, uint32_t gofs_x, uint32_t gofs_y, uint32_t gofs_z,
-                                   f3 o, f3 inv, float below, uint32_t thresh) {
-    // The record lives in FIXED registers v[100:113] (x, y, z granules, descriptors): inline asm cannot name the single
-    // registers of a 128-bit operand, and the slab arithmetic works on them in place.
-    uint32_t t0, tx, ty, tz, pop, cnt;
+// The whole wave-level walk loop (walk_loop_wave's nest: interior steps until `vote` lanes wait at a leaf, one leaf step,
+// until at most exit_at lanes still walk) as ONE block of hand-scheduled code.
+//   cur / spa     descriptor of the lane's current node (sign-extended 16-bit form: interior >= 0, leaf < -1, DONE = -1) and
+//                 LDS byte address of its stack top (16-bit entries, 128 bytes apart)
+//   gofs          the ray's granule offsets {x, y, z} inside a pair record; the records start at LDS address 0 (they are the
+//                 first thing in the kernel's dynamic LDS; walk_run checks it and takes walk_loop_wave otherwise)
+//   sph           LDS byte address of the spheres {centre, r^2}
+// The record and the sphere live in FIXED registers v[100:113]: inline asm cannot name the single registers of a 128-bit
+// operand, and the arithmetic works on them in place.
+// Interior step: raytrace.wgsl:327-342 + 387-398 (see walk_interior_step for the forms used: near / far planes by granule,
+// the three compares of the push rule as one).  Leaf step: raytrace.wgsl:348-362 + 371-383 -- the discriminant, then
+// hipcc's own correctly rounded sqrt and divide expansions, instruction for instruction as it emits them for sphere_test
+// (2^32 pre-scale below 2^-96, v_sqrt_f32 + two residual corrections, class fix-up; v_div_scale x2, v_rcp_f32 + one Newton step,
+// three fma steps, v_div_fmas, v_div_fixup), with the wait states its hazard recogniser would insert; the accept rule
+// t > 0.001 && t < closest moves t and the sphere id under EXEC.
+BRT_DEV void walk_wave_lds_asm(uint32_t& cur, uint32_t& spa, float& closest, uint32_t& closest_idx, uint32_t gofs_x, uint32_t gofs_y,
+                               uint32_t gofs_z, f3 o, f3 inv, f3 d, float a, uint32_t sph, uint32_t exit_at, uint32_t vote) {
+    uint32_t t0, tx, ty, tz, pop, cnt, nw, thr;
+    float below;
     uint64_t s_all, s_take, s_p2, s_any, s_both;
-    const uint32_t rec_bytes = PAIR_BYTES;
+    const uint32_t rec_bytes = PAIR_BYTES, c_tiny = 0x0f800000u /* 2^-96 */, c_eps = 0x3a83126fu /* 0.001f */, c_cls = 0x260u /* +-0, +inf */;
     asm volatile(
         "s_waitcnt lgkmcnt(0)\n"                                // nothing of the compiler's in flight: the counted waits below are exact
         "s_mov_b64 %[s_all], exec\n"
-        "v_cmp_lt_i32_e32 vcc, -1, %[cur]\n"                    // take: interior descriptors are >= 0
+        "v_add_u32_e32 %[below], -1, %[closest]\n"              // the largest float below closest (closest is FLT_MAX or an accepted t > 0)
+        // ---- outer loop: leave when at most exit_at lanes still walk -------------------------------------------------------
+        "3:\n"
+        "v_cmp_ne_u32_e32 vcc, -1, %[cur]\n"
+        "s_bcnt1_i32_b64 %[nw], vcc\n"
+        "s_cmp_le_u32 %[nw], %[exit_at]\n"
+        "s_cbranch_scc1 9f\n"
+        "s_max_u32 %[thr], %[nw], %[vote]\n"                    // interior steps while more than max(walking, vote) - vote lanes are at one
+        "s_sub_u32 %[thr], %[thr], %[vote]\n"
+        "v_cmp_lt_i32_e32 vcc, -1, %[cur]\n"                    // interior descriptors are >= 0
+        "s_bcnt1_i32_b64 %[cnt], vcc\n"
+        "s_cmp_le_u32 %[cnt], %[thr]\n"
+        "s_cbranch_scc1 5f\n"
+        // ---- interior steps ----------------------------------------------------------------------------------------------------
         "1:\n"
         "s_mov_b64 %[s_take], vcc\n"
         "s_mov_b64 exec, vcc\n"
-        // record address and the five reads: {near L, near R, far L, far R} per axis, the two descriptors, the would-be pop
         "v_mul_lo_u32 %[t0], %[cur], %[rec_bytes]\n"
         "v_add_u32_e32 %[tx], %[t0], %[gofs_x]\n"
         "v_add_u32_e32 %[ty], %[t0], %[gofs_y]\n"
         "v_add_u32_e32 %[tz], %[t0], %[gofs_z]\n"
-        "ds_read_b128 v[100:103], %[tx]\n"
+        "ds_read_b128 v[100:103], %[tx]\n"                      // { near L, near R, far L, far R } per axis
         "ds_read_b128 v[104:107], %[ty]\n"
         "ds_read_b128 v[108:111], %[tz]\n"
-        "ds_read_b64 v[112:113], %[t0] offset:96\n"
-        "ds_read_i16 %[pop], %[spa]\n"
-        // (b - o) * (1/d), raytrace.wgsl:388-390
+        "ds_read_b64 v[112:113], %[t0] offset:96\n"             // descriptors of L and R
+        "ds_read_i16 %[pop], %[spa]\n"                          // the would-be pop
         "s_waitcnt lgkmcnt(4)\n"
         "v_sub_f32_e32 v100, v100, %[ox]\n v_sub_f32_e32 v101, v101, %[ox]\n v_sub_f32_e32 v102, v102, %[ox]\n v_sub_f32_e32 v103, v103, %[ox]\n"
         "v_mul_f32_e32 v100, v100, %[ix]\n v_mul_f32_e32 v101, v101, %[ix]\n v_mul_f32_e32 v102, v102, %[ix]\n v_mul_f32_e32 v103, v103, %[ix]\n"
@@ -516,19 +538,18 @@ BRT_DEV void walk_interior_run_lds(uint32_t& cur, uint32_t& spa, uint32_t gofs_x
         "s_waitcnt lgkmcnt(2)\n"
         "v_sub_f32_e32 v108, v108, %[oz]\n v_sub_f32_e32 v109, v109, %[oz]\n v_sub_f32_e32 v110, v110, %[oz]\n v_sub_f32_e32 v111, v111, %[oz]\n"
         "v_mul_f32_e32 v108, v108, %[iz]\n v_mul_f32_e32 v109, v109, %[iz]\n v_mul_f32_e32 v110, v110, %[iz]\n v_mul_f32_e32 v111, v111, %[iz]\n"
-        // t_near = max(near x, near y, near z, denorm_min), t_far = min(far x, far y, far z, below(closest)) per child
         "v_max_f32_e32 v100, v100, v104\n"
         "v_max_f32_e32 v101, v101, v105\n"
         "v_min_f32_e32 v102, v102, v106\n"
         "v_min_f32_e32 v103, v103, v107\n"
-        "v_max3_f32 v100, v100, v108, 1\n"
+        "v_max3_f32 v100, v100, v108, 1\n"                      // t_near = max(.., denorm_min)
         "v_max3_f32 v101, v101, v109, 1\n"
-        "v_min3_f32 v102, v102, v110, %[below]\n"
+        "v_min3_f32 v102, v102, v110, %[below]\n"               // t_far = min(.., below(closest))
         "v_min3_f32 v103, v103, v111, %[below]\n"
         "s_waitcnt lgkmcnt(1)\n"                                // descriptors are here (the pop may still be on its way)
-        "ds_write_b16 %[spa], v112 offset:128\n"               // child L above the top: dead unless both are pushed
-        "v_cmp_le_f32_e32 vcc, v100, v102\n"                // p1: child L is pushed (raytrace.wgsl:331)
-        "v_cmp_le_f32_e64 %[s_p2], v101, v103\n"            // p2: child R is pushed (raytrace.wgsl:338)
+        "ds_write_b16 %[spa], v112 offset:128\n"                // child L above the top: dead unless both are pushed
+        "v_cmp_le_f32_e32 vcc, v100, v102\n"                    // p1: child L is pushed (raytrace.wgsl:331)
+        "v_cmp_le_f32_e64 %[s_p2], v101, v103\n"                // p2: child R is pushed (raytrace.wgsl:338)
         "s_or_b64 %[s_any], vcc, %[s_p2]\n"
         "s_and_b64 %[s_both], vcc, %[s_p2]\n"
         "s_waitcnt lgkmcnt(1)\n"                                // the pop is here (the store may still be on its way)
@@ -544,48 +565,105 @@ BRT_DEV void walk_interior_run_lds(uint32_t& cur, uint32_t& spa, uint32_t gofs_x
         "s_mov_b64 exec, %[s_all]\n"
         "v_cmp_lt_i32_e32 vcc, -1, %[cur]\n"
         "s_bcnt1_i32_b64 %[cnt], vcc\n"
-        "s_cmp_gt_u32 %[cnt], %[thresh]\n"
+        "s_cmp_gt_u32 %[cnt], %[thr]\n"
         "s_cbranch_scc1 1b\n"
+        // ---- one leaf step for every lane that waits at a leaf --------------------------------------------------------------
+        "5:\n"
+        "v_cmp_gt_i32_e32 vcc, -1, %[cur]\n"                    // leaf descriptors are < -1
+        "s_and_b64 exec, %[s_all], vcc\n"
+        "v_and_b32_e32 v112, 0x3fff, %[cur]\n"                  // the leaf's sphere
+        "v_lshl_add_u32 %[t0], v112, 4, %[sph]\n"
+        "ds_read_b128 v[100:103], %[t0]\n"                      // { centre, r^2 }
+        "ds_read_i16 %[cur], %[spa]\n"                          // pop
+        "v_add_u32_e32 %[spa], 0xffffff80, %[spa]\n"
+        "s_waitcnt lgkmcnt(1)\n"
+        "v_sub_f32_e32 v104, v100, %[ox]\n"                     // oc = centre - origin
+        "v_sub_f32_e32 v105, v101, %[oy]\n"
+        "v_sub_f32_e32 v106, v102, %[oz]\n"
+        "v_mul_f32_e32 v107, %[dx], v104\n"                     // h = dot(d, oc) = (dx ocx + dy ocy) + dz ocz
+        "v_mul_f32_e32 v108, %[dy], v105\n"
+        "v_mul_f32_e32 v104, v104, v104\n"                      // dot(oc, oc)
+        "v_mul_f32_e32 v105, v105, v105\n"
+        "v_add_f32_e32 v104, v104, v105\n"
+        "v_mul_f32_e32 v105, v106, v106\n"
+        "v_mul_f32_e32 v109, %[dz], v106\n"
+        "v_add_f32_e32 v107, v107, v108\n"
+        "v_add_f32_e32 v104, v105, v104\n"
+        "v_add_f32_e32 v107, v109, v107\n"                      // h
+        "v_sub_f32_e32 v104, v104, v103\n"                      // c = dot(oc, oc) - r^2
+        "v_mul_f32_e32 v105, v107, v107\n"                      // h h
+        "v_mul_f32_e32 v104, %[a], v104\n"                      // a c
+        "v_sub_f32_e32 v104, v105, v104\n"                      // discriminant
+        // sqrt(discriminant), correctly rounded (a negative one gives NaN, rejected below like the shader's -1)
+        "v_mul_f32_e32 v105, 0x4f800000, v104\n"
+        "v_cmp_gt_f32_e32 vcc, %[c_tiny], v104\n"
+        "s_nop 1\n"
+        "v_cndmask_b32_e32 v104, v104, v105, vcc\n"
+        "v_sqrt_f32_e32 v105, v104\n"
+        "s_nop 0\n"
+        "v_add_u32_e32 v106, -1, v105\n"
+        "v_fma_f32 v108, -v106, v105, v104\n"
+        "v_cmp_ge_f32_e64 %[s_p2], 0, v108\n"
+        "v_add_u32_e32 v108, 1, v105\n"
+        "s_nop 0\n"
+        "v_cndmask_b32_e64 v106, v105, v106, %[s_p2]\n"
+        "v_fma_f32 v105, -v108, v105, v104\n"
+        "v_cmp_lt_f32_e64 %[s_p2], 0, v105\n"
+        "s_nop 1\n"
+        "v_cndmask_b32_e64 v105, v106, v108, %[s_p2]\n"
+        "v_mul_f32_e32 v106, 0x37800000, v105\n"
+        "v_cndmask_b32_e32 v105, v105, v106, vcc\n"
+        "v_cmp_class_f32_e64 vcc, v104, %[c_cls]\n"
+        "s_nop 1\n"
+        "v_cndmask_b32_e32 v104, v105, v104, vcc\n"
+        "v_sub_f32_e32 v104, v107, v104\n"                      // h - sqrt(discriminant)
+        // ... / a, correctly rounded
+        "v_div_scale_f32 v105, %[s_p2], %[a], %[a], v104\n"
+        "v_rcp_f32_e32 v106, v105\n"
+        "s_nop 0\n"
+        "v_fma_f32 v107, -v105, v106, 1.0\n"
+        "v_fmac_f32_e32 v106, v107, v106\n"
+        "v_div_scale_f32 v107, vcc, v104, %[a], v104\n"
+        "v_mul_f32_e32 v108, v107, v106\n"
+        "v_fma_f32 v109, -v105, v108, v107\n"
+        "v_fmac_f32_e32 v108, v109, v106\n"
+        "v_fma_f32 v105, -v105, v108, v107\n"
+        "v_div_fmas_f32 v105, v105, v106, v108\n"
+        "v_div_fixup_f32 v104, v105, %[a], v104\n"              // t
+        // accepted iff t > 0.001 && t < closest (raytrace.wgsl:353-354; strict: the first sphere reached wins ties)
+        "v_cmp_lt_f32_e32 vcc, %[c_eps], v104\n"
+        "v_cmp_lt_f32_e64 %[s_p2], v104, %[closest]\n"
+        "s_and_b64 exec, vcc, %[s_p2]\n"
+        "v_mov_b32_e32 %[closest], v104\n"
+        "v_mov_b32_e32 %[cidx], v112\n"
+        "v_add_u32_e32 %[below], -1, v104\n"
+        "s_mov_b64 exec, %[s_all]\n"
+        "s_waitcnt lgkmcnt(0)\n"                                // the pop has long arrived; the next test reads it
+        "s_branch 3b\n"
+        "9:\n"
         "s_waitcnt lgkmcnt(0)\n"
-        : [cur] "+v"(cur), [spa] "+v"(spa), [t0] "=&v"(t0), [tx] "=&v"(tx),
-          [ty] "=&v"(ty), [tz] "=&v"(tz), [pop] "=&v"(pop), [cnt] "=&s"(cnt), [s_all] "=&s"(s_all), [s_take] "=&s"(s_take), [s_p2] "=&s"(s_p2),
-          [s_any] "=&s"(s_any), [s_both] "=&s"(s_both)
-        : [gofs_x] "v"(gofs_x), [gofs_y] "v"(gofs_y), [gofs_z] "v"(gofs_z), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z),
-          [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [below] "v"(below), [thresh] "s"(thresh), [rec_bytes] "s"(rec_bytes)
-        : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113");
+        : [cur] "+v"(cur), [spa] "+v"(spa), [closest] "+v"(closest), [cidx] "+v"(closest_idx), [below] "=&v"(below), [t0] "=&v"(t0),
+          [tx] "=&v"(tx), [ty] "=&v"(ty), [tz] "=&v"(tz), [pop] "=&v"(pop), [cnt] "=&s"(cnt), [nw] "=&s"(nw), [thr] "=&s"(thr),
+          [s_all] "=&s"(s_all), [s_take] "=&s"(s_take), [s_p2] "=&s"(s_p2), [s_any] "=&s"(s_any), [s_both] "=&s"(s_both)
+        : [gofs_x] "v"(gofs_x), [gofs_y] "v"(gofs_y), [gofs_z] "v"(gofs_z), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [ix] "v"(inv.x),
+          [iy] "v"(inv.y), [iz] "v"(inv.z), [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z), [a] "v"(a), [sph] "s"(sph), [exit_at] "s"(exit_at),
+          [vote] "s"(vote), [rec_bytes] "s"(rec_bytes), [c_tiny] "s"(c_tiny), [c_eps] "s"(c_eps), [c_cls] "s"(c_cls)
+        : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112",
+          "v113");
 }
 
 template <bool D16, bool SIMPLE_TREE, typename StackT>
 BRT_DEV void walk_loop_wave_lds(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, uint32_t ox, uint32_t oy, uint32_t oz,
                                 float& closest, uint32_t& closest_idx, uint32_t& cur, StackT*& sp, uint32_t& n,
                                 uint32_t exit_at, uint32_t vote, HitCounters& hc) {
-    using DS = Desc<D16>;
     static_assert(D16 && SIMPLE_TREE && sizeof(StackT) == 2, "LDS-resident simple tree: 16-bit descriptors, no overflow rule, no leaf table");
     typedef __attribute__((address_space(3))) StackT lds_stack;
-    typedef float vf4 __attribute__((ext_vector_type(4)));
-    typedef const __attribute__((address_space(3))) vf4 lds_f4;
     uint32_t spa = (uint32_t)(uintptr_t)(lds_stack*)sp;
     const uint32_t sph = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.sph_base);
-    float below = float_below(closest);
-    for (;;) {
-        const uint32_t n_walk = wave_count(cur != DS::DONE);
-        if (n_walk <= exit_at) break;
-        // Interior steps until at least `vote` of the walking lanes wait at a leaf, i.e. while more than n_walk - vote
-        // lanes are at interior nodes (or, when fewer than `vote` lanes walk, until none is).  walk_loop_wave counts the
-        // leaf lanes instead; the rules differ only when a lane ends its walk inside the run, and only in when the leaf
-        // step runs.
-        const uint32_t thresh = (uint32_t)__builtin_amdgcn_readfirstlane((int)((n_walk > vote ? n_walk : vote) - vote));
-        if (wave_count(DS::is_interior(cur)) > thresh) walk_interior_run_lds(cur, spa, ox, oy, oz, o, inv, below, thresh);
-        if (DS::is_leaf(cur)) {                            // raytrace.wgsl:325-326, 348-362: the leaf's sphere, then pop
-            const uint32_t first = cur & DS::INDEX_MASK;
-            const vf4 sv = *reinterpret_cast<lds_f4*>((uintptr_t)(sph + first * 16u));
-            const float4 s = make_float4(sv.x, sv.y, sv.z, sv.w);
-            cur = (uint32_t)(int32_t)*reinterpret_cast<lds_stack*>((uintptr_t)spa);
-            spa -= 128u;
-            sphere_test(o, d, a, s, first, closest, closest_idx);
-            below = float_below(closest);
-        }
-    }
+    // (the leaf step runs when at least `vote` of the lanes that walked at the last leaf step wait at a leaf -- walk_loop_wave
+    //  counts the leaf lanes instead; the rules differ only when a lane ends its walk inside a run of interior steps, and only
+    //  in when the leaf step runs)
+    walk_wave_lds_asm(cur, spa, closest, closest_idx, ox, oy, oz, o, inv, d, a, sph, exit_at, vote);
     sp = (StackT*)reinterpret_cast<lds_stack*>((uintptr_t)spa);
 }
 
