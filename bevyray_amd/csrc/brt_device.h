@@ -575,7 +575,6 @@ BRT_DEV void walk_wave_lds_asm(uint32_t& cur, uint32_t& spa, float& closest, uin
         "v_lshl_add_u32 %[t0], v112, 4, %[sph]\n"
         "ds_read_b128 v[100:103], %[t0]\n"                      // { centre, r^2 }
         "ds_read_i16 %[cur], %[spa]\n"                          // pop
-        "v_add_u32_e32 %[spa], 0xffffff80, %[spa]\n"
         "s_waitcnt lgkmcnt(1)\n"
         "v_sub_f32_e32 v104, v100, %[ox]\n"                     // oc = centre - origin
         "v_sub_f32_e32 v105, v101, %[oy]\n"
@@ -594,36 +593,35 @@ BRT_DEV void walk_wave_lds_asm(uint32_t& cur, uint32_t& spa, float& closest, uin
         "v_mul_f32_e32 v105, v107, v107\n"                      // h h
         "v_mul_f32_e32 v104, %[a], v104\n"                      // a c
         "v_sub_f32_e32 v104, v105, v104\n"                      // discriminant
-        // sqrt(discriminant), correctly rounded (a negative one gives NaN, rejected below like the shader's -1)
+        // sqrt(discriminant), correctly rounded: hipcc's expansion (a negative argument gives NaN, rejected below like the
+        // shader's -1).  Same operations on the same values as the compiler emits; the order is chosen so that every wait
+        // state its hazard recogniser fills with s_nop (VALU -> vcc / SGPR -> v_cndmask: 2, v_sqrt / v_rcp -> use: 1) holds
+        // an instruction that is needed anyway.
+        "v_cmp_gt_f32_e32 vcc, %[c_tiny], v104\n"               // below 2^-96: scale by 2^32 (vcc stays until the result is scaled back)
         "v_mul_f32_e32 v105, 0x4f800000, v104\n"
-        "v_cmp_gt_f32_e32 vcc, %[c_tiny], v104\n"
-        "s_nop 1\n"
+        "v_add_u32_e32 %[spa], 0xffffff80, %[spa]\n"            // (the pop's pointer move)
         "v_cndmask_b32_e32 v104, v104, v105, vcc\n"
-        "v_sqrt_f32_e32 v105, v104\n"
-        "s_nop 0\n"
-        "v_add_u32_e32 v106, -1, v105\n"
-        "v_fma_f32 v108, -v106, v105, v104\n"
+        "v_sqrt_f32_e32 v105, v104\n"                           // s
+        "v_cmp_class_f32_e64 %[s_both], v104, %[c_cls]\n"       // +-0 and +inf are their own roots
+        "v_add_u32_e32 v106, -1, v105\n"                        // s - 1 ulp
+        "v_add_u32_e32 v109, 1, v105\n"                         // s + 1 ulp
+        "v_fma_f32 v108, -v106, v105, v104\n"                   // x - (s - 1 ulp) s
+        "v_fma_f32 v110, -v109, v105, v104\n"                   // x - (s + 1 ulp) s
         "v_cmp_ge_f32_e64 %[s_p2], 0, v108\n"
-        "v_add_u32_e32 v108, 1, v105\n"
-        "s_nop 0\n"
+        "v_cmp_lt_f32_e64 %[s_any], 0, v110\n"
+        "s_nop 0\n"                                             // (the one wait state left over)
         "v_cndmask_b32_e64 v106, v105, v106, %[s_p2]\n"
-        "v_fma_f32 v105, -v108, v105, v104\n"
-        "v_cmp_lt_f32_e64 %[s_p2], 0, v105\n"
-        "s_nop 1\n"
-        "v_cndmask_b32_e64 v105, v106, v108, %[s_p2]\n"
+        "v_cndmask_b32_e64 v105, v106, v109, %[s_any]\n"
         "v_mul_f32_e32 v106, 0x37800000, v105\n"
         "v_cndmask_b32_e32 v105, v105, v106, vcc\n"
-        "v_cmp_class_f32_e64 vcc, v104, %[c_cls]\n"
-        "s_nop 1\n"
-        "v_cndmask_b32_e32 v104, v105, v104, vcc\n"
+        "v_cndmask_b32_e64 v104, v105, v104, %[s_both]\n"
         "v_sub_f32_e32 v104, v107, v104\n"                      // h - sqrt(discriminant)
-        // ... / a, correctly rounded
+        // ... / a, correctly rounded: hipcc's expansion
         "v_div_scale_f32 v105, %[s_p2], %[a], %[a], v104\n"
         "v_rcp_f32_e32 v106, v105\n"
-        "s_nop 0\n"
-        "v_fma_f32 v107, -v105, v106, 1.0\n"
-        "v_fmac_f32_e32 v106, v107, v106\n"
         "v_div_scale_f32 v107, vcc, v104, %[a], v104\n"
+        "v_fma_f32 v109, -v105, v106, 1.0\n"
+        "v_fmac_f32_e32 v106, v109, v106\n"
         "v_mul_f32_e32 v108, v107, v106\n"
         "v_fma_f32 v109, -v105, v108, v107\n"
         "v_fmac_f32_e32 v108, v109, v106\n"
