@@ -175,10 +175,16 @@ def main():
     def run_workload(wl, scene_kind, steps, warmup, counters=True):
         """Times `steps` frames of one workload; returns a dict (meaningful on every rank after the reductions)."""
         W, H, spp, bounces = wl["width"], wl["height"], wl["spp"], wl["bounces"]
-        buffers = brt.generate_scene(scene_kind, wl["scene_seed"])
+        scene = brt.generate_scene(scene_kind, wl["scene_seed"])
+        # The scene goes up WITHOUT a BVH: the callee builds the tree (binned SAH), the integration INTEGRATION.md recommends --
+        # the reference's own obvhs PLOC build (extract.rs:315-332) is then not needed at all.  `buffers` carries that same tree
+        # (brt_build_bvh_sah is the builder brt_upload_scene uses) for the CPU oracle; the caller's-PLOC-tree variant is timed
+        # below as an extra.
+        buffers = brt.Buffers(scene.models, scene.materials, brt.build_bvh_sah(scene.models))
+        upload = brt.Buffers(scene.models, scene.materials, None)
         cam_fn = brt.rtiow_camera if scene_kind == brt.SCENE_RTIOW_FINAL else brt.cover_camera   # configs 3 / 4: the book's view
         lvl, cam, win = cam_fn(W, H, spp, bounces, brt.Raytracing.Pure, wl["random_seed"])
-        node.write_buffers(buffers)             # scene resident in HBM before anything is timed
+        node.write_buffers(upload)              # scene resident in HBM before anything is timed
         rows = brt.tile_rows(H, world)
         tile = torch.zeros((rows, W, 4), dtype=torch.float32, device=dev)
         sync()                                  # the zero fill ran on torch's stream, the trace kernel has its own
@@ -210,7 +216,7 @@ def main():
         barrier()
         elapsed = all_max(time.perf_counter() - t0)
         total_rays = all_sum(rays)
-        res = {"W": W, "H": H, "spp": spp, "bounces": bounces, "buffers": buffers, "lvl": lvl, "cam": cam, "win": win,
+        res = {"W": W, "H": H, "spp": spp, "bounces": bounces, "buffers": buffers, "scene": scene, "upload": upload, "lvl": lvl, "cam": cam, "win": win,
                "frame": frame, "counted": counted, "elapsed": elapsed, "total_rays": total_rays, "steps": steps,
                "kernel_ms": float(np.mean(kernel_ms)), "kernel_ms_per_rank": all_list(float(np.mean(kernel_ms))),
                "rays_per_rank": all_list(rays / steps),
@@ -241,10 +247,17 @@ def main():
         extras["first_frame_prepass_ms"] = round(all_max(st1.get("prepass_ms", 0.0)), 3)
         extras["first_frame_call_wall_ms"] = round(all_max(st1["total_ms"]), 3)   # host wall time of that call (incl. building the order)
         extras["second_frame_ms"] = round(all_max(second), 3)
-        # (c) an animated scene: the reference re-extracts and re-uploads every frame (extract.rs:299-336, README.md:17);
+        # (c) the caller's own tree: the PLOC BVH that the reference's extract stage would hand over (extract.rs:315-332)
+        node.write_buffers(head["scene"])
+        ks = [step()[0]["kernel_ms"] for _ in range(8)]
+        extras["caller_ploc_tree_ms"] = round(all_max(float(np.median(ks[3:]))), 3)
+        node.write_buffers(head["upload"])
+        for _ in range(3):
+            step()
+        # (d) an animated scene: the reference re-extracts and re-uploads every frame (extract.rs:299-336, README.md:17);
         #     one sphere moves a little per frame, the caller's BVH is rebuilt by the callee (NULL BVH upload)
         import copy
-        moving = copy.deepcopy(head["buffers"])
+        moving = copy.deepcopy(head["scene"])
         ks, ups = [], []
         for i in range(12):
             moving.models["position"][7, 0] += np.float32(0.002)
@@ -254,7 +267,7 @@ def main():
             ks.append(step()[0]["kernel_ms"])
         extras["animated_scene_ms"] = [round(all_max(k), 3) for k in ks[4:]]
         extras["animated_scene_upload_wall_ms"] = round(float(np.median(ups)), 3)
-        node.write_buffers(head["buffers"])
+        node.write_buffers(head["upload"])
     cfg4 = None
     if not args.no_extras and world > 1:
         # config 2's longest pixel chains take ~5 ms whatever N is; BASELINE.json's own
@@ -277,6 +290,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if stub is None else "synthetic (STUB tracer: no rays traced)",
             "config": {"workload": "README cover scene 1920x1080, 64 spp, 8 bounces (BASELINE.json configs[1])",
                        "spheres": int(len(head["buffers"].models)), "bvh_nodes": int(len(head["buffers"].bvh)),
+                       "bvh": "built by the callee (brt_upload_scene without a BVH: binned SAH, INTEGRATION.md section 3); "
+                              "`caller_ploc_tree_ms` = the same frame in the caller's PLOC tree",
                        "scene_seed": WORKLOAD["scene_seed"], "random_seed": WORKLOAD["random_seed"], "level": "Pure",
                        "parallelism": f"interleaved 8-row strips over {world} GPU(s), one RCCL gather per frame"},
             "n_ranks_seen": dist.get_world_size() if world > 1 else 1,

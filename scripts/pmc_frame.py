@@ -22,7 +22,7 @@ def main():
     b = brt.generate_scene(scene, 1)
     lvl, cam, win = cam_fn(w, h, spp, bounces)
     with brt.RaytracePlugin([0]) as p:
-        p.node.write_buffers(b)
+        p.node.write_buffers(brt.Buffers(b.models, b.materials, None))   # as bench.py: the callee builds the tree
         out = p.alloc_frame(w, h)
         for i in range(frames):
             p.node.run(lvl, cam, win, w, h, out=out)
