@@ -520,22 +520,22 @@ BRT_DEV void walk_wave_lds_asm(uint32_t& cur, uint32_t& spa, float& closest, uin
         "1:\n"
         "s_mov_b64 %[s_take], vcc\n"
         "s_mov_b64 exec, vcc\n"
+        "ds_read_i16 %[pop], %[spa]\n"                          // the would-be pop: needs no address arithmetic, goes out first
         "v_mul_lo_u32 %[t0], %[cur], %[rec_bytes]\n"
         "v_add_u32_e32 %[tx], %[t0], %[gofs_x]\n"
-        "v_add_u32_e32 %[ty], %[t0], %[gofs_y]\n"
-        "v_add_u32_e32 %[tz], %[t0], %[gofs_z]\n"
         "ds_read_b128 v[100:103], %[tx]\n"                      // { near L, near R, far L, far R } per axis
+        "v_add_u32_e32 %[ty], %[t0], %[gofs_y]\n"
         "ds_read_b128 v[104:107], %[ty]\n"
+        "v_add_u32_e32 %[tz], %[t0], %[gofs_z]\n"
         "ds_read_b128 v[108:111], %[tz]\n"
         "ds_read_b64 v[112:113], %[t0] offset:96\n"             // descriptors of L and R
-        "ds_read_i16 %[pop], %[spa]\n"                          // the would-be pop
-        "s_waitcnt lgkmcnt(4)\n"
+        "s_waitcnt lgkmcnt(3)\n"
         "v_sub_f32_e32 v100, v100, %[ox]\n v_sub_f32_e32 v101, v101, %[ox]\n v_sub_f32_e32 v102, v102, %[ox]\n v_sub_f32_e32 v103, v103, %[ox]\n"
         "v_mul_f32_e32 v100, v100, %[ix]\n v_mul_f32_e32 v101, v101, %[ix]\n v_mul_f32_e32 v102, v102, %[ix]\n v_mul_f32_e32 v103, v103, %[ix]\n"
-        "s_waitcnt lgkmcnt(3)\n"
+        "s_waitcnt lgkmcnt(2)\n"
         "v_sub_f32_e32 v104, v104, %[oy]\n v_sub_f32_e32 v105, v105, %[oy]\n v_sub_f32_e32 v106, v106, %[oy]\n v_sub_f32_e32 v107, v107, %[oy]\n"
         "v_mul_f32_e32 v104, v104, %[iy]\n v_mul_f32_e32 v105, v105, %[iy]\n v_mul_f32_e32 v106, v106, %[iy]\n v_mul_f32_e32 v107, v107, %[iy]\n"
-        "s_waitcnt lgkmcnt(2)\n"
+        "s_waitcnt lgkmcnt(1)\n"
         "v_sub_f32_e32 v108, v108, %[oz]\n v_sub_f32_e32 v109, v109, %[oz]\n v_sub_f32_e32 v110, v110, %[oz]\n v_sub_f32_e32 v111, v111, %[oz]\n"
         "v_mul_f32_e32 v108, v108, %[iz]\n v_mul_f32_e32 v109, v109, %[iz]\n v_mul_f32_e32 v110, v110, %[iz]\n v_mul_f32_e32 v111, v111, %[iz]\n"
         "v_max_f32_e32 v100, v100, v104\n"
@@ -546,13 +546,12 @@ BRT_DEV void walk_wave_lds_asm(uint32_t& cur, uint32_t& spa, float& closest, uin
         "v_max3_f32 v101, v101, v109, 1\n"
         "v_min3_f32 v102, v102, v110, %[below]\n"               // t_far = min(.., below(closest))
         "v_min3_f32 v103, v103, v111, %[below]\n"
-        "s_waitcnt lgkmcnt(1)\n"                                // descriptors are here (the pop may still be on its way)
+        "s_waitcnt lgkmcnt(0)\n"                                // descriptors (and the pop, which went out first) are here
         "ds_write_b16 %[spa], v112 offset:128\n"                // child L above the top: dead unless both are pushed
         "v_cmp_le_f32_e32 vcc, v100, v102\n"                    // p1: child L is pushed (raytrace.wgsl:331)
         "v_cmp_le_f32_e64 %[s_p2], v101, v103\n"                // p2: child R is pushed (raytrace.wgsl:338)
         "s_or_b64 %[s_any], vcc, %[s_p2]\n"
         "s_and_b64 %[s_both], vcc, %[s_p2]\n"
-        "s_waitcnt lgkmcnt(1)\n"                                // the pop is here (the store may still be on its way)
         "s_andn2_b64 exec, %[s_take], %[s_any]\n"               // no child pushed: pop
         "v_mov_b32_e32 %[cur], %[pop]\n"
         "v_add_u32_e32 %[spa], 0xffffff80, %[spa]\n"
