@@ -109,6 +109,16 @@ BRT_DEV float sqrt_plain(float x) {
     return r;
 }
 
+// sqrt of three values at once (the sample colour, raytrace.wgsl:223): the short form when every active lane's
+// components are zero (sqrt_plain returns +-0 for +-0: v_sqrt_f32 does, and both residual tests are false) or in the plain range
+BRT_DEV f3 sqrt3(f3 c) {
+    const float ax = __builtin_fabsf(c.x), ay = __builtin_fabsf(c.y), az = __builtin_fabsf(c.z);
+    const float mx = max_f(max_f(ax, ay), az);
+    const bool plain = (min_f(min_f(ax, ay), az) >= 0x1p-80f && mx <= 0x1p80f) || mx == 0.0f;
+    if (wave_all(plain)) return mk3(sqrt_plain(c.x), sqrt_plain(c.y), sqrt_plain(c.z));
+    return mk3(__builtin_sqrtf(c.x), __builtin_sqrtf(c.y), __builtin_sqrtf(c.z));
+}
+
 BRT_DEV f3 normalize3(f3 v) {
 #if BRT_SHARED_RCP & 1
     // components in [2^-40, 2^39]  =>  dot in [2^-80, 2^80) and len in [max |v_i|, 2 max |v_i|): both plain
@@ -160,6 +170,71 @@ BRT_DEV f3 rng_unit_ball(uint32_t& state) {
         if (dot3(p, p) <= 1.0f) break;
     }
     return p;
+}
+
+// The rejection sampler of a ROUND by hand (random.wgsl:19-24 + raytrace.wgsl:238 / :285), for the lanes active at the call:
+// lanes of m2 need two balls (diffuse: acc = normal + ball, then + roughness * ball), lanes of m1 one (metal: acc = -0 + roughness * ball).
+// Every iteration draws a candidate p for each lane that still needs one and, where |p|^2 <= 1, does acc += scale * p.  What the
+// compiler's version (shade_landed, COUNTERS builds) spends per iteration beside the three draws -- four v_cndmask, a counter
+// with borrow, a compare on it -- is here: the 6 instructions of acc += scale * p under EXEC = accepted lanes, one v_mov for the
+// lanes that go from two needed to one, and the bookkeeping of who needs how many as two scalar masks (the scalar unit runs beside
+// the vector pipe: tests/tools/issue_bench.hip).  43 vector instructions per iteration instead of 50, none of them a 4-cycle select.
+// Per lane: the same draws and the same mul / add, in the same order.
+#ifndef BRT_BALL_ASM
+#define BRT_BALL_ASM 1
+#endif
+BRT_DEV void ball_loop_asm(uint32_t& rng, f3& acc, float scale, float rough, uint64_t m2, uint64_t m1) {
+    uint32_t t;
+    float x, y, z, q, r;
+    uint64_t s_all, s_up;
+    const uint32_t c_mul = 277803737u, c_2m31 = 0x30000000u /* 2^-31 */;
+#define BRT_RNG_DRAW(dst)                                                                                                   \
+    "v_add_u32_e32 %[rng], 0xd8e8c2ba, %[rng]\n"          /* random.wgsl:9: state + 747796405 + 2891336453 */             \
+    "v_lshrrev_b32_e32 %[t], 28, %[rng]\n"                                                                                  \
+    "v_add_u32_e32 %[t], 4, %[t]\n"                                                                                         \
+    "v_lshrrev_b32_e32 %[t], %[t], %[rng]\n"                                                                                \
+    "v_xor_b32_e32 %[rng], %[t], %[rng]\n"                                                                                  \
+    "v_mul_lo_u32 %[rng], %[rng], %[c_mul]\n"                                                                               \
+    "v_lshrrev_b32_e32 %[t], 22, %[rng]\n"                                                                                  \
+    "v_xor_b32_e32 %[rng], %[t], %[rng]\n"                                                                                  \
+    "v_cvt_f32_u32_e32 " dst ", %[rng]\n"                                                                                  \
+    "v_fma_f32 " dst ", " dst ", %[c_2m31], -1.0\n"       /* rng_ball_coord: 2 * (state * 2^-32) - 1, rounded once */
+    asm volatile(
+        "s_mov_b64 %[s_all], exec\n"
+        "s_or_b64 exec, %[m2], %[m1]\n"
+        "s_cbranch_execz 2f\n"
+        "1:\n"
+        BRT_RNG_DRAW("%[x]")
+        BRT_RNG_DRAW("%[y]")
+        BRT_RNG_DRAW("%[z]")
+        "v_mul_f32_e32 %[q], %[x], %[x]\n"                  // dot3(p, p) = (x*x + y*y) + z*z
+        "v_mul_f32_e32 %[r], %[y], %[y]\n"
+        "v_add_f32_e32 %[q], %[q], %[r]\n"
+        "v_mul_f32_e32 %[r], %[z], %[z]\n"
+        "v_add_f32_e32 %[q], %[q], %[r]\n"
+        "v_cmp_ge_f32_e32 vcc, 1.0, %[q]\n"                 // accepted (inactive lanes: 0)
+        "s_and_b64 %[s_up], %[m2], vcc\n"                   // two needed -> one
+        "s_andn2_b64 %[m1], %[m1], vcc\n"                   // one needed -> none
+        "s_andn2_b64 %[m2], %[m2], vcc\n"
+        "s_or_b64 %[m1], %[m1], %[s_up]\n"
+        "s_mov_b64 exec, vcc\n"
+        "v_mul_f32_e32 %[x], %[scale], %[x]\n"              // acc = acc + scale * p
+        "v_mul_f32_e32 %[y], %[scale], %[y]\n"
+        "v_mul_f32_e32 %[z], %[scale], %[z]\n"
+        "v_add_f32_e32 %[ax], %[ax], %[x]\n"
+        "v_add_f32_e32 %[ay], %[ay], %[y]\n"
+        "v_add_f32_e32 %[az], %[az], %[z]\n"
+        "s_mov_b64 exec, %[s_up]\n"
+        "v_mov_b32_e32 %[scale], %[rough]\n"                // the second ball is scaled by the roughness
+        "s_or_b64 exec, %[m2], %[m1]\n"                     // SCC: somebody still needs one
+        "s_cbranch_scc1 1b\n"
+        "2:\n"
+        "s_mov_b64 exec, %[s_all]\n"
+        : [rng] "+v"(rng), [ax] "+v"(acc.x), [ay] "+v"(acc.y), [az] "+v"(acc.z), [scale] "+v"(scale), [m2] "+s"(m2), [m1] "+s"(m1),
+          [t] "=&v"(t), [x] "=&v"(x), [y] "=&v"(y), [z] "=&v"(z), [q] "=&v"(q), [r] "=&v"(r), [s_all] "=&s"(s_all), [s_up] "=&s"(s_up)
+        : [rough] "v"(rough), [c_mul] "s"(c_mul), [c_2m31] "s"(c_2m31)
+        : "vcc", "scc", "memory");
+#undef BRT_RNG_DRAW
 }
 
 // raytrace.wgsl:387-398 with 1/d hoisted per ray.  Returns whether the child is pushed
@@ -230,7 +305,7 @@ struct HitCounters {
     uint32_t sec_exec[8], sec_lanes[8];
     unsigned long long ticks_ball;   // COUNTERS builds: wave time in the rejection-sampler loop (100 MHz ticks)
 };
-enum { SEC_INTERIOR = 0, SEC_LEAF, SEC_CAMERA, SEC_SCATTER, SEC_SKY, SEC_BALL, SEC_REFILL, SEC_ROUND };
+enum { SEC_INTERIOR = 0, SEC_LEAF, SEC_CAMERA, SEC_SCATTER, SEC_SKY, SEC_BALL, SEC_CAMERA_TOP, SEC_ROUND };   // SEC_CAMERA: camera rays made in shade_landed; _TOP: at the top of a round
 
 // Counts one execution of a code section and its active lanes.  May be called under divergent
 // control flow: the ballot only sees the lanes that reached the call; the first of them books it.
@@ -870,7 +945,9 @@ BRT_DEV uint32_t pixel_seed(const FrameParams& fp, float uvx, float uvy) {
 
 // raytrace.wgsl:139-156 with frame-uniform terms hoisted into FrameParams.
 // ndc0x = uv.x*2-1, ndc0y = 1-uv.y*2.
-BRT_DEV f3 camera_ray_dir(const FrameParams& fp, float ndc0x, float ndc0y, uint32_t& rng) {
+// camera_dir_raw: the direction before normalize() (the persistent kernel normalises it together with the
+// reflected / refracted directions of the same round: shade_landed, brt_trace.h)
+BRT_DEV f3 camera_dir_raw(const FrameParams& fp, float ndc0x, float ndc0y, uint32_t& rng) {
     const float rx = rng_float(rng) - 0.5f;
     const float ry = rng_float(rng) - 0.5f;
     const float ndc_x = ndc0x + fp.inv_width * rx;
@@ -880,7 +957,10 @@ BRT_DEV f3 camera_ray_dir(const FrameParams& fp, float ndc0x, float ndc0y, uint3
     const f3 cd = mk3(fp.cam_dir[0], fp.cam_dir[1], fp.cam_dir[2]);
     const f3 cr = mk3(fp.cam_right[0], fp.cam_right[1], fp.cam_right[2]);
     const f3 cu = mk3(fp.cam_up[0], fp.cam_up[1], fp.cam_up[2]);
-    return normalize3((cd + sx * cr) + sy * cu);
+    return (cd + sx * cr) + sy * cu;
+}
+BRT_DEV f3 camera_ray_dir(const FrameParams& fp, float ndc0x, float ndc0y, uint32_t& rng) {
+    return normalize3(camera_dir_raw(fp, ndc0x, ndc0y, rng));
 }
 
 // raytrace.wgsl:104-122: final colour of a pixel from the averaged sample colour/depth.

@@ -125,6 +125,173 @@ BRT_DEV bool shade_segment(const ScenePtrs& sc, const FrameParams& fp, f3& o, f3
     return ended;
 }
 
+// ---- the landed ray segments of a ROUND, for a divergent wave ------------------------------------------------
+// What shade_segment + scatter do for one ray (raytrace.wgsl:189-223, :231-299), then -- for the lanes whose sample ended
+// here and whose pixel has samples left -- the next sample's camera ray (:162, :175-186), arranged by what a wave pays:
+// a round of the persistent kernel has lanes in every state (on the cover frame ~25 of 64 end at the sky, ~38 scatter,
+// ~25 start a sample), and each divergent section costs the wave its full instruction count.  The shader has five
+// normalize() calls on a sample's way (camera ray, sky gradient, hit normal, reflected / glass direction); a lane is in
+// at most two of them per round, so TWO bodies serve all five:
+//   N1  normalize(hit ? position - centre : direction)        hit normal | sky gradient
+//   N2  normalize(metal ? reflect(d, n) : glass ? d : camera)  metal | glass | the next sample's camera ray
+// and the two RNG draws of the camera jitter follow the sample's last draw in the lane's own sequence, wherever the
+// sample ended.  Per lane: the shader's operations, operands and order -- only the company in the wave changes.
+//
+// Samples end EARLY (before N2: sky; diffuse absorbed or at the bounce limit; glass at the bounce limit, whose draw of
+// :269 is made first) or LATE (metal absorbed or at the limit -- `absorbed` needs N2 -- and glass at the limit under the
+// or-short-circuit policy): early ones get their camera ray in N2, late ones are flagged need_cam and get it at the top
+// of the next round (1 in ~40 samples on the cover frame).
+template <bool COUNTERS, int LEAN, bool TUNABLE>
+BRT_DEV void shade_landed(const ScenePtrs& sc, const FrameParams& fp, bool landed, float t, uint32_t idx, PixelState& ps,
+                          f3& o, f3& d, f3& tput, uint32_t& bounce, float& first_depth, bool& active, bool& need_cam,
+                          uint32_t& n_rays, HitCounters& hc, float* out_tile, const float* raster_rgba,
+                          const float* raster_depth) {
+    const bool osc = TUNABLE && (fp.policy_flags & 1u);      // alternative reading of :269 (fixtures only)
+    const bool hit = landed && t != kInf, sky = landed && t == kInf;
+    prof_section<COUNTERS>(hc, SEC_SCATTER, hit);
+    prof_section<COUNTERS>(hc, SEC_SKY, sky);
+    // a sample ends with linear colour c: :223, :165-166, then the pixel if that was its last sample
+    auto end_sample = [&](f3 c) {
+        ps.sum = ps.sum + sqrt3(c);                                                                   // :223, :165
+        if (!LEAN) ps.dsum = ps.dsum + (first_depth == kInf ? fp.fallback_far : first_depth);        // :166,219-221 (levels 1, 2 only)
+        ps.sample++;
+        bounce = 0;
+        need_cam = true;
+        if (ps.sample == fp.sample_count) {
+            pixel_finish<LEAN != 0>(fp, ps, out_tile, raster_rgba, raster_depth);
+            if (!LEAN && fp.tile_cost) {
+                atomicAdd(&fp.tile_cost[ps.tile], n_rays - ps.rays_begin);
+                atomicMax(&fp.tile_cost[fp.local_strips * fp.tiles_x + ps.tile], n_rays - ps.rays_begin);
+            }
+            active = false;
+        }
+    };
+    if (!landed) return;
+    n_rays++;
+    if (bounce == 0) first_depth = t;                                              // :193-195
+    // ---- N1 ----
+    // (state is updated IN PLACE and as early as its old value is dead -- o here, for every hit lane, whether its sample
+    // goes on or not: a conditional assignment at the end costs the wave a copy of every such value at each join)
+    f3 v1 = d;
+    if (hit) {
+        hc.hits++;
+        const float4 s = sc.spheres[idx];
+        o = mk3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);                      // ray_at, :130-132: the next segment's origin
+        v1 = mk3(o.x - s.x, o.y - s.y, o.z - s.z);                                 // :356
+    }
+    const f3 n1 = normalize3(v1);
+    // ---- hit: the material lottery and the balls (scatter(), brt_device.h) ----
+    // (kind, att, acc, ior, draw: only ever read for hit lanes -- deliberately left undefined for the others)
+    bool metal = false, glass = false, diffuse = false, absorbed = false;
+    f3 att, acc;
+    float ior, draw;
+    if (hit) {
+        const uint32_t mid = sc.sphere_material[idx];
+        const float4 m0 = sc.materials[2 * mid];      // base_color.rgb, metallic
+        const float4 m1 = sc.materials[2 * mid + 1];  // roughness, reflectance, ior, specular_transmission
+        metal = rng_float(ps.rng) < m0.w;                                          // :234
+        glass = !metal && (rng_float(ps.rng) < m1.w);                              // :249 (drawn only when not metal)
+        diffuse = !metal && !glass;
+        if (glass && !osc) draw = rng_float(ps.rng);                               // :269, default policy: always drawn
+        ior = m1.z;
+        att = glass ? mk3(1.0f, 1.0f, 1.0f) : mk3(m0.x, m0.y, m0.z);
+        uint32_t need = metal ? 1u : (diffuse ? 2u : 0u);
+        acc = diffuse ? n1 : mk3(-0.0f, -0.0f, -0.0f);
+        float scale = diffuse ? 1.0f : m1.x;
+        unsigned long long t_ball = 0;
+        if (COUNTERS) t_ball = wall_clock64();
+        if (BRT_BALL_ASM && !COUNTERS) {
+            ball_loop_asm(ps.rng, acc, scale, m1.x, __builtin_amdgcn_ballot_w64(diffuse), __builtin_amdgcn_ballot_w64(metal));
+            need = 0u;
+        }
+        while (need != 0u) {                                                      // random.wgsl:19-24
+            if (COUNTERS) prof_section<COUNTERS>(hc, SEC_BALL, true);
+            const float px = rng_ball_coord(ps.rng);
+            const float py = rng_ball_coord(ps.rng);
+            const float pz = rng_ball_coord(ps.rng);
+            const f3 p = mk3(px, py, pz);
+            const bool ok = dot3(p, p) <= 1.0f;
+            const f3 cand = acc + scale * p;
+            acc = mk3(ok ? cand.x : acc.x, ok ? cand.y : acc.y, ok ? cand.z : acc.z);
+            scale = ok ? m1.x : scale;
+            need -= ok ? 1u : 0u;
+        }
+        if (COUNTERS) {   // booked by the first lane of the section, like prof_section
+            const uint64_t m = __ballot(true);
+            if (mbcnt64(m) == 0u) hc.ticks_ball += wall_clock64() - t_ball;
+        }
+        if (diffuse) {                                                            // :281-297
+            const float eps = 1e-8f;
+            if (__builtin_fabsf(acc.x) < eps && __builtin_fabsf(acc.y) < eps && __builtin_fabsf(acc.z) < eps) acc = n1;
+            absorbed = dot3(acc, n1) < 0.0f;
+        }
+    }
+    // ---- early ends ----
+    const bool limit = hit && bounce >= fp.bounce_count;        // :189: this was the last segment the loop allows
+    const bool early = sky || (diffuse && (absorbed || limit)) || (glass && limit && !osc);
+    bool cam = false;
+    f3 cdir;
+    if (early) {
+        f3 c;
+        if (sky) {
+            const float a = 0.5f * (n1.y + 1.0f);                                  // :364-369
+            const float b = 1.0f - a;
+            c = tput * mk3(b * 1.0f + a * 0.5f, b * 1.0f + a * 0.7f, b * 1.0f + a * 1.0f);
+        } else if (absorbed) {
+            c = tput * mk3(0.0f, 0.0f, 0.0f);                                      // :207-209: light stays 0
+        } else {
+            c = mk3(0.0f, 0.0f, 0.0f);                                             // :215-217: throughput 0 (x light 0)
+        }
+        end_sample(c);
+        cam = active;
+        if (cam) {
+            prof_section<COUNTERS>(hc, SEC_CAMERA, true);
+            cdir = camera_dir_raw(fp, ps.ndc0x, ps.ndc0y, ps.rng);                 // :162 + :175-186
+        }
+    }
+    // ---- N2 ----
+    const bool second = (metal || glass) && !early;
+    if (second || cam) {
+        const float dn = dot3(d, n1);                                             // :358 front_face (incoming direction); reflect3
+        f3 v2 = metal ? d - (2.0f * dn) * n1 : d;                                 // :238 reflect() / :261
+        if (cam) v2 = cdir;
+        const f3 u = normalize3(v2);
+        if (cam) {
+            d = u;                      // (origin, throughput, first depth of the new sample: top of the next round)
+            need_cam = false;
+        } else if (metal) {                                                       // :234-245
+            d = u + acc;
+            absorbed = dot3(d, n1) < 0.0f;
+        } else {                                                                  // glass, :249-280
+            const float ri = dn < 0.0f ? (1.0f / ior) : ior;
+            const float cos_theta = min_f(dot3(neg3(u), n1), 1.0f);
+            const float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+            const bool cannot_refract = ri * sin_theta > 1.0f;
+            const float refl = schlick(cos_theta, ri);
+            bool reflects = cannot_refract;
+            if (osc) {
+                if (!cannot_refract) reflects = refl > rng_float(ps.rng);
+            } else {
+                reflects = reflects || (refl > draw);
+            }
+            d = reflects ? reflect3(u, n1) : refract3(u, n1, ri);
+        }
+    }
+    // ---- the paths that go on: next segment from the hit point; late ends ----
+    if (hit && !early) {
+        if (diffuse) d = acc;
+        bool late = absorbed;                                                     // metal only
+        f3 c = tput * mk3(0.0f, 0.0f, 0.0f);
+        if (!absorbed) {
+            tput = tput * att;                                                    // :211
+            bounce++;
+            late = bounce > fp.bounce_count;                                      // loop exit, :189
+            if (late) c = mk3(0.0f, 0.0f, 0.0f);                                  // :215-217
+        }
+        if (late) end_sample(c);
+    }
+}
+
 // ---- drain pool ------------------------------------------------------------------------------
 // When the pixel queue is empty a wave's lanes run out of pixels one by one, but a round costs the
 // wave the same instructions with 5 live lanes as with 60: on the cover frame 18 % of all rounds were
@@ -259,6 +426,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     bool active = false;
     bool exhausted = !TUNABLE;        // the lane queue has nothing (more) for this lane; without a lane queue: from the start
     bool in_flight = false;           // this lane's walk was suspended by walk_run's early exit
+    bool need_cam = false;            // this lane's next segment is a camera ray that shade_landed has not made yet (new pixel, late end)
     bool crit = false;                // this lane's pixel is one of the frame's longest chains (FrameParams::crit_*)
     bool wave_crit = false;
     WalkState<StackT> walk;
@@ -287,7 +455,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                 // level-1/2 result (found by scripts/fuzz_parity.py; tests: sample_count 0).
                 asm volatile("" : "+v"(ps.sum.x), "+v"(ps.sum.y), "+v"(ps.sum.z), "+v"(ps.dsum));
                 pixel_finish<LEAN != 0>(fp, ps, out_tile, raster_rgba, raster_depth);
-            } else { active = true; bounce = 0; }
+            } else { active = true; bounce = 0; need_cam = true; }
         }
     };
 
@@ -399,7 +567,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                                              __uint_as_float(LEAN ? 0u : ps.tile), __uint_as_float(LEAN ? 0u : n_rays - ps.rays_begin));
                         rec[3] = make_float4(o.x, o.y, o.z, d.x);
                         rec[4] = make_float4(d.y, d.z, tput.x, tput.y);
-                        rec[5] = make_float4(tput.z, __uint_as_float(bounce), first_depth, __uint_as_float(crit ? 1u : 0u));
+                        rec[5] = make_float4(tput.z, __uint_as_float(bounce), first_depth, __uint_as_float((crit ? 1u : 0u) | (need_cam ? 2u : 0u)));
                         active = false;
                     }
                     // (while the tile queue has tiles the wave stays: it takes one next round)
@@ -420,7 +588,8 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                         ps.out_index = __float_as_uint(r2.x); ps.frame_index = __float_as_uint(r2.y);
                         if (!LEAN) { ps.tile = __float_as_uint(r2.z); ps.rays_begin = n_rays - __float_as_uint(r2.w); }
                         o = mk3(r3.x, r3.y, r3.z); d = mk3(r3.w, r4.x, r4.y); tput = mk3(r4.z, r4.w, r5.x);
-                        bounce = __float_as_uint(r5.y); first_depth = r5.z; crit = __float_as_uint(r5.w) != 0u;
+                        bounce = __float_as_uint(r5.y); first_depth = r5.z;
+                        crit = (__float_as_uint(r5.w) & 1u) != 0u; need_cam = (__float_as_uint(r5.w) & 2u) != 0u;
                         active = true; in_flight = false; exhausted = true;
                     }
                     if (lane == 0) pool_ctl[1] = count - k;
@@ -440,13 +609,17 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         prof_section<COUNTERS>(hc, SEC_ROUND, active);
         if (COUNTERS && __ballot(exhausted) != 0ull) drain_lane_rounds += (unsigned long long)__popcll(__ballot(active)) | (1ull << 32);
         const bool fresh = active && !in_flight;       // starts a ray segment in this round
-        prof_section<COUNTERS>(hc, SEC_CAMERA, fresh && bounce == 0);
+        prof_section<COUNTERS>(hc, SEC_CAMERA_TOP, fresh && need_cam);
         if (fresh && bounce == 0) {
-            // new sample: raytrace.wgsl:162 + :175-186
-            d = camera_ray_dir(fp, ps.ndc0x, ps.ndc0y, ps.rng);
+            // the first segment of a sample, raytrace.wgsl:175-186; its direction (:162) was made by shade_landed when the previous
+            // sample ended, unless this is the pixel's first sample or that one ended late
             o = mk3(fp.cam_pos[0], fp.cam_pos[1], fp.cam_pos[2]);
             tput = mk3(1.0f, 1.0f, 1.0f);
             first_depth = kInf;
+            if (need_cam) {
+                d = camera_ray_dir(fp, ps.ndc0x, ps.ndc0y, ps.rng);
+                need_cam = false;
+            }
         }
         if (fresh) walk_begin<D16>(walk, sc, sv.root_desc, stk, d);
         if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_pre += now - t_mark; t_mark = now; }
@@ -456,27 +629,8 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         const bool landed = active && !in_flight;      // walk finished: shade this segment now
         const float t = walk.closest;
         const uint32_t idx = walk.closest_idx;
-        prof_section<COUNTERS>(hc, SEC_SCATTER, landed && t != kInf);
-        prof_section<COUNTERS>(hc, SEC_SKY, landed && t == kInf);
-        if (landed) {
-            n_rays++;
-            f3 color;
-            if (shade_segment<COUNTERS>(sc, fp, o, d, tput, bounce, first_depth, t, idx, ps.rng, color, hc,
-                                        TUNABLE && (fp.policy_flags & 1u))) {
-                ps.sum = ps.sum + color;                                                   // :165
-                if (!LEAN) ps.dsum = ps.dsum + (first_depth == kInf ? fp.fallback_far : first_depth); // :166,219-221 (levels 1, 2 only)
-                ps.sample++;
-                bounce = 0;
-                if (ps.sample == fp.sample_count) {
-                    pixel_finish<LEAN != 0>(fp, ps, out_tile, raster_rgba, raster_depth);
-                    if (!LEAN && fp.tile_cost) {
-                        atomicAdd(&fp.tile_cost[ps.tile], n_rays - ps.rays_begin);
-                        atomicMax(&fp.tile_cost[fp.local_strips * fp.tiles_x + ps.tile], n_rays - ps.rays_begin);
-                    }
-                    active = false;
-                }
-            }
-        }
+        shade_landed<COUNTERS, LEAN, TUNABLE>(sc, fp, landed, t, idx, ps, o, d, tput, bounce, first_depth, active, need_cam, n_rays, hc,
+                                              out_tile, raster_rgba, raster_depth);
     }
 
     // ---- counters: one atomic per wave ----

@@ -339,7 +339,7 @@ class RaytracePlugin:
         """Lane-utilisation profile of the last FLAG_COUNTERS launch: section -> (executions, lanes)."""
         raw = (C.c_uint64 * 64)()
         _lib.check(self._lib.brt_debug_profile(self._ctx, raw), self._ctx)
-        names = ["interior", "leaf", "camera", "scatter", "sky", "ball", "sec6", "round"]
+        names = ["interior", "leaf", "camera", "scatter", "sky", "ball", "camera_top", "round"]
         prof = {n: (int(raw[8 + 2 * k]), int(raw[9 + 2 * k])) for k, n in enumerate(names)}
         # wave time stamps (100 MHz wall clock): first start, first / last "pixel queue empty", last end
         self.last_order_meta = {"critical_tiles": int(raw[40]), "longest_pixel_rays": int(raw[41])}
