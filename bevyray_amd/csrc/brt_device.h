@@ -775,14 +775,11 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, f3
         const uint32_t vote = (uint32_t)__builtin_amdgcn_readfirstlane((int)(leaf_vote < 1u ? 1u : leaf_vote));
         if (n_walking > exit_at) {
             if (__ballot(unsafe) == 0ull) {
-                bool by_hand = false;
-                if constexpr (BRT_WALK_FAST && MODE == SCENE_LDS && !COUNTERS && SIMPLE_TREE && D16) {
-                    if (sc.near_base == 0u) {       // the records start at LDS address 0 (always, unless the kernel grows static LDS)
-                        by_hand = true;
-                        walk_loop_wave_lds<D16, SIMPLE_TREE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp, n, exit_at, vote, hc);
-                    }
-                }
-                if (!by_hand)
+                // by hand where the pair records start at LDS address 0: the kernel has no static LDS, which launch_persistent_t
+                // (brt_trace.h) checks on the host -- a run-time test here would give the loop's results two homes and a copy each
+                if constexpr (BRT_WALK_FAST && MODE == SCENE_LDS && !COUNTERS && SIMPLE_TREE && D16)
+                    walk_loop_wave_lds<D16, SIMPLE_TREE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp, n, exit_at, vote, hc);
+                else
                     walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, false, MODE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp,
                                                                             n, exit_at, vote, hc);
             }

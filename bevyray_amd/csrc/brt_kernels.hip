@@ -198,6 +198,12 @@ __global__ void k_debug_eval(uint32_t op, const float* __restrict__ in, float* _
                 if (!(x >= 0x1p-80f && x <= 0x1p80f)) continue;
                 if (__float_as_uint(sqrt_plain(x)) != __float_as_uint(__builtin_sqrtf(x))) { if (!bad) bad_x = first + k; bad++; }
             }
+            if (i == 0) {   // and +-0, which sqrt3 (brt_device.h) also sends through the short form
+                for (uint32_t z = 0u; z < 2u; z++) {
+                    const float x = __uint_as_float(z << 31);
+                    if (__float_as_uint(sqrt_plain(x)) != __float_as_uint(__builtin_sqrtf(x))) { if (!bad) bad_x = z << 31; bad++; }
+                }
+            }
             r[0] = (float)bad; r[1] = __uint_as_float(bad_x);
             break;
         }

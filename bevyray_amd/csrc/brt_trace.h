@@ -280,15 +280,14 @@ BRT_DEV void shade_landed(const ScenePtrs& sc, const FrameParams& fp, bool lande
     // ---- the paths that go on: next segment from the hit point; late ends ----
     if (hit && !early) {
         if (diffuse) d = acc;
-        bool late = absorbed;                                                     // metal only
-        f3 c = tput * mk3(0.0f, 0.0f, 0.0f);
-        if (!absorbed) {
+        if (absorbed || limit) {                                                  // metal; glass under the or-short-circuit policy
+            f3 c = mk3(0.0f, 0.0f, 0.0f);                                         // loop exit, :189 + :215-217: throughput 0 (x light 0)
+            if (absorbed) c = tput * c;                                           // :207-209: light stays 0
+            end_sample(c);
+        } else {
             tput = tput * att;                                                    // :211
             bounce++;
-            late = bounce > fp.bounce_count;                                      // loop exit, :189
-            if (late) c = mk3(0.0f, 0.0f, 0.0f);                                  // :215-217
         }
-        if (late) end_sample(c);
     }
 }
 
@@ -686,6 +685,14 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
 template <int MODE, bool D, bool S, bool C, bool T, int LEAN = 0>
 static hipError_t launch_persistent_t(const TraceLaunch& tl) {
     auto kern = k_trace_persistent<MODE, D, S, C, T, LEAN>;
+    if (MODE == SCENE_LDS) {
+        // the hand-written walk loop (walk_wave_lds_asm) addresses the pair records from LDS address 0: the dynamic LDS must start there
+        static const size_t static_lds = [&] {
+            hipFuncAttributes at{};
+            return hipFuncGetAttributes(&at, reinterpret_cast<const void*>(kern)) == hipSuccess ? at.sharedSizeBytes : (size_t)1;
+        }();
+        if (static_lds != 0) return hipErrorInvalidConfiguration;
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)tl.lds_bytes);
     if (e != hipSuccess) return e;

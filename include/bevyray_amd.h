@@ -215,7 +215,7 @@ enum {
     BRT_DBG_DIV_SWEEP = 7, /* in: seed (bits), count          out: mismatches of the short forms over `count` random plain-range pairs,
                               bits of the first mismatching n and d */
     BRT_DBG_SQRT_SWEEP = 8 /* in: first (bits), count         out: mismatches of the short sqrt over `count` consecutive floats per element
-                              (element i starts at first + i * count), bits of the first mismatching argument */
+                              (element i starts at first + i * count; element 0 also checks +0 and -0), bits of the first mismatching argument */
 };
 int32_t brt_debug_eval(brt_ctx* ctx, uint32_t op, const float* in16, float* out8, uint32_t n);
 

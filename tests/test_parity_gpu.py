@@ -952,7 +952,8 @@ DBG_DIV, DBG_DIV_SWEEP, DBG_SQRT_SWEEP = 6, 7, 8
 
 def test_short_sqrt_is_the_compilers_sqrt_on_every_float_of_its_range(plugin):
     """sqrt_plain (hipcc's correctly rounded sqrt without its tiny-argument scaling and class test) against
-    __builtin_sqrtf on EVERY float in [2^-80, 2^80]: 1.34e9 values, bit for bit."""
+    __builtin_sqrtf on EVERY float in [2^-80, 2^80]: 1.34e9 values, bit for bit -- and on +0 and -0, which the sample colour's
+    sqrt3 also sends through it."""
     lo = int(np.float32(2.0 ** -80).view(np.uint32))
     hi = int(np.float32(2.0 ** 80).view(np.uint32))
     per = 65536
