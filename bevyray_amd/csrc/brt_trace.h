@@ -441,6 +441,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     if (COUNTERS) t_start = t_mark = wall_clock64();
 
     bool tiles_done = false;          // the tile queue (slots FrameParams::queue_lane .. queue_size) is empty
+    bool again_mark = false;          // COUNTERS: the round that starts follows another one directly (phase times)
     // lane takes queue slot q of `tile`
     auto begin_pixel = [&](uint32_t q, uint32_t tile) {
         const PixelCoord c = slot_to_pixel<TUNABLE>(fp, q, tile);
@@ -605,6 +606,13 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         }
         if (__ballot(active) == 0) continue;      // (pool on) nothing live but paths may still arrive
 
+        // ---- rounds.  While the wave is full enough that nothing above can apply -- more live paths than pool_adopt (>= drain_donate), so
+        //      no tile, no hand-over, no take-over, no leave, finish_walks false; no lane queue; the same critical pixels -- the rounds run
+        //      in a loop of their own: the management code redefines every state variable on some path (a path taken over from the pool),
+        //      and in ONE loop with it the compiler gave all 24 of them a second home and copied them there and back every round.
+        bool again;
+        do {
+        if (COUNTERS && again_mark) { const unsigned long long now = wall_clock64(); ticks_shade += now - t_mark; t_mark = now; }
         prof_section<COUNTERS>(hc, SEC_ROUND, active);
         if (COUNTERS && __ballot(exhausted) != 0ull) drain_lane_rounds += (unsigned long long)__popcll(__ballot(active)) | (1ull << 32);
         const bool fresh = active && !in_flight;       // starts a ray segment in this round
@@ -630,6 +638,11 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         const uint32_t idx = walk.closest_idx;
         shade_landed<COUNTERS, LEAN, TUNABLE>(sc, fp, landed, t, idx, ps, o, d, tput, bounce, first_depth, active, need_cam, n_rays, hc,
                                               out_tile, raster_rgba, raster_depth);
+        finish_walks = false;
+        again_mark = true;
+        again = !TUNABLE && wave_count(active) > pool_adopt && (crit_end == 0u || (__ballot(active && crit) != 0ull) == wave_crit);
+        } while (again);
+        again_mark = false;
     }
 
     // ---- counters: one atomic per wave ----
