@@ -606,7 +606,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         }
         if (__ballot(active) == 0) continue;      // (pool on) nothing live but paths may still arrive
 
-        // ---- rounds.  While the wave is full enough that nothing above can apply -- more live paths than pool_adopt (>= drain_donate), so
+        // ---- rounds.  While nothing above can apply -- more live paths than pool_adopt (>= drain_donate), or no pool, or a critical wave:
         //      no tile, no hand-over, no take-over, no leave, finish_walks false; no lane queue; the same critical pixels -- the rounds run
         //      in a loop of their own: the management code redefines every state variable on some path (a path taken over from the pool),
         //      and in ONE loop with it the compiler gave all 24 of them a second home and copied them there and back every round.
@@ -640,7 +640,14 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                                               out_tile, raster_rgba, raster_depth);
         finish_walks = false;
         again_mark = true;
-        again = !TUNABLE && wave_count(active) > pool_adopt && (crit_end == 0u || (__ballot(active && crit) != 0ull) == wave_crit);
+        {
+            // another round at once unless the management code could do something: no live path (next tile / leave), a lane queue, other
+            // critical pixels than before, or -- with a drain pool, for a wave that is not critical -- few enough live paths to hand them
+            // over or to take some over
+            const uint32_t live_now = wave_count(active);
+            again = !TUNABLE && live_now != 0u && (crit_end == 0u || (__ballot(active && crit) != 0ull) == wave_crit) &&
+                    (live_now > pool_adopt || fp.pool_cap == 0u || wave_crit);
+        }
         } while (again);
         again_mark = false;
     }
