@@ -774,18 +774,20 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, f3
         exit_at = (uint32_t)__builtin_amdgcn_readfirstlane((int)exit_at);
         const uint32_t vote = (uint32_t)__builtin_amdgcn_readfirstlane((int)(leaf_vote < 1u ? 1u : leaf_vote));
         if (n_walking > exit_at) {
-            if (__ballot(unsafe) == 0ull) {
-                // by hand where the pair records start at LDS address 0: the kernel has no static LDS, which launch_persistent_t
-                // (brt_trace.h) checks on the host -- a run-time test here would give the loop's results two homes and a copy each
-                if constexpr (BRT_WALK_FAST && MODE == SCENE_LDS && !COUNTERS && SIMPLE_TREE && D16)
-                    walk_loop_wave_lds<D16, SIMPLE_TREE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp, n, exit_at, vote, hc);
-                else
-                    walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, false, MODE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp,
-                                                                            n, exit_at, vote, hc);
-            }
-            else
+            // by hand where the pair records start at LDS address 0: the kernel has no static LDS, which launch_persistent_t
+            // (brt_trace.h) checks on the host -- a run-time test here would give the loop's results two homes and a copy each.
+            // For the same reason the (rare) wave with an unsafe ray does not take the repairing loop INSTEAD of the hand-written one
+            // but BEFORE it: that loop leaves with at most exit_at lanes walking, and the hand-written one then returns at its first test.
+            constexpr bool kByHand = BRT_WALK_FAST && MODE == SCENE_LDS && !COUNTERS && SIMPLE_TREE && D16;
+            const bool any_unsafe = __ballot(unsafe) != 0ull;
+            if (any_unsafe)
                 walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, true, MODE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp,
                                                                        n, exit_at, vote, hc);
+            if constexpr (kByHand)
+                walk_loop_wave_lds<D16, SIMPLE_TREE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp, n, exit_at, vote, hc);
+            else if (!any_unsafe)
+                walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, false, MODE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp,
+                                                                        n, exit_at, vote, hc);
         }
     } else {
         while (cur != DS::DONE && (SIMPLE_TREE || n < 31u)) {
