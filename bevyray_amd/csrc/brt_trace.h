@@ -606,9 +606,8 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         }
         if (__ballot(active) == 0) continue;      // (pool on) nothing live but paths may still arrive
 
-        // ---- rounds.  While nothing above can apply -- more live paths than pool_adopt (>= drain_donate), or no pool, or a critical wave:
-        //      no tile, no hand-over, no take-over, no leave, finish_walks false; no lane queue; the same critical pixels -- the rounds run
-        //      in a loop of their own: the management code redefines every state variable on some path (a path taken over from the pool),
+        // ---- rounds.  While nothing above would apply (the test at the bottom) -- no tile, no hand-over, no take-over, no leave; no lane
+        //      queue; the same critical pixels -- the rounds run in a loop of their own: the management code redefines every state variable on some path (a path taken over from the pool),
         //      and in ONE loop with it the compiler gave all 24 of them a second home and copied them there and back every round.
         bool again;
         do {
@@ -638,15 +637,18 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         const uint32_t idx = walk.closest_idx;
         shade_landed<COUNTERS, LEAN, TUNABLE>(sc, fp, landed, t, idx, ps, o, d, tput, bounce, first_depth, active, need_cam, n_rays, hc,
                                               out_tile, raster_rgba, raster_depth);
-        finish_walks = false;
         again_mark = true;
         {
-            // another round at once unless the management code could do something: no live path (next tile / leave), a lane queue, other
-            // critical pixels than before, or -- with a drain pool, for a wave that is not critical -- few enough live paths to hand them
-            // over or to take some over
+            // another round at once unless the management code would do something: no live path (next tile / leave), a lane queue, other
+            // critical pixels than before, or -- with a drain pool, for a wave that is not critical -- paths to hand over (thin, no walk in
+            // flight, not the last wave alive) or to take over (the same tests as above, on what this round left)
             const uint32_t live_now = wave_count(active);
-            again = !TUNABLE && live_now != 0u && (crit_end == 0u || (__ballot(active && crit) != 0ull) == wave_crit) &&
-                    (live_now > pool_adopt || fp.pool_cap == 0u || wave_crit);
+            bool mgmt = TUNABLE || live_now == 0u || (crit_end != 0u && (__ballot(active && crit) != 0ull) != wave_crit);
+            const bool pooled = fp.pool_cap != 0u && !wave_crit;
+            if (!mgmt && pooled && live_now <= pool_adopt)
+                mgmt = (live_now <= drain_donate && __ballot(in_flight) == 0ull && pool_peek(pool_ctl, 2) > 1u) || pool_peek(pool_ctl, 1) != 0u;
+            finish_walks = pooled && live_now <= drain_donate;
+            again = !mgmt;
         }
         } while (again);
         again_mark = false;
