@@ -648,7 +648,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             if (!mgmt && pooled && live_now <= pool_adopt)
                 mgmt = (live_now <= drain_donate && __ballot(in_flight) == 0ull && pool_peek(pool_ctl, 2) > 1u) || pool_peek(pool_ctl, 1) != 0u;
             finish_walks = pooled && live_now <= drain_donate;
-            again = !mgmt;
+            again = __builtin_amdgcn_readfirstlane(mgmt ? 0 : 1) != 0;      // (wave-uniform by construction; the LDS peeks hide that from the compiler)
         }
         } while (again);
         again_mark = false;
