@@ -272,6 +272,38 @@ def test_analytic_cases(plugin, oracle):
         render_both(plugin, oracle, bb, lvl, cam, win, 48, 27)
 
 
+@pytest.mark.parametrize("bounces", [0, 1, 3])
+def test_late_sample_ends_and_paths_taken_over(oracle, bounces):
+    """shade_landed (brt_trace.h) makes the next sample's camera ray where a sample ends -- except for samples that end LATE
+    (a metal hit absorbed or at the bounce limit), which get it at the top of the next round -- and the round loop leaves for
+    the management code only when a wave has paths to hand over or to take over (the `need_cam` flag travels in the pool's
+    records).  A scene of rough metal (absorbs often), glass and diffuse spheres at bounce limits 0 / 1 / 3, frames large
+    enough for the drain pool, three frames per context so that the general, the measuring and the LEAN instantiations all
+    run: pixels and ray counts equal the oracle's; the COUNTERS instantiation (compiler-built rejection sampler and walk
+    loop) agrees on all five counters."""
+    rng = np.random.default_rng(77 + bounces)
+    data = [((0, -1000.0, 0), 1000.0, brt.StandardMaterial(base_color=(0.5, 0.5, 0.5)))]
+    for k in range(90):
+        x, z = rng.uniform(-6, 6, 2)
+        kind = k % 3
+        mat = (brt.StandardMaterial(metallic=1.0, perceptual_roughness=float(rng.uniform(0.6, 1.0)), base_color=tuple(rng.uniform(0.3, 1.0, 3))),
+               brt.StandardMaterial(specular_transmission=1.0, ior=float(rng.uniform(1.1, 1.8))),
+               brt.StandardMaterial(base_color=tuple(rng.uniform(0.1, 0.9, 3)), perceptual_roughness=float(rng.uniform(0.0, 1.0))))[kind]
+        data.append(((float(x), 0.3, float(z)), 0.3, mat))
+    b = make_buffers(data)
+    w, h = 320, 200
+    lvl, cam, win = uniforms(w, h, spp=12, bounces=bounces, pos=(9.0, 2.2, 4.0), target=(0, 0.2, 0), fov=0.6, seed=0.41)
+    want, cnt = oracle.render(b, lvl, cam, win, w, h)
+    with brt.RaytracePlugin([0]) as p:
+        for frame in range(3):
+            got = p.node.run(lvl, cam, win, w, h, buffers=b)
+            assert_frames_equal(got, want)
+            assert p.node.last_stats["rays"] == cnt["rays"], frame
+        got = p.node.run(lvl, cam, win, w, h, buffers=b, flags=brt.FLAG_COUNTERS)
+        assert_frames_equal(got, want)
+        assert {k: p.node.last_stats[k] for k in COUNTER_KEYS} == cnt
+
+
 def test_levels_with_raster_inputs(plugin, oracle):
     b = brt.generate_scene(brt.SCENE_COVER, 1)
     w, h = 40, 24
