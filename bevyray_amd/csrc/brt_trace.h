@@ -607,7 +607,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         if (__ballot(active) == 0) continue;      // (pool on) nothing live but paths may still arrive
 
         // ---- rounds.  While nothing above would apply (the test at the bottom) -- no tile, no hand-over, no take-over, no leave; no lane
-        //      queue; the same critical pixels -- the rounds run in a loop of their own: the management code redefines every state variable on some path (a path taken over from the pool),
+        //      queue refill; the same critical pixels -- the rounds run in a loop of their own: the management code redefines every state variable on some path (a path taken over from the pool),
         //      and in ONE loop with it the compiler gave all 24 of them a second home and copied them there and back every round.
         bool again;
         do {
@@ -643,8 +643,9 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             // critical pixels than before, or -- with a drain pool, for a wave that is not critical -- paths to hand over (thin, no walk in
             // flight, not the last wave alive) or to take over (the same tests as above, on what this round left)
             const uint32_t live_now = wave_count(active);
-            bool mgmt = TUNABLE || live_now == 0u || (crit_end != 0u && (__ballot(active && crit) != 0ull) != wave_crit);
-            const bool pooled = fp.pool_cap != 0u && !wave_crit;
+            bool mgmt = live_now == 0u || (crit_end != 0u && (__ballot(active && crit) != 0ull) != wave_crit) ||
+                        (TUNABLE && __ballot(!active && !exhausted) != 0ull);     // (a lane that may still take a pixel from the lane queue)
+            const bool pooled = fp.pool_cap != 0u && !wave_crit && (!TUNABLE || __ballot(exhausted) != 0ull);
             if (!mgmt && pooled && live_now <= pool_adopt)
                 mgmt = (live_now <= drain_donate && __ballot(in_flight) == 0ull && pool_peek(pool_ctl, 2) > 1u) || pool_peek(pool_ctl, 1) != 0u;
             finish_walks = pooled && live_now <= drain_donate;
