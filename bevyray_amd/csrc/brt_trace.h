@@ -11,6 +11,10 @@
 #include "brt_device.h"
 #include "brt_kernels.h"
 
+#ifndef BRT_PHASE_PRIO_AT
+#define BRT_PHASE_PRIO_AT 2   // 0: no phase priorities; 1: raised for the walk; 2: raised from the top of the round (walk begin included)
+#endif
+
 namespace brt {
 
 // ---- queue slot -> pixel -------------------------------------------------------------------
@@ -615,6 +619,13 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         prof_section<COUNTERS>(hc, SEC_ROUND, active);
         if (COUNTERS && __ballot(exhausted) != 0ull) drain_lane_rounds += (unsigned long long)__popcll(__ballot(active)) | (1ull << 32);
         const bool fresh = active && !in_flight;       // starts a ray segment in this round
+        // Issue priority by phase (LDS-resident scenes): from here to the end of the walk a wave goes ahead of its SIMD mates that are
+        // shading.  The walk is where the LDS round trips are (a step cannot start before the one before it has chosen its node), the
+        // shading code is arithmetic that fills the slots those leave; without it the four waves of a SIMD take turns by age and a
+        // walking wave waits behind a shading one with its next read not even issued.  (Critical waves stay at 3, FrameParams::crit_*.
+        // Scenes walked from L2 -- config 5 -- lose 2 % with it: there a walking wave mostly waits, whatever its priority.)
+        constexpr int kPhasePrio = MODE == SCENE_LDS ? BRT_PHASE_PRIO_AT : 0;
+        if (kPhasePrio == 2 && !wave_crit) __builtin_amdgcn_s_setprio(1);
         prof_section<COUNTERS>(hc, SEC_CAMERA_TOP, fresh && need_cam);
         if (fresh && bounce == 0) {
             // the first segment of a sample, raytrace.wgsl:175-186; its direction (:162) was made by shade_landed when the previous
@@ -629,12 +640,14 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         }
         if (fresh) walk_begin<D16>(walk, sc, sv.root_desc, stk, d);
         if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_pre += now - t_mark; t_mark = now; }
+        if (kPhasePrio == 1 && !wave_crit) __builtin_amdgcn_s_setprio(1);
         if (active) walk_run<64, COUNTERS, D16, SIMPLE, MODE>(sc, walk, stk, o, d, finish_walks ? 0u : walk_exit_lanes, leaf_vote, hc);
         in_flight = active && walk_pending<D16, SIMPLE>(walk);
         if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_walk += now - t_mark; t_mark = now; }
         const bool landed = active && !in_flight;      // walk finished: shade this segment now
         const float t = walk.closest;
         const uint32_t idx = walk.closest_idx;
+        if (kPhasePrio != 0 && !wave_crit) __builtin_amdgcn_s_setprio(0);
         shade_landed<COUNTERS, LEAN, TUNABLE>(sc, fp, landed, t, idx, ps, o, d, tput, bounce, first_depth, active, need_cam, n_rays, hc,
                                               out_tile, raster_rgba, raster_depth);
         again_mark = true;
