@@ -391,7 +391,11 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t n_waves = blockDim.x >> 6;
-    StackT* stk = stacks + wave * ((sv.stack_entries + 2u) * 64u) + lane;   // + 2: DONE sentinel (entry 0) and one spare entry
+    // This lane's column of the wave's [entry][64] stack array.  16-bit entries: lanes l and l + 32 share a dword (column 2 (l mod 32)
+    // + l / 32) instead of lanes 2k and 2k + 1: the LDS serves a wave's access 32 lanes at a time, and two lanes of one half that sit at
+    // different stack depths would hit the same bank at different addresses -- a 2-way conflict on every pop and push of the walk.
+    const uint32_t stack_col = D16 ? ((lane & 31u) * 2u + (lane >> 5)) : lane;
+    StackT* stk = stacks + wave * ((sv.stack_entries + 2u) * 64u) + stack_col;   // + 2: DONE sentinel (entry 0) and one spare entry
     // behind the stacks (same sums as trace_lds_bytes): the workgroup's share of the pixel queue, then the
     // drain pool (4 control words, then the records)
     char* const lds = reinterpret_cast<char*>(smem);
