@@ -222,8 +222,8 @@ int32_t brt_debug_eval(brt_ctx* ctx, uint32_t op, const float* in16, float* out8
 /* Diagnostic: the 64 raw control words of the last launch on the context's first device: out64[0..4]
  * = the brt_stats counters; after a BRT_FLAG_COUNTERS launch out64[8+2k], out64[9+2k] = how
  * often the waves executed code section k and the sum of active lanes over those executions
- * (k: 0 interior step, 1 leaf step, 2 camera ray, 3 scatter, 4 sky, 5 rejection-sampler iteration, 6 -,
- * 7 ray round); wave timeline in 100 MHz ticks: [24] ~first start, [25] ~first / [26] last "lane queue empty",
+ * (k: 0 interior step, 1 leaf step, 2 camera ray made where a sample ended, 3 scatter, 4 sky, 5 rejection-sampler iteration,
+ * 6 camera ray made at the top of a round (first sample of a pixel, late sample ends), 7 ray round); wave timeline in 100 MHz ticks: [24] ~first start, [25] ~first / [26] last "lane queue empty",
  * [27] last end, [28] sum of (end - empty) over waves, [29] waves, [30]/[31] live lanes and rounds after "empty";
  * wave time summed over waves: [5] pixel refill, [6] walk loop, [7] shading, [43] drain logic + camera ray +
  * walk begin, [44] rejection-sampler loop; [40] critical tiles and [41] longest pixel (rays) of the view's last measured frame.
