@@ -337,7 +337,7 @@ bool is_pinned(const brt_ctx* ctx, const void* p, size_t bytes) {
 // view) and the next frames use the order built from that.  Pixels never change, only the queue order does.
 // BRT_LPT=0 disables (raster order); BRT_LPT_SORT, BRT_LPT_LANE_PERMILLE, BRT_LPT_SKY_SLACK, BRT_CRIT: see
 // update_tile_order.
-constexpr uint32_t kLptRefresh = 16, kLptAfterUpload = 4;
+constexpr uint32_t kLptRefresh = 64, kLptAfterUpload = 4;   // (64: a view whose key and scene do not change has nothing new to measure; 16 until round 3 cost the steady state two slower frames in 32)
 bool lpt_enabled(const brt_ctx* ctx) { return ctx->knobs[K_LPT] != 0; }
 
 // The dispatch order only depends on which tiles hold long pixels: it survives a scene upload (an animated scene

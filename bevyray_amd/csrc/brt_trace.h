@@ -327,7 +327,7 @@ BRT_DEV uint32_t pool_peek(const uint32_t* ctl, int i) { return __atomic_load_n(
 // (brt_device.h).  TUNABLE: tuning knobs live (FrameParams) instead of folded to their defaults, lane queue built in.
 // LEAN: what the steady-state frame of a Pure-level view needs and nothing else, so that the other checks, registers
 // and kernel arguments leave the round loop.  1: level 3 (no raster inputs, no depth average) and no tile-cost
-// measurement (15 of 16 frames); 2: also no critical tiles (the host can rule them out: launch_part).  Same box,
+// measurement (63 of 64 frames); 2: also no critical tiles (the host can rule them out: launch_part).  Same box,
 // headline frame: 12.87 (0) -> 12.73 (1) -> 12.59 ms (2).
 template <int MODE, bool D16, bool SIMPLE, bool COUNTERS, bool TUNABLE, int LEAN>
 __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView sv, FrameParams fp,
