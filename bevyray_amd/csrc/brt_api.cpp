@@ -84,7 +84,7 @@ struct DeviceCtx {
 enum Knob : int {
     K_BOTTOM_UP, K_REFILL_MIN, K_WALK_EXIT, K_LEAF_VOTE, K_DRAIN_DONATE, K_POOL_ADOPT, K_WGQ_BATCH, K_LPT_LANE_PERMILLE, K_TUNABLE,
     K_FORCE_GLOBAL_SCENE, K_FORCE_LDS_TOP, K_BLOCK_THREADS, K_WG_PER_CU, K_POOL_CAP, K_LPT, K_LPT_SORT, K_LPT_SKY_SLACK, K_CRIT,
-    K_ORDER_ON_HOST, K_NO_LEAN, K_PREPASS_SPP, K_NO_DIRTY_TRACKING, K_CPU_BVH, K_PLOC_ONE_BLOCK_MAX, K_BVH_QUALITY, K_COUNT
+    K_ORDER_ON_HOST, K_NO_LEAN, K_PREPASS_SPP, K_NO_DIRTY_TRACKING, K_CPU_BVH, K_PLOC_ONE_BLOCK_MAX, K_BVH_QUALITY, K_POOL_FORCE, K_COUNT
 };
 struct KnobDef { const char* name; uint32_t dflt; };
 constexpr KnobDef kKnobs[K_COUNT] = {
@@ -93,7 +93,7 @@ constexpr KnobDef kKnobs[K_COUNT] = {
     {"BRT_TUNABLE", 0}, {"BRT_FORCE_GLOBAL_SCENE", 0}, {"BRT_FORCE_LDS_TOP", 0}, {"BRT_BLOCK_THREADS", 0}, {"BRT_WG_PER_CU", 0},
     {"BRT_POOL_CAP", 384}, {"BRT_LPT", 1}, {"BRT_LPT_SORT", 1}, {"BRT_LPT_SKY_SLACK", 20}, {"BRT_CRIT", 1}, {"BRT_ORDER_ON_HOST", 0},
     {"BRT_NO_LEAN", 0}, {"BRT_PREPASS_SPP", 2}, {"BRT_NO_DIRTY_TRACKING", 0}, {"BRT_CPU_BVH", 0},
-    {"BRT_PLOC_ONE_BLOCK_MAX", kPlocOneBlockMax}, {"BRT_BVH_QUALITY", 1}};
+    {"BRT_PLOC_ONE_BLOCK_MAX", kPlocOneBlockMax}, {"BRT_BVH_QUALITY", 1}, {"BRT_POOL_FORCE", 0}};
 struct Knobs {
     uint32_t v[K_COUNT];
     Knobs() { for (int i = 0; i < K_COUNT; i++) v[i] = kKnobs[i].dflt; }
@@ -259,7 +259,9 @@ LaunchPlan plan_launch(const Knobs& kn, const DeviceCtx& dc, const FrameParams& 
     // with / without the pool: 6.33 / 5.43 / 5.45 / 5.29 against 6.89 / 5.10 / 5.15 / 5.04 ms; config 4 in 8 / 16 parts: 106.8 / 91.0
     // against 107.9 / 86.4 ms (whole frames: 10.8 against 12.7 ms, 674 against 721 ms).
     const uint64_t n_tiles = fp.queue_size / 64u, wave_slots = (uint64_t)dc.num_cus * (BRT_BLOCK / 64u);
-    const uint32_t pool_max = (2u * n_tiles <= 5u * wave_slots) ? 0u : kn[K_POOL_CAP];
+    // (BRT_POOL_FORCE=1 keeps the pool whatever the frame size: the pool's hand-over / take-over paths are then exercised by
+    //  the small frames of the parity tests too)
+    const uint32_t pool_max = (2u * n_tiles <= 5u * wave_slots && kn[K_POOL_FORCE] == 0u) ? 0u : kn[K_POOL_CAP];
     auto pool_of = [&](uint32_t block) {
         const uint32_t want = fp.drain_donate * (block / 64u - 1u);
         return want < pool_max ? want : pool_max;
@@ -595,14 +597,17 @@ void free_device(DeviceCtx& dc) {
 constexpr uint32_t kMaxSahModels = 1u << 16;         // host-side binned SAH for callee-built trees up to here
 constexpr uint32_t kMaxGpuBuildModels = 1u << 24;   // scratch ~ 250 B per sphere; the grid version of the builder has no structural limit
 
-// PLOC on the context's first device: models (host) -> nodes (host vector), build time in ms.
-int32_t build_bvh_on_device(brt_ctx* ctx, const Model* models, uint32_t n, std::vector<BVHNode>* out, double* build_ms) {
+// A BVH built on the context's first device: models (host) -> nodes (host vector), kernel time in ms.  sah: the binned-SAH tree of
+// brt_sah.h (brt_sah.hip), else PLOC (brt_bvh.hip); each byte-identical to its CPU twin.
+int32_t build_bvh_on_device(brt_ctx* ctx, const Model* models, uint32_t n, bool sah, std::vector<BVHNode>* out, double* build_ms) {
     out->clear();
     if (n == 0) return BRT_OK;
-    if (n > kMaxGpuBuildModels) return ctx_fail(ctx, BRT_ERR_UNSUPPORTED, "GPU BVH build supports up to 2^24 spheres");
+    if (n > (sah ? kMaxSahModels : kMaxGpuBuildModels))
+        return ctx_fail(ctx, BRT_ERR_UNSUPPORTED, sah ? "GPU SAH build supports up to 65 536 spheres" : "GPU BVH build supports up to 2^24 spheres");
     DeviceCtx& dc = ctx->devs[0];
     HIP_TRY(ctx, hipSetDevice(dc.device));
-    int32_t rc = ensure(ctx, &dc.d_bvh_scratch, &dc.bvh_scratch_cap, ploc_scratch_bytes(n, nullptr, ctx->knobs[K_PLOC_ONE_BLOCK_MAX]));
+    int32_t rc = ensure(ctx, &dc.d_bvh_scratch, &dc.bvh_scratch_cap,
+                        sah ? sah_scratch_bytes(n) : ploc_scratch_bytes(n, nullptr, ctx->knobs[K_PLOC_ONE_BLOCK_MAX]));
     if (rc != BRT_OK) return rc;
     rc = ensure(ctx, &dc.d_bvh_models, &dc.bvh_models_cap, (size_t)n * sizeof(Model));
     if (rc != BRT_OK) return rc;
@@ -610,7 +615,8 @@ int32_t build_bvh_on_device(brt_ctx* ctx, const Model* models, uint32_t n, std::
     BVHNode* d_out = nullptr;
     uint32_t* d_info = nullptr;
     HIP_TRY(ctx, hipEventRecord(dc.ev0, dc.stream));
-    HIP_TRY(ctx, launch_build_ploc(reinterpret_cast<const Model*>(dc.d_bvh_models), n, dc.d_bvh_scratch, &d_out, &d_info, ctx->knobs[K_PLOC_ONE_BLOCK_MAX], dc.stream));
+    if (sah) HIP_TRY(ctx, launch_build_sah(reinterpret_cast<const Model*>(dc.d_bvh_models), n, dc.d_bvh_scratch, &d_out, &d_info, dc.stream));
+    else HIP_TRY(ctx, launch_build_ploc(reinterpret_cast<const Model*>(dc.d_bvh_models), n, dc.d_bvh_scratch, &d_out, &d_info, ctx->knobs[K_PLOC_ONE_BLOCK_MAX], dc.stream));
     HIP_TRY(ctx, hipEventRecord(dc.ev1, dc.stream));
     out->resize(2 * (size_t)n - 1);
     HIP_TRY(ctx, hipMemcpyAsync(out->data(), d_out, out->size() * sizeof(BVHNode), hipMemcpyDeviceToHost, dc.stream));
@@ -774,16 +780,15 @@ int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, co
     std::vector<BVHNode> built;
     const BVHNode* nodes = static_cast<const BVHNode*>(bvh_nodes);
     if (n_models > 0 && models && (!bvh_nodes || n_nodes == 0)) {
-        // no BVH from the caller: build it here.  Default: binned SAH on the host up to kMaxSahModels spheres (fewer node
-        // visits per ray than PLOC: DESIGN.md section 9; 0.2 ms for the cover scene, ~4 ms for 10 004 spheres), PLOC on
-        // the GPU above that or with the knob BRT_BVH_QUALITY=0 (the same bytes as the CPU PLOC builder)
+        // no BVH from the caller: build it here, on the GPU.  Default: the binned-SAH tree of brt_sah.h up to kMaxSahModels spheres
+        // (fewer node visits per ray than PLOC: DESIGN.md section 9), PLOC above that or with the knob BRT_BVH_QUALITY=0.
+        // BRT_CPU_BVH=1: the CPU twin of either (the same bytes).
+        const bool sah = ctx->knobs[K_BVH_QUALITY] != 0u && n_models <= kMaxSahModels;
+        const bool on_gpu = ctx->knobs[K_CPU_BVH] == 0u && n_models <= kMaxGpuBuildModels;
         int32_t rc;
-        if (ctx->knobs[K_BVH_QUALITY] != 0u && n_models <= kMaxSahModels)
-            rc = build_bvh_sah(static_cast<const Model*>(models), n_models, &built);
-        else
-            rc = (n_models <= kMaxGpuBuildModels && ctx->knobs[K_CPU_BVH] == 0)
-                     ? build_bvh_on_device(ctx, static_cast<const Model*>(models), n_models, &built, nullptr)
-                     : build_bvh_ploc(static_cast<const Model*>(models), n_models, &built);
+        if (on_gpu) rc = build_bvh_on_device(ctx, static_cast<const Model*>(models), n_models, sah, &built, nullptr);
+        else rc = sah ? build_bvh_sah(static_cast<const Model*>(models), n_models, &built)
+                      : build_bvh_ploc(static_cast<const Model*>(models), n_models, &built);
         if (rc != BRT_OK) return rc;
         nodes = built.data();
         n_nodes = (uint32_t)built.size();
@@ -1063,6 +1068,22 @@ int32_t render_frame_device(brt_ctx* ctx, const void* camera80, const void* wind
     HIP_TRY(ctx, hipSetDevice(d0.device));
     const bool own_stream = (hip_stream == nullptr) && !(flags & BRT_FLAG_CALLER_STREAM);
     hipStream_t stream0 = own_stream ? d0.stream : static_cast<hipStream_t>(hip_stream);
+    // A previous asynchronous frame (caller's stream) may still be copying into the gather buffer or reading a tile / raster copy:
+    // hipFree only synchronises the current device, so buffers grow only once every device of the context has drained.
+    {
+        bool grow = d0.gather_cap < tile_bytes * n_parts;
+        for (uint32_t p = 1; p < n_parts; p++) {
+            const DeviceCtx& dc = ctx->devs[p];
+            grow = grow || dc.tile_cap < tile_bytes || (d_raster_rgba && dc.raster_rgba_cap < frame_px * 16) ||
+                   (d_raster_depth && level != 0u && dc.raster_depth_cap < frame_px * 4);
+        }
+        if (grow)
+            for (auto& dc : ctx->devs) {
+                HIP_TRY(ctx, hipSetDevice(dc.device));
+                for (hipEvent_t e : {dc.ev_last, dc.ev_copy, dc.ev_asm}) HIP_TRY(ctx, hipEventSynchronize(e));
+            }
+        HIP_TRY(ctx, hipSetDevice(d0.device));
+    }
     int32_t rc = ensure(ctx, &d0.d_gather, &d0.gather_cap, tile_bytes * n_parts);
     if (rc != BRT_OK) return rc;
     // the other devices start behind whatever the caller enqueued before this call (its raster inputs)
@@ -1082,7 +1103,9 @@ int32_t render_frame_device(brt_ctx* ctx, const void* camera80, const void* wind
             out = dc.d_tile;
             HIP_TRY(ctx, hipStreamWaitEvent(sp, d0.ev_in, 0));
             HIP_TRY(ctx, hipStreamWaitEvent(sp, d0.ev_asm, 0));     // the gather buffer is free again (previous frame assembled)
-            if (d_raster_rgba && level != 0u) {
+            // (level 0 reads the raster colour too -- k_passthrough, raytrace.wgsl:97-99 -- so it is forwarded at every level: a
+            //  device must never be handed a pointer into another device's memory, peer access is not enabled)
+            if (d_raster_rgba) {
                 rc = ensure(ctx, &dc.d_raster_rgba, &dc.raster_rgba_cap, frame_px * 16);
                 if (rc != BRT_OK) return rc;
                 HIP_TRY(ctx, hipMemcpyPeerAsync(dc.d_raster_rgba, dc.device, d_raster_rgba, d0.device, frame_px * 16, sp));
@@ -1105,7 +1128,7 @@ int32_t render_frame_device(brt_ctx* ctx, const void* camera80, const void* wind
         }
         rc = attach_tile_order(ctx, dc, fps[p], sp, own_stream);
         if (rc != BRT_OK) return rc;
-        rc = launch_part(ctx, dc, fps[p], level == 0u ? d_raster_rgba : d_rgba, d_depth, out, sp, flags, true, &lp);
+        rc = launch_part(ctx, dc, fps[p], d_rgba, d_depth, out, sp, flags, true, &lp);
         if (rc != BRT_OK) return rc;
         if (p != 0) {
             HIP_TRY(ctx, hipMemcpyPeerAsync(d0.d_gather + (size_t)p * tile_floats, d0.device, dc.d_tile, dc.device, tile_bytes, sp));
@@ -1222,7 +1245,24 @@ int32_t brt_build_bvh_device(brt_ctx* ctx, const void* models, uint32_t n_models
     if (n_models == 0) return BRT_OK;
     if (!models) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "models is null");
     std::vector<BVHNode> nodes;
-    int32_t rc = build_bvh_on_device(ctx, static_cast<const Model*>(models), n_models, &nodes, out_build_ms);
+    int32_t rc = build_bvh_on_device(ctx, static_cast<const Model*>(models), n_models, false, &nodes, out_build_ms);
+    if (rc != BRT_OK) return rc;
+    *out_n_nodes = (uint32_t)nodes.size();
+    if (nodes.size() > capacity || !out_nodes)
+        return ctx_fail(ctx, BRT_ERR_CAPACITY, "BVH needs " + std::to_string(nodes.size()) + " nodes, capacity " + std::to_string(capacity));
+    std::memcpy(out_nodes, nodes.data(), nodes.size() * sizeof(BVHNode));
+    return BRT_OK;
+}
+
+int32_t brt_build_bvh_sah_device(brt_ctx* ctx, const void* models, uint32_t n_models, void* out_nodes, uint32_t capacity,
+                                 uint32_t* out_n_nodes, double* out_build_ms) {
+    if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (!out_n_nodes) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "out_n_nodes is null");
+    *out_n_nodes = 0;
+    if (n_models == 0) return BRT_OK;
+    if (!models) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "models is null");
+    std::vector<BVHNode> nodes;
+    int32_t rc = build_bvh_on_device(ctx, static_cast<const Model*>(models), n_models, true, &nodes, out_build_ms);
     if (rc != BRT_OK) return rc;
     *out_n_nodes = (uint32_t)nodes.size();
     if (nodes.size() > capacity || !out_nodes)

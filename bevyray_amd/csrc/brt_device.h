@@ -21,6 +21,15 @@ namespace brt {
 
 #define BRT_DEV __device__ __forceinline__
 
+// The hand-written loops (walk_wave_lds_asm, ball_loop_asm) name gfx950 registers and count its wait states and its lgkmcnt by
+// hand: a device pass for any other target (the Makefile's ARCH can be overridden) compiles them out and takes the
+// compiler-built loops (walk_loop_wave, the `while (need)` sampler of shade_landed) instead.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#define BRT_HAND_ASM 0
+#else
+#define BRT_HAND_ASM 1
+#endif
+
 #ifndef BRT_EXEC_MOVES
 #define BRT_EXEC_MOVES 0   // bit 0: sphere test, bit 1: ball loop -- `if` bodies of v_mov under EXEC instead of v_cndmask selects; measured: -0.0 ... +0.8 % (the compiler adds a branch per `if`), off
 #endif
@@ -181,9 +190,10 @@ BRT_DEV f3 rng_unit_ball(uint32_t& state) {
 // the vector pipe: tests/tools/issue_bench.hip).  43 vector instructions per iteration instead of 50, none of them a 4-cycle select.
 // Per lane: the same draws and the same mul / add, in the same order.
 #ifndef BRT_BALL_ASM
-#define BRT_BALL_ASM 1
+#define BRT_BALL_ASM BRT_HAND_ASM
 #endif
 BRT_DEV void ball_loop_asm(uint32_t& rng, f3& acc, float scale, float rough, uint64_t m2, uint64_t m1) {
+#if BRT_HAND_ASM
     uint32_t t;
     float x, y, z, q, r;
     uint64_t s_all, s_up;
@@ -235,6 +245,7 @@ BRT_DEV void ball_loop_asm(uint32_t& rng, f3& acc, float scale, float rough, uin
         : [rough] "v"(rough), [c_mul] "s"(c_mul), [c_2m31] "s"(c_2m31)
         : "vcc", "scc", "memory");
 #undef BRT_RNG_DRAW
+#endif
 }
 
 // raytrace.wgsl:387-398 with 1/d hoisted per ray.  Returns whether the child is pushed
@@ -552,14 +563,15 @@ BRT_DEV void walk_loop_wave(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, ui
 // back edge) and one compare: ~134.  Same per-lane steps in the same order as walk_loop_wave: pixels and counters do
 // not change.  (Only for SIMPLE trees, without COUNTERS, for waves without unsafe rays; everything else takes walk_loop_wave.)
 #ifndef BRT_WALK_FAST
-#define BRT_WALK_FAST 1
+#define BRT_WALK_FAST BRT_HAND_ASM
 #endif
 // The whole wave-level walk loop (walk_loop_wave's nest: interior steps until `vote` lanes wait at a leaf, one leaf step,
 // until at most exit_at lanes still walk) as ONE block of hand-scheduled code.
 //   cur / spa     descriptor of the lane's current node (sign-extended 16-bit form: interior >= 0, leaf < -1, DONE = -1) and
 //                 LDS byte address of its stack top (16-bit entries, 128 bytes apart)
 //   gofs          the ray's granule offsets {x, y, z} inside a pair record; the records start at LDS address 0 (they are the
-//                 first thing in the kernel's dynamic LDS; walk_run checks it and takes walk_loop_wave otherwise)
+//                 first thing in the kernel's dynamic LDS and the kernel has no static LDS: launch_persistent_t, brt_trace.h,
+//                 checks that on the HOST and fails the launch with hipErrorInvalidConfiguration otherwise)
 //   sph           LDS byte address of the spheres {centre, r^2}
 // The record and the sphere live in FIXED registers v[100:113]: inline asm cannot name the single registers of a 128-bit
 // operand, and the arithmetic works on them in place.
@@ -571,6 +583,7 @@ BRT_DEV void walk_loop_wave(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, ui
 // t > 0.001 && t < closest moves t and the sphere id under EXEC.
 BRT_DEV void walk_wave_lds_asm(uint32_t& cur, uint32_t& spa, float& closest, uint32_t& closest_idx, uint32_t gofs_x, uint32_t gofs_y,
                                uint32_t gofs_z, f3 o, f3 inv, f3 d, float a, uint32_t sph, uint32_t exit_at, uint32_t vote) {
+#if BRT_HAND_ASM
     uint32_t t0, tx, ty, tz, pop, cnt, nw, thr;
     float below;
     uint64_t s_all, s_take, s_p2, s_any, s_both;
@@ -722,6 +735,7 @@ BRT_DEV void walk_wave_lds_asm(uint32_t& cur, uint32_t& spa, float& closest, uin
           [vote] "s"(vote), [rec_bytes] "s"(rec_bytes), [c_tiny] "s"(c_tiny), [c_eps] "s"(c_eps), [c_cls] "s"(c_cls)
         : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112",
           "v113");
+#endif
 }
 
 template <bool D16, bool SIMPLE_TREE, typename StackT>

@@ -7,6 +7,7 @@
 // None of this traces rays; there is no CPU rendering path in the product.
 #include "brt_host.h"
 #include "brt_ploc.h"
+#include "brt_sah.h"
 
 #include <algorithm>
 #include <cmath>
@@ -242,112 +243,97 @@ int32_t build_bvh_sah(const Model* models, uint32_t n_models, std::vector<BVHNod
     out->clear();
     if (n_models == 0) return BRT_OK;
     const uint32_t n = n_models;
-    constexpr int kBins = 16;
-    constexpr uint32_t kMaxDepth = 28;                       // leaves at depth <= 28: stack_entries <= 29 < 31 (simple tree)
-    std::vector<PlocBox> box(n);
+    std::vector<SahKeyBox> box(n);
     std::vector<double> cen(3 * (size_t)n);
     for (uint32_t i = 0; i < n; i++) {
-        box[i] = ploc_model_box(models[i].position, models[i].radius);
-        for (int k = 0; k < 3; k++) {
-            const double c = 0.5 * ((double)box[i].mn[k] + (double)box[i].mx[k]);
-            cen[3 * (size_t)i + k] = std::isfinite(c) ? c : 0.0;
-        }
+        const PlocBox b = ploc_model_box(models[i].position, models[i].radius);
+        box[i] = sah_keybox(b);
+        for (int k = 0; k < 3; k++) cen[3 * (size_t)i + k] = sah_centroid(b, k);
     }
-    std::vector<uint32_t> idx(n);
+    std::vector<uint32_t> idx(n), tmp(n);
     for (uint32_t i = 0; i < n; i++) idx[i] = i;
     out->resize(2 * (size_t)n - 1);
-    auto half_area = [](const PlocBox& b) {
-        const double dx = (double)b.mx[0] - (double)b.mn[0], dy = (double)b.mx[1] - (double)b.mn[1], dz = (double)b.mx[2] - (double)b.mn[2];
-        const double a = (dx * dy + dy * dz) + dz * dx;
-        return std::isfinite(a) ? a : std::numeric_limits<double>::max();
-    };
-    auto ceil_log2 = [](uint32_t c) { uint32_t d = 0; while ((1u << d) < c) d++; return d; };
-    auto write_node = [&](uint32_t slot, const PlocBox& b, uint32_t index, uint32_t count) {
+    auto write_node = [&](uint32_t slot, const SahKeyBox& kb, uint32_t index, uint32_t count) {
         BVHNode& o = (*out)[slot];
         std::memset(&o, 0, sizeof o);
+        const PlocBox b = sah_unkeybox(kb);
         for (int k = 0; k < 3; k++) { o.bounds_min[k] = b.mn[k]; o.bounds_max[k] = b.mx[k]; }
         o.index = index;
         o.model_count = count;
     };
-    struct Job { uint32_t slot, begin, end, depth; };
+    // (the rule, the cost and the numbering: brt_sah.h; brt_sah.hip runs the same nodes in another order and writes the same bytes)
+    struct Job { uint32_t slot, begin, end, depth, rank; };
     std::vector<Job> todo;
-    todo.push_back({0u, 0u, n, 0u});
-    uint32_t next_slot = 1;
+    todo.push_back({0u, 0u, n, 0u, 0u});
     while (!todo.empty()) {
         const Job j = todo.back();
         todo.pop_back();
         const uint32_t count = j.end - j.begin;
-        PlocBox nb = box[idx[j.begin]];
-        for (uint32_t i = j.begin + 1; i < j.end; i++) nb = ploc_merge(nb, box[idx[i]]);
+        SahKeyBox nb = sah_keybox_empty();
+        for (uint32_t i = j.begin; i < j.end; i++) sah_keybox_merge(nb, box[idx[i]]);
         if (count == 1) {
             write_node(j.slot, nb, idx[j.begin], 1u);          // leaf: the model id itself (extract.rs:318,329)
             continue;
         }
         uint32_t mid = j.begin + count / 2;                    // fallback: halves in the current order
-        const bool balanced_only = j.depth + ceil_log2(count) >= kMaxDepth;
+        const bool balanced_only = j.depth + sah_ceil_log2(count) >= kSahMaxDepth;
         if (!balanced_only && count > 2) {
             double cmin[3], cmax[3];
-            for (int k = 0; k < 3; k++) { cmin[k] = std::numeric_limits<double>::max(); cmax[k] = -std::numeric_limits<double>::max(); }
+            for (int k = 0; k < 3; k++) { cmin[k] = kSahDblMax; cmax[k] = -kSahDblMax; }
             for (uint32_t i = j.begin; i < j.end; i++)
                 for (int k = 0; k < 3; k++) {
                     const double c = cen[3 * (size_t)idx[i] + k];
-                    cmin[k] = std::min(cmin[k], c);
-                    cmax[k] = std::max(cmax[k], c);
+                    cmin[k] = c < cmin[k] ? c : cmin[k];
+                    cmax[k] = c > cmax[k] ? c : cmax[k];
                 }
-            double best_cost = std::numeric_limits<double>::max();
+            double best_cost = kSahDblMax;
             int best_axis = -1, best_bin = -1;
             for (int k = 0; k < 3; k++) {
-                const double ext = cmax[k] - cmin[k];
-                if (!(ext > 0.0) || !std::isfinite(ext)) continue;
-                PlocBox bb[kBins];
-                uint32_t bc[kBins] = {};
-                const double scale = (double)kBins / ext;
+                if (!sah_axis_usable(cmin[k], cmax[k])) continue;
+                SahKeyBox bb[kSahBins];
+                uint32_t bc[kSahBins] = {};
+                for (int b = 0; b < kSahBins; b++) bb[b] = sah_keybox_empty();
+                const double scale = (double)kSahBins / (cmax[k] - cmin[k]);
                 for (uint32_t i = j.begin; i < j.end; i++) {
-                    int b = (int)((cen[3 * (size_t)idx[i] + k] - cmin[k]) * scale);
-                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
-                    bb[b] = bc[b] ? ploc_merge(bb[b], box[idx[i]]) : box[idx[i]];
+                    const int b = sah_bin(cen[3 * (size_t)idx[i] + k], cmin[k], scale);
+                    sah_keybox_merge(bb[b], box[idx[i]]);
                     bc[b]++;
                 }
-                // sweep: cost of splitting after bin s = area(left) * n_left + area(right) * n_right
-                double right_area[kBins];
-                uint32_t right_n[kBins];
-                PlocBox acc{};
-                uint32_t cn = 0;
-                for (int b = kBins - 1; b >= 1; b--) {
-                    if (bc[b]) { acc = cn ? ploc_merge(acc, bb[b]) : bb[b]; cn += bc[b]; }
-                    right_area[b] = cn ? half_area(acc) : 0.0;
-                    right_n[b] = cn;
-                }
-                cn = 0;
-                for (int b = 0; b + 1 < kBins; b++) {
-                    if (bc[b]) { acc = cn ? ploc_merge(acc, bb[b]) : bb[b]; cn += bc[b]; }
-                    if (cn == 0 || right_n[b + 1] == 0) continue;
-                    const double cost = half_area(acc) * (double)cn + right_area[b + 1] * (double)right_n[b + 1];
-                    if (cost < best_cost) { best_cost = cost; best_axis = k; best_bin = b; }   // strict <: first axis / bin wins ties
+                // cost of splitting after bin s = area(left) * n_left + area(right) * n_right
+                for (int s = 0; s + 1 < kSahBins; s++) {
+                    SahKeyBox L = sah_keybox_empty(), R = sah_keybox_empty();
+                    uint32_t nl = 0, nr = 0;
+                    for (int b = 0; b < kSahBins; b++) {
+                        if (b <= s) { sah_keybox_merge(L, bb[b]); nl += bc[b]; }
+                        else { sah_keybox_merge(R, bb[b]); nr += bc[b]; }
+                    }
+                    if (nl == 0 || nr == 0) continue;
+                    const double cost = sah_half_area(L) * (double)nl + sah_half_area(R) * (double)nr;
+                    if (cost < best_cost) { best_cost = cost; best_axis = k; best_bin = s; }   // strict <: first axis / bin wins ties
                 }
             }
             if (best_axis >= 0) {
-                const double ext = cmax[best_axis] - cmin[best_axis], scale = (double)kBins / ext;
-                auto left_side = [&](uint32_t m) {
-                    int b = (int)((cen[3 * (size_t)m + best_axis] - cmin[best_axis]) * scale);
-                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
-                    return b <= best_bin;
-                };
-                const auto it = std::stable_partition(idx.begin() + j.begin, idx.begin() + j.end, left_side);
-                const uint32_t m = (uint32_t)(it - idx.begin());
-                // a lopsided split must leave both sides inside the depth budget; else halves
+                const double scale = (double)kSahBins / (cmax[best_axis] - cmin[best_axis]);
+                uint32_t nl = 0, nr = 0;                       // stable partition by "bin <= best_bin"
+                for (uint32_t i = j.begin; i < j.end; i++) {
+                    const uint32_t m = idx[i];
+                    if (sah_bin(cen[3 * (size_t)m + best_axis], cmin[best_axis], scale) <= best_bin) idx[j.begin + nl++] = m;
+                    else tmp[nr++] = m;
+                }
+                for (uint32_t i = 0; i < nr; i++) idx[j.begin + nl + i] = tmp[i];
+                const uint32_t m = j.begin + nl;
+                // a lopsided split must leave both sides inside the depth budget; else halves (of the new order)
                 if (m > j.begin && m < j.end) {
                     const uint32_t big = std::max(m - j.begin, j.end - m);
-                    if (j.depth + 1 + ceil_log2(big) <= kMaxDepth) mid = m;
+                    if (j.depth + 1 + sah_ceil_log2(big) <= kSahMaxDepth) mid = m;
                 }
             }
         }
-        const uint32_t child = next_slot;
-        next_slot += 2;
+        const uint32_t child = 1u + 2u * j.rank;
         write_node(j.slot, nb, child, 0u);
         // the reference pops child `index + 1` first (raytrace.wgsl:329-341): no preference is encoded here
-        todo.push_back({child + 1, mid, j.end, j.depth + 1});
-        todo.push_back({child, j.begin, mid, j.depth + 1});
+        todo.push_back({child + 1, mid, j.end, j.depth + 1, j.rank + (mid - j.begin)});
+        todo.push_back({child, j.begin, mid, j.depth + 1, j.rank + 1u});
     }
     return BRT_OK;
 }

@@ -327,8 +327,8 @@ BRT_DEV uint32_t pool_peek(const uint32_t* ctl, int i) { return __atomic_load_n(
 // (brt_device.h).  TUNABLE: tuning knobs live (FrameParams) instead of folded to their defaults, lane queue built in.
 // LEAN: what the steady-state frame of a Pure-level view needs and nothing else, so that the other checks, registers
 // and kernel arguments leave the round loop.  1: level 3 (no raster inputs, no depth average) and no tile-cost
-// measurement (63 of 64 frames); 2: also no critical tiles (the host can rule them out: launch_part).  Same box,
-// headline frame: 12.87 (0) -> 12.73 (1) -> 12.59 ms (2).
+// measurement; 2: also no critical tiles (the host can rule them out: launch_part).  (A/B at the time it went in, round 2:
+// headline frame 12.87 (0) -> 12.73 (1) -> 12.59 ms (2); current timings: docs/experiments.md.)
 template <int MODE, bool D16, bool SIMPLE, bool COUNTERS, bool TUNABLE, int LEAN>
 __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView sv, FrameParams fp,
                                                                 uint32_t* __restrict__ queue_counter,

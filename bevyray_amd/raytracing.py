@@ -335,6 +335,18 @@ class RaytracePlugin:
                                                   C.byref(ms)), self._ctx)
         return _trim(nodes, out_n.value), ms.value
 
+    def build_bvh_sah(self, models: np.ndarray):
+        """GPU binned-SAH build (brt_build_bvh_sah_device): returns (nodes, kernel ms); same bytes as build_bvh_sah()."""
+        models = np.ascontiguousarray(models, MODEL_DTYPE)
+        n = len(models)
+        cap = max(1, 2 * n)
+        nodes = np.zeros(cap, BVH_NODE_DTYPE)
+        out_n = C.c_uint32(0)
+        ms = C.c_double(0.0)
+        _lib.check(self._lib.brt_build_bvh_sah_device(self._ctx, models.ctypes.data, n, nodes.ctypes.data, cap, C.byref(out_n),
+                                                      C.byref(ms)), self._ctx)
+        return _trim(nodes, out_n.value), ms.value
+
     def debug_profile(self) -> dict:
         """Lane-utilisation profile of the last FLAG_COUNTERS launch: section -> (executions, lanes)."""
         raw = (C.c_uint64 * 64)()

@@ -259,16 +259,25 @@ int32_t brt_build_bvh(const void* models, uint32_t n_models,
 /* A better tree for the same contract: top-down binned SAH (16 bins, single-sphere leaves, depth capped below the
  * shader's 32-entry stack).  The reference rebuilds PLOC on the CPU every frame (extract.rs:315-321, "TODO" at
  * extract.rs:264-267); the shader only needs the node contract above, and an SAH tree costs the ray loop fewer node
- * visits (10 004-sphere grid: 23.6 -> 19.1 interior visits per ray).  This is what brt_upload_scene builds when the
- * caller passes no BVH (up to 65 536 spheres; above that, or with the knob BRT_BVH_QUALITY=0: PLOC on the GPU). */
+ * visits (10 004-sphere grid: 23.6 -> 19.1 interior visits per ray).  This is the CPU statement of the tree
+ * brt_upload_scene builds ON THE GPU (brt_build_bvh_sah_device, the same bytes) when the caller passes no BVH (up to 65 536
+ * spheres; above that, or with the knob BRT_BVH_QUALITY=0: PLOC on the GPU). */
 int32_t brt_build_bvh_sah(const void* models, uint32_t n_models,
                           void* out_nodes, uint32_t capacity, uint32_t* out_n_nodes);
 
 /* The same build on the GPU (PLOC in one workgroup, bevyray_amd/csrc/brt_bvh.hip): takes the
  * host model vector, returns byte-identical nodes to brt_build_bvh plus the kernel time.
- * brt_upload_scene uses it when the caller passes no BVH.  Needs a context (a GPU). */
+ * brt_upload_scene uses it when the caller passes no BVH and the scene has more than 65 536 spheres (or BRT_BVH_QUALITY=0).
+ * Needs a context (a GPU). */
 int32_t brt_build_bvh_device(brt_ctx* ctx, const void* models, uint32_t n_models,
                              void* out_nodes, uint32_t capacity, uint32_t* out_n_nodes, double* out_build_ms);
+
+/* The binned-SAH tree of brt_build_bvh_sah built on the GPU (bevyray_amd/csrc/brt_sah.hip: one workgroup for the nodes of more
+ * than 1024 spheres, then a workgroup per subtree, a wave per node): byte-identical nodes plus the kernel time.  This is what
+ * brt_upload_scene runs when the caller passes no BVH (up to 65 536 spheres), so that a scene that changes every frame --
+ * the reference rebuilds and re-uploads per frame, extract.rs:299-336 -- costs no host-side build.  Needs a context (a GPU). */
+int32_t brt_build_bvh_sah_device(brt_ctx* ctx, const void* models, uint32_t n_models,
+                                 void* out_nodes, uint32_t capacity, uint32_t* out_n_nodes, double* out_build_ms);
 
 /* Checks what brt_upload_scene checks, without a context. */
 int32_t brt_validate_scene(const void* models, uint32_t n_models,

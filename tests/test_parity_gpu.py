@@ -231,6 +231,12 @@ def test_near_far_read_offsets_and_their_repair(plugin, oracle):
     for x in (0.0, float(plane), -0.5):
         cam["position"] = (x, 0.0, 0.0)
         render_both(plugin, oracle, b, lvl, cam, win, 24, 24)
+        # without counters the wave with an unsafe ray runs the repairing loop and THEN the hand-written one (walk_run): also at
+        # the extremes of the two thresholds both loops take
+        render_both(plugin, oracle, b, lvl, cam, win, 24, 24, flags=0)
+        for vote, exit_at in ((0, 0), (64, 63), (63, 1), (1, 62)):
+            with plugin.tuning(BRT_LEAF_VOTE=vote, BRT_WALK_EXIT=exit_at):
+                render_both(plugin, oracle, b, lvl, cam, win, 24, 24, flags=0)
     # boxes the reference never validates: swapped bounds, infinite bounds, a NaN bound
     lvl, cam, win = uniforms(40, 24, spp=3, bounces=5, pos=(0.3, 0.4, 1.0), target=(0.0, 0.0, -5.0), fov=0.7, seed=0.25)
     for victim, edit in ((1, "swap"), (2, "inf"), (3, "nan"), (4, "swap")):
@@ -277,8 +283,8 @@ def test_late_sample_ends_and_paths_taken_over(oracle, bounces):
     """shade_landed (brt_trace.h) makes the next sample's camera ray where a sample ends -- except for samples that end LATE
     (a metal hit absorbed or at the bounce limit), which get it at the top of the next round -- and the round loop leaves for
     the management code only when a wave has paths to hand over or to take over (the `need_cam` flag travels in the pool's
-    records).  A scene of rough metal (absorbs often), glass and diffuse spheres at bounce limits 0 / 1 / 3, frames large
-    enough for the drain pool, three frames per context so that the general, the measuring and the LEAN instantiations all
+    records).  A scene of rough metal (absorbs often), glass and diffuse spheres at bounce limits 0 / 1 / 3, with the drain pool
+    forced on (BRT_POOL_FORCE: a frame of this size runs without it by default) and off, three frames per context so that the general, the measuring and the LEAN instantiations all
     run: pixels and ray counts equal the oracle's; the COUNTERS instantiation (compiler-built rejection sampler and walk
     loop) agrees on all five counters."""
     rng = np.random.default_rng(77 + bounces)
@@ -294,14 +300,21 @@ def test_late_sample_ends_and_paths_taken_over(oracle, bounces):
     w, h = 320, 200
     lvl, cam, win = uniforms(w, h, spp=12, bounces=bounces, pos=(9.0, 2.2, 4.0), target=(0, 0.2, 0), fov=0.6, seed=0.41)
     want, cnt = oracle.render(b, lvl, cam, win, w, h)
-    with brt.RaytracePlugin([0]) as p:
-        for frame in range(3):
-            got = p.node.run(lvl, cam, win, w, h, buffers=b)
+    for force in (1, 0):      # a frame of this size runs WITHOUT the pool by default (plan_launch): BRT_POOL_FORCE=1 is the case under test
+        with brt.RaytracePlugin([0]) as p:
+            p.set_tuning("BRT_POOL_FORCE", force)
+            for frame in range(3):
+                got = p.node.run(lvl, cam, win, w, h, buffers=b)
+                assert_frames_equal(got, want)
+                assert p.node.last_stats["rays"] == cnt["rays"], frame
+            lds_plain = p.node.last_stats["lds_bytes"]
+            got = p.node.run(lvl, cam, win, w, h, buffers=b, flags=brt.FLAG_COUNTERS)
             assert_frames_equal(got, want)
-            assert p.node.last_stats["rays"] == cnt["rays"], frame
-        got = p.node.run(lvl, cam, win, w, h, buffers=b, flags=brt.FLAG_COUNTERS)
-        assert_frames_equal(got, want)
-        assert {k: p.node.last_stats[k] for k in COUNTER_KEYS} == cnt
+            assert {k: p.node.last_stats[k] for k in COUNTER_KEYS} == cnt
+            if force:
+                with p.tuning(BRT_POOL_FORCE=0):
+                    p.node.run(lvl, cam, win, w, h)
+                    assert p.node.last_stats["lds_bytes"] < lds_plain      # the pool really was part of the forced launches
 
 
 def test_levels_with_raster_inputs(plugin, oracle):
@@ -605,6 +618,75 @@ def _ploc_build_cases(plugin, oracle):
     assert_frames_equal(f1, f2) and all(plugin.node.last_stats[k] == s1[k] for k in COUNTER_KEYS)
 
 
+def _sah_build_scenes():
+    rng = np.random.default_rng(23)
+    scenes = [brt.generate_scene(brt.SCENE_COVER, s).models for s in (1, 2)]
+    scenes += [brt.generate_scene(brt.SCENE_RTIOW_FINAL, 1).models, brt.generate_scene(brt.SCENE_STRESS_GRID, 1).models]
+    # sizes around every hand-over of the builder: 1 (a leaf root), wave split (<= 192), block split, the 1024-sphere subtree
+    # limit (k_sah_top above it), several subtrees, the 65 536-sphere limit of the SAH path
+    for n in (1, 2, 3, 4, 5, 63, 64, 65, 191, 192, 193, 500, 1023, 1024, 1025, 2049, 4100, 20000, 65536):
+        m = np.zeros(n, brt.MODEL_DTYPE)
+        m["position"] = rng.uniform(-20, 20, (n, 3)).astype(np.float32)
+        m["radius"] = rng.uniform(0.05, 2.0, n).astype(np.float32)
+        scenes.append(m)
+    dup = np.zeros(300, brt.MODEL_DTYPE); dup["position"] = (1.0, 2.0, 3.0); dup["radius"] = 0.5     # no axis has an extent: halves
+    line = np.zeros(1500, brt.MODEL_DTYPE); line["position"][:, 0] = np.arange(1500, dtype=np.float32); line["radius"] = 0.25   # one usable axis
+    plane = np.zeros(3000, brt.MODEL_DTYPE); plane["position"][:, [0, 2]] = rng.uniform(-9, 9, (3000, 2)).astype(np.float32); plane["radius"] = 0.1
+    row = np.zeros(2200, brt.MODEL_DTYPE)      # geometric row: lopsided SAH splits run into the depth budget (28 levels)
+    row["position"][:, 0] = (1.5 ** (np.arange(2200) % 180)).astype(np.float32); row["position"][:, 1] = np.arange(2200) // 180; row["radius"] = 0.01
+    clump = np.zeros(5000, brt.MODEL_DTYPE)    # many equal centroids among distinct ones: bins of very different fill
+    clump["position"] = np.round(rng.normal(0, 3, (5000, 3))).astype(np.float32); clump["radius"] = 0.3
+    zeros = np.zeros(700, brt.MODEL_DTYPE)     # box bounds of both zero signs: -0.0 from 0.25 - (0.15 + 0.1) style sums
+    zeros["position"] = rng.choice(np.array([-0.35, 0.35, 0.0, -0.0], np.float32), (700, 3)); zeros["radius"] = 0.25
+    scenes += [dup, line, plane, row, clump, zeros]
+    for bad in (np.nan, np.inf, -np.inf, 3e38, -1.0):      # non-finite spheres, negative radii: same tree, same (canonical) NaN bits
+        for n in (150, 2500):
+            m = np.zeros(n, brt.MODEL_DTYPE)
+            m["position"] = rng.uniform(-5, 5, (n, 3)).astype(np.float32)
+            m["radius"] = rng.uniform(0.1, 1.0, n).astype(np.float32)
+            m["position"][::7, 2] = bad
+            m["radius"][3::11] = bad
+            scenes.append(m)
+    return scenes
+
+
+def test_gpu_sah_build_is_byte_identical_to_cpu_build(plugin, oracle):
+    """SURVEY 8(f1) for the tree the product recommends: brt_sah.hip (what brt_upload_scene runs when the caller passes no BVH)
+    writes the bytes of the CPU statement of the rule (brt_build_bvh_sah; extract.rs:315-332 is what both replace)."""
+    for models in _sah_build_scenes():
+        cpu = brt.build_bvh_sah(models)
+        gpu, ms = plugin.build_bvh_sah(models)
+        assert len(cpu) == len(gpu) == 2 * len(models) - 1
+        assert np.array_equal(cpu.view(np.uint8), gpu.view(np.uint8)), f"n={len(models)}"
+        assert brt.validate_scene(models, np.zeros(max(1, int(models["material_id"].max()) + 1), brt.MATERIAL_DTYPE), gpu) <= 28
+        # and again: the build is deterministic (LDS atomics on integer keys, nothing depends on arrival order)
+        again, _ = plugin.build_bvh_sah(models)
+        assert np.array_equal(gpu.view(np.uint8), again.view(np.uint8))
+    # the upload path: pixels and all five counters through the GPU-built tree equal the oracle's on the CPU twin's tree
+    b = brt.generate_scene(brt.SCENE_STRESS_GRID, 1)
+    lvl, cam, win = brt.cover_camera(96, 54, 2, 4)
+    got = plugin.node.run(lvl, cam, win, 96, 54, buffers=brt.Buffers(b.models, b.materials, None), flags=brt.FLAG_COUNTERS)
+    stats = dict(plugin.node.last_stats)
+    want, cnt = oracle.render(brt.Buffers(b.models, b.materials, brt.build_bvh_sah(b.models)), lvl, cam, win, 96, 54)
+    assert_frames_equal(got, want)
+    assert {k: stats[k] for k in COUNTER_KEYS} == cnt
+    with plugin.tuning(BRT_CPU_BVH=1):          # the CPU twin inside brt_upload_scene: the same
+        got2 = plugin.node.run(lvl, cam, win, 96, 54, buffers=brt.Buffers(b.models, b.materials, None), flags=brt.FLAG_COUNTERS)
+        assert {k: plugin.node.last_stats[k] for k in COUNTER_KEYS} == cnt
+    assert_frames_equal(got2, want)
+
+
+def test_gpu_sah_build_time(plugin):
+    """VERDICT r3 task 1: <= 1.5 ms at 10 004 spheres, <= 0.3 ms at 506 (kernel time, HIP events; best of 5 after a warm-up).
+    The bounds asserted here carry a 2x margin for a busy box; scripts/sah_time.py prints the figures (profiles/r04/)."""
+    for kind, bound in ((brt.SCENE_COVER, 0.6), (brt.SCENE_STRESS_GRID, 3.0)):
+        m = brt.generate_scene(kind, 1).models
+        plugin.build_bvh_sah(m)
+        best = min(plugin.build_bvh_sah(m)[1] for _ in range(5))
+        print(f"GPU SAH build, {len(m)} spheres: {best:.3f} ms")
+        assert best <= bound, (len(m), best)
+
+
 @pytest.mark.parametrize("level", [0, 1, 2, 3])
 def test_sample_count_zero_is_zero_over_zero(plugin, oracle, level):
     """raytrace.wgsl:161-170 with sample_count 0: every channel is 0/0 = NaN (and the depth test of
@@ -630,15 +712,19 @@ def test_sample_count_zero_is_zero_over_zero(plugin, oracle, level):
     {"BRT_WALK_EXIT": "63", "BRT_REFILL_MIN": "9"}, {"BRT_WALK_EXIT": "40", "BRT_FORCE_GLOBAL_SCENE": "1"},
     {"BRT_LEAF_VOTE": "0"}, {"BRT_LEAF_VOTE": "64"}, {"BRT_LEAF_VOTE": "20", "BRT_WALK_EXIT": "0"},
     {"BRT_LEAF_VOTE": "3", "BRT_WALK_EXIT": "30", "BRT_BLOCK_THREADS": "256"},
-    # drain pool: off, eager, tiny pool (donations that do not fit), other workgroup shapes
-    {"BRT_DRAIN_DONATE": "0"}, {"BRT_DRAIN_DONATE": "56"}, {"BRT_DRAIN_DONATE": "8", "BRT_POOL_CAP": "16"},
-    {"BRT_DRAIN_DONATE": "40", "BRT_BLOCK_THREADS": "256"}, {"BRT_DRAIN_DONATE": "33", "BRT_FORCE_GLOBAL_SCENE": "1"},
-    {"BRT_DRAIN_DONATE": "48", "BRT_WALK_EXIT": "0", "BRT_BLOCK_THREADS": "512", "BRT_WG_PER_CU": "2"},
+    # drain pool: off, eager, tiny pool (donations that do not fit), other workgroup shapes.  BRT_POOL_FORCE=1: plan_launch
+    # switches the pool off for launches of at most ~2.5 tiles per wave slot (every frame of this size), so the pool cases force it on
+    {"BRT_DRAIN_DONATE": "0"}, {"BRT_DRAIN_DONATE": "56", "BRT_POOL_FORCE": "1"}, {"BRT_DRAIN_DONATE": "8", "BRT_POOL_CAP": "16", "BRT_POOL_FORCE": "1"},
+    {"BRT_DRAIN_DONATE": "40", "BRT_BLOCK_THREADS": "256", "BRT_POOL_FORCE": "1"}, {"BRT_DRAIN_DONATE": "33", "BRT_FORCE_GLOBAL_SCENE": "1", "BRT_POOL_FORCE": "1"},
+    {"BRT_DRAIN_DONATE": "48", "BRT_WALK_EXIT": "0", "BRT_BLOCK_THREADS": "512", "BRT_WG_PER_CU": "2", "BRT_POOL_FORCE": "1"},
+    {"BRT_POOL_FORCE": "1"}, {"BRT_POOL_FORCE": "1", "BRT_TUNABLE": "1"}, {"BRT_POOL_FORCE": "1", "BRT_POOL_CAP": "40"},
+    {"BRT_POOL_FORCE": "1", "BRT_LEAF_VOTE": "64", "BRT_WALK_EXIT": "63"},
     # workgroup share of the pixel queue: one tile at a time, the maximum, with other workgroup shapes
     {"BRT_WGQ_BATCH": "64"}, {"BRT_WGQ_BATCH": "512"}, {"BRT_WGQ_BATCH": "192", "BRT_BLOCK_THREADS": "256"},
     {"BRT_WGQ_BATCH": "512", "BRT_FORCE_GLOBAL_SCENE": "1", "BRT_REFILL_MIN": "5"},
     # who takes pooled paths over: nearly full waves too, only thin ones (thinner than the donors: paths wait in the pool)
-    {"BRT_POOL_ADOPT": "62"}, {"BRT_POOL_ADOPT": "20", "BRT_DRAIN_DONATE": "40"}, {"BRT_POOL_ADOPT": "0"},
+    {"BRT_POOL_ADOPT": "62", "BRT_POOL_FORCE": "1"}, {"BRT_POOL_ADOPT": "20", "BRT_DRAIN_DONATE": "40", "BRT_POOL_FORCE": "1"},
+    {"BRT_POOL_ADOPT": "0", "BRT_POOL_FORCE": "1"},
     # the knobs-live instantiation with every knob at its default; top-of-tree LDS tile of 1 / 37 / 300 / all records
     {"BRT_TUNABLE": "1"}, {"BRT_FORCE_LDS_TOP": "1"}, {"BRT_FORCE_LDS_TOP": "37"},
     {"BRT_FORCE_LDS_TOP": "300", "BRT_TUNABLE": "1"}, {"BRT_FORCE_LDS_TOP": "100000"},
@@ -654,8 +740,18 @@ def test_tuning_knobs_do_not_change_results(plugin, oracle, env):
         bb = brt.Buffers(b.models, b.materials, None) if "BRT_CPU_BVH" in env else b
         got = plugin.node.run(lvl, cam, win, 120, 68, buffers=bb, flags=brt.FLAG_COUNTERS)
         stats = dict(plugin.node.last_stats)
+        # ... and without the counters: the COUNTERS instantiation runs the compiler-built walk loop and rejection sampler, the
+        # shipped kernel the hand-written ones (walk_wave_lds_asm, ball_loop_asm: brt_device.h), whose leaf-vote rule differs
+        got_plain = plugin.node.run(lvl, cam, win, 120, 68, flags=0)
+        rays_plain = plugin.node.last_stats["rays"]
+        if "BRT_POOL_FORCE" in env:        # the forced launches really carried a pool
+            plugin.set_tuning("BRT_POOL_FORCE", 0)
+            plugin.node.run(lvl, cam, win, 120, 68)
+            assert plugin.node.last_stats["lds_bytes"] < stats["lds_bytes"]
     want, cnt = oracle.render(b, lvl, cam, win, 120, 68)
     assert_frames_equal(got, want)
+    assert_frames_equal(got_plain, want)
+    assert rays_plain == cnt["rays"]
     assert {k: stats[k] for k in COUNTER_KEYS} == cnt
     if "BRT_FORCE_GLOBAL_SCENE" in env:
         assert stats["scene_in_lds"] == 0
