@@ -14,7 +14,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("BRT_LIB_PATH") or os.path.join(_HERE, "libbevyray_amd.so")   # BRT_LIB_PATH: A/B of builds
-_SOURCES = ["brt_api.cpp", "brt_host.cpp", "brt_kernels.hip", "brt_trace_prod.hip", "brt_trace_tune.hip", "brt_trace.h",
+_SOURCES = ["brt_api.cpp", "brt_interop.cpp", "brt_ctx.h", "brt_host.cpp", "brt_kernels.hip", "brt_trace_prod.hip", "brt_trace_tune.hip", "brt_trace.h",
             "brt_host.h", "brt_kernels.h", "brt_layout.h", "brt_device.h", "brt_ploc.h", "brt_sah.h", "brt_bvh.hip", "brt_sah.hip", "brt_order.hip", "Makefile"]
 
 _lock = threading.Lock()
@@ -28,6 +28,7 @@ class BrtStats(C.Structure):
         ("kernel_ms", C.c_double), ("gather_ms", C.c_double), ("total_ms", C.c_double),
         ("lds_bytes", C.c_uint32), ("scene_in_lds", C.c_uint32), ("n_workgroups", C.c_uint32),
         ("threads_per_workgroup", C.c_uint32), ("prepass_ms", C.c_double),
+        ("kernel_variant", C.c_uint32), ("measured_tile_costs", C.c_uint32),
     ]
 
     def as_dict(self):
@@ -74,6 +75,14 @@ _PROTOTYPES = {
     "brt_render_device": (_I32, [_VP, _VP, _VP, _U32, _U32, _U32, _VP, _VP, _VP, _VP, _U32, C.POINTER(BrtStats)]),
     "brt_tile_rows": (_U32, [_U32, _U32]),
     "brt_deinterleave_device": (_I32, [_VP, _VP, _U32, _U32, _U32, _VP, _VP, _U32]),
+    "brt_rccl_unique_id": (_I32, [_VP]),
+    "brt_rccl_comm_create": (_I32, [_VP, _VP, _I32, _I32, C.POINTER(_VP)]),
+    "brt_rccl_comm_destroy": (_I32, [_VP, _VP]),
+    "brt_gather_rccl": (_I32, [_VP, _VP, _I32, _I32, _VP, _VP, _U32, _U32, _VP, _VP, _U32]),
+    "brt_import_frame_fd": (_I32, [_VP, _I32, C.c_uint64, _U32, C.POINTER(_VP)]),
+    "brt_release_frame": (_I32, [_VP, _VP]),
+    "brt_debug_export_frame_fd": (_I32, [_VP, C.c_uint64, C.POINTER(_I32), C.POINTER(_VP)]),
+    "brt_debug_copy_to_host": (_I32, [_VP, _VP, _VP, C.c_uint64]),
     "brt_debug_eval": (_I32, [_VP, _U32, _VP, _VP, _U32]),
     "brt_debug_profile": (_I32, [_VP, C.POINTER(C.c_uint64)]),
     "brt_debug_tile_order": (_I32, [_VP, _VP, _VP, _U32, _U32, C.c_uint64, _VP, _VP]),
@@ -118,7 +127,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.brt_abi_version() != 3:
+    if lib.brt_abi_version() != 4:
         raise RuntimeError("libbevyray_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -13,136 +13,11 @@
 #include <string>
 #include <vector>
 
-#include "brt_host.h"
-#include "brt_kernels.h"
+#include "brt_ctx.h"
 
 using namespace brt;
 
 namespace {
-
-struct DeviceCtx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t ev_last = nullptr;   // end of the last launch that used the control block (any stream)
-    hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;   // around the dispatch-order pre-pass of a first frame
-    int num_cus = 0;
-    size_t max_lds = 0;
-    // scene
-    char* d_scene = nullptr;
-    size_t scene_cap = 0;
-    DeviceSceneView view{};
-    // control block: 32 x u64 counters @0 (5 stats + section profile @8..23), queue counter @256
-    char* d_ctrl = nullptr;
-    // frame-sized buffers owned by the context (brt_render)
-    float* d_tile = nullptr;
-    size_t tile_cap = 0;
-    float* d_raster_rgba = nullptr;
-    size_t raster_rgba_cap = 0;
-    float* d_raster_depth = nullptr;
-    size_t raster_depth_cap = 0;
-    float* d_gather = nullptr;   // first device only: the tiles of all devices back to back (brt_render_device)
-    size_t gather_cap = 0;
-    hipEvent_t ev_copy = nullptr;   // this device's tile has arrived in the first device's gather buffer
-    hipEvent_t ev_asm = nullptr;    // first device: the frame of the last brt_render_device call is assembled (the gather buffer is free)
-    hipEvent_t ev_in = nullptr;     // first device: the caller's stream at the start of a brt_render_device call
-    hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr;   // first device: around waiting for the tiles + de-interleave
-    float* h_stage = nullptr;  // pinned
-    size_t stage_cap = 0;
-    // longest-first dispatch (see plan_tile_order): this frame's per-tile ray counts and the
-    // order derived from the previous frame of the same view
-    uint32_t* d_tile_cost = nullptr;
-    size_t tile_cost_cap = 0;
-    uint32_t* d_tile_order = nullptr;
-    uint32_t order_lane = 0;                             // tiles of the lane queue; the rest of d_tile_order is the tile queue
-    uint32_t order_crit = 0;                             // d_tile_order[0 .. crit) are the CRITICAL tiles
-    size_t tile_order_cap = 0;
-    uint32_t* d_order_meta = nullptr;                    // order built on the GPU: [0] critical tiles, [1] longest pixel
-    char* d_order_scratch = nullptr;
-    size_t order_scratch_cap = 0;
-    bool order_on_device = false;                        // d_tile_order / d_order_meta were written by brt_order.hip
-    uint64_t view_rays = 0;                              // rays of the last completed frame of the view `view_key` (0: unknown)
-    uint32_t view_key[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // order key + sample_count, bounce_count
-    bool order_valid = false;
-    uint32_t order_age = 0;                       // frames since the costs were last measured
-    uint32_t order_key[6] = {0, 0, 0, 0, 0, 0};   // width, height, part, n_parts, scene epoch, n_tiles
-    std::vector<uint32_t> h_cost;
-    std::vector<uint32_t> h_order;
-    // GPU BVH build
-    char* d_bvh_scratch = nullptr;
-    size_t bvh_scratch_cap = 0;
-    char* d_bvh_models = nullptr;
-    size_t bvh_models_cap = 0;
-};
-
-
-// ---- tuning knobs -----------------------------------------------------------------------------------------------------
-// Scheduling / launch-shape knobs of the trace path.  None of them changes a pixel (every one has a test that says so).
-// They live in the context: brt_set_tuning(ctx, name, value) sets one; brt_create reads the environment variables of the
-// same names ONCE, and only when BRT_ENABLE_TUNING=1 is set -- nothing reads the environment per frame, and the one
-// switch that does change pixels (the reading of `||` in raytrace.wgsl:269) is not a knob at all: brt_set_policy.
-enum Knob : int {
-    K_BOTTOM_UP, K_REFILL_MIN, K_WALK_EXIT, K_LEAF_VOTE, K_DRAIN_DONATE, K_POOL_ADOPT, K_WGQ_BATCH, K_LPT_LANE_PERMILLE, K_TUNABLE,
-    K_FORCE_GLOBAL_SCENE, K_FORCE_LDS_TOP, K_BLOCK_THREADS, K_WG_PER_CU, K_POOL_CAP, K_LPT, K_LPT_SORT, K_LPT_SKY_SLACK, K_CRIT,
-    K_ORDER_ON_HOST, K_NO_LEAN, K_PREPASS_SPP, K_NO_DIRTY_TRACKING, K_CPU_BVH, K_PLOC_ONE_BLOCK_MAX, K_BVH_QUALITY, K_POOL_FORCE, K_COUNT
-};
-struct KnobDef { const char* name; uint32_t dflt; };
-constexpr KnobDef kKnobs[K_COUNT] = {
-    {"BRT_BOTTOM_UP", 0}, {"BRT_REFILL_MIN", kRefillMin}, {"BRT_WALK_EXIT", kWalkExitLanes}, {"BRT_LEAF_VOTE", kLeafVote},
-    {"BRT_DRAIN_DONATE", kDrainDonate}, {"BRT_POOL_ADOPT", kPoolAdopt}, {"BRT_WGQ_BATCH", 0}, {"BRT_LPT_LANE_PERMILLE", 0},
-    {"BRT_TUNABLE", 0}, {"BRT_FORCE_GLOBAL_SCENE", 0}, {"BRT_FORCE_LDS_TOP", 0}, {"BRT_BLOCK_THREADS", 0}, {"BRT_WG_PER_CU", 0},
-    {"BRT_POOL_CAP", 384}, {"BRT_LPT", 1}, {"BRT_LPT_SORT", 1}, {"BRT_LPT_SKY_SLACK", 20}, {"BRT_CRIT", 1}, {"BRT_ORDER_ON_HOST", 0},
-    {"BRT_NO_LEAN", 0}, {"BRT_PREPASS_SPP", 2}, {"BRT_NO_DIRTY_TRACKING", 0}, {"BRT_CPU_BVH", 0},
-    {"BRT_PLOC_ONE_BLOCK_MAX", kPlocOneBlockMax}, {"BRT_BVH_QUALITY", 1}, {"BRT_POOL_FORCE", 0}};
-struct Knobs {
-    uint32_t v[K_COUNT];
-    Knobs() { for (int i = 0; i < K_COUNT; i++) v[i] = kKnobs[i].dflt; }
-    uint32_t operator[](Knob k) const { return v[k]; }
-};
-
-}  // namespace
-
-struct brt_ctx {
-    std::vector<DeviceCtx> devs;
-    EncodedScene enc;
-    bool has_scene = false;
-    uint32_t scene_epoch = 0;   // bumped by every upload
-    uint32_t last_n_models = 0; // spheres of the last successful upload
-    std::vector<std::pair<char*, size_t>> pinned;   // brt_host_alloc blocks
-    // bytes of the last successful upload (dirty tracking: an unchanged scene is not re-sent)
-    std::vector<char> last_models, last_materials, last_bvh;
-    Knobs knobs;                // tuning knobs (brt_set_tuning; environment once at brt_create under BRT_ENABLE_TUNING=1)
-    uint32_t policy_flags = 0;  // brt_set_policy
-    std::string last_error;
-};
-
-namespace {
-
-int32_t ctx_fail(brt_ctx* ctx, int32_t code, const std::string& msg) {
-    if (ctx) ctx->last_error = msg;
-    g_last_error = msg;
-    return code;
-}
-
-#define HIP_TRY(ctx, expr)                                                                              \
-    do {                                                                                                \
-        hipError_t _e = (expr);                                                                         \
-        if (_e != hipSuccess)                                                                           \
-            return ctx_fail(ctx, BRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));       \
-    } while (0)
-
-template <typename T>
-int32_t ensure(brt_ctx* ctx, T** ptr, size_t* cap, size_t bytes) {
-    if (*cap >= bytes && *ptr) return BRT_OK;
-    if (*ptr) HIP_TRY(ctx, hipFree(*ptr));
-    *ptr = nullptr;
-    *cap = 0;
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(ptr), bytes));
-    *cap = bytes;
-    return BRT_OK;
-}
-
-inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 uint32_t env_u32(const char* name, uint32_t dflt) {
     const char* v = std::getenv(name);
@@ -231,6 +106,8 @@ struct LaunchPlan {
     uint32_t block, grid, wg_per_cu;
     uint32_t pool_cap;           // records of the drain pool per workgroup (0: none)
     size_t lds_bytes;
+    uint32_t variant;            // brt_stats::kernel_variant of the launch
+    uint32_t measured;           // the launch measured the tile costs
 };
 
 // Choose the kernel variant and grid.
@@ -335,12 +212,26 @@ bool is_pinned(const brt_ctx* ctx, const void* p, size_t bytes) {
 
 // Dispatch order of the 8x8 tiles (brt_host.cpp build_tile_order has the rule).  The cost of a tile is not
 // known in advance, but a renderer draws nearly the same frame again and again: the kernel measures the rays
-// each tile needed (sum and longest pixel: two atomics per finished pixel, every kLptRefresh-th frame of a
-// view) and the next frames use the order built from that.  Pixels never change, only the queue order does.
+// each tile needed (sum and longest pixel: two atomics per finished pixel, on the frames named below) and the next
+// frames use the order built from that.  Pixels never change, only the queue order does.
 // BRT_LPT=0 disables (raster order); BRT_LPT_SORT, BRT_LPT_LANE_PERMILLE, BRT_LPT_SKY_SLACK, BRT_CRIT: see
 // update_tile_order.
-constexpr uint32_t kLptRefresh = 64, kLptAfterUpload = 4;   // (64: a view whose key and scene do not change has nothing new to measure; 16 until round 3 cost the steady state two slower frames in 32)
+// When the costs are measured again (round 4; the measurement itself runs in the LEAN instantiations now and costs a frame ~1 %):
+//   * never for a view whose camera and scene do not change: there is nothing new to measure (until round 3: every 64th frame);
+//   * EVERY frame while the camera moves (the reference's demo is a fly-camera app, src/main.rs:40): the order a frame runs in
+//     is then the one measured on the frame before it -- one frame stale instead of up to 64;
+//   * within kLptAfterUpload frames of a scene upload (an animated scene re-uploads every frame, extract.rs:299-336).
+// The order is a hint: a stale one costs speed, never a pixel.
+constexpr uint32_t kLptAfterUpload = 4;
 bool lpt_enabled(const brt_ctx* ctx) { return ctx->knobs[K_LPT] != 0; }
+uint64_t camera_hash(const FrameParams& fp) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const float* f, int n) {
+        for (int i = 0; i < n; i++) { uint32_t u; std::memcpy(&u, f + i, 4); h = (h ^ u) * 1099511628211ull; }
+    };
+    mix(fp.cam_pos, 3); mix(fp.cam_dir, 3); mix(fp.cam_up, 3); mix(&fp.tan_half_fov, 1); mix(&fp.aspect, 1);
+    return h | 1ull;    // never 0 (= "not measured yet")
+}
 
 // The dispatch order only depends on which tiles hold long pixels: it survives a scene upload (an animated scene
 // re-uploads every frame, extract.rs:299-336, and moves little between two frames) and is measured again soon after one
@@ -356,7 +247,7 @@ void view_key_of(const brt_ctx* ctx, const FrameParams& fp, uint32_t key[8]) {
 }
 
 // before the launch: attach the order table if the history matches this view, and -- when the
-// history is missing or kLptRefresh frames old -- the (zeroed) cost buffer to measure again
+// history is missing, the camera has moved or a scene upload asks for it -- the (zeroed) cost buffer to measure again
 int32_t attach_tile_order(brt_ctx* ctx, DeviceCtx& dc, FrameParams& fp, hipStream_t stream, bool may_measure) {
     fp.tile_order = nullptr;
     fp.tile_cost = nullptr;
@@ -372,7 +263,9 @@ int32_t attach_tile_order(brt_ctx* ctx, DeviceCtx& dc, FrameParams& fp, hipStrea
         fp.crit_end = dc.order_crit * 64u;
         fp.order_meta = dc.order_on_device ? dc.d_order_meta : nullptr;   // then the kernel reads the critical count there
     }
-    if (may_measure && (!match || ++dc.order_age >= kLptRefresh)) {
+    bool due = !match || camera_hash(fp) != dc.order_cam || ctx->knobs[K_LPT_REFRESH_EVERY] == 1u;
+    if (may_measure && match && dc.remeasure_in != 0u && --dc.remeasure_in == 0u) due = true;
+    if (may_measure && due) {
         int32_t rc = ensure(ctx, &dc.d_tile_cost, &dc.tile_cost_cap, (size_t)n_tiles * 8);   // sums, then maxima
         if (rc != BRT_OK) return rc;
         HIP_TRY(ctx, hipMemsetAsync(dc.d_tile_cost, 0, (size_t)n_tiles * 8, stream));
@@ -423,7 +316,8 @@ int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hi
     }
     order_key_of(ctx, fp, dc.order_key);
     dc.order_valid = true;
-    dc.order_age = 0;
+    dc.remeasure_in = 0;
+    dc.order_cam = camera_hash(fp);
     return BRT_OK;
 }
 
@@ -466,9 +360,11 @@ int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const fl
                 const bool known = dc.view_rays != 0 && std::memcmp(key, dc.view_key, sizeof key) == 0;
                 const uint64_t per_lane = known ? dc.view_rays / ((uint64_t)dc.num_cus * BRT_BLOCK) : 0;
                 const uint64_t longest_bound = (uint64_t)fp.sample_count * ((uint64_t)fp.bounce_count + 1u);
-                const bool lean1 = !tl.frame.tunable && fp.level == 3u && fp.tile_cost == nullptr && !tl.counters_on &&
-                                   ctx->knobs[K_NO_LEAN] == 0u;
+                const bool lean1 = !tl.frame.tunable && fp.level == 3u && !tl.counters_on && ctx->knobs[K_NO_LEAN] == 0u &&
+                                   (fp.tile_cost == nullptr || ctx->knobs[K_LEAN_MEASURE] != 0u);
                 tl.lean = !lean1 ? 0 : ((known && longest_bound < per_lane / 2) ? 2 : 1);
+                lp.variant = (uint32_t)tl.lean | (tl.frame.tunable ? 16u : 0u);
+                lp.measured = fp.tile_cost != nullptr ? 1u : 0u;
             }
             tl.scene_mode = lp.scene_mode;
             tl.scene.lds_pairs = lp.lds_pairs;
@@ -531,7 +427,7 @@ int32_t prepass_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const 
     HIP_TRY(ctx, hipEventRecord(dc.ev_p1, stream));
     rc = update_tile_order(ctx, dc, pp, stream);      // on the GPU, behind the pre-pass, no host round trip (default settings)
     if (rc != BRT_OK) return rc;
-    dc.order_age = kLptRefresh - 1u;                  // the frame that follows measures again, at full sample count
+    dc.remeasure_in = 1u;                             // the frame that follows measures again, at full sample count
     *ran = true;
     return BRT_OK;
 }
@@ -756,6 +652,7 @@ int32_t brt_host_free(brt_ctx* ctx, void* ptr) {
 
 int32_t brt_destroy(brt_ctx* ctx) {
     if (!ctx) return BRT_OK;
+    release_external_frames(ctx);
     for (auto& b : ctx->pinned) (void)hipHostFree(b.first);
     for (auto& d : ctx->devs) free_device(d);
     delete ctx;
@@ -849,7 +746,7 @@ int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, co
     ctx->last_n_models = n_models;
     for (auto& dc : ctx->devs) {
         if (!same_shape) { dc.order_valid = false; dc.view_rays = 0; }
-        else if (dc.order_valid && dc.order_age + kLptAfterUpload < kLptRefresh) dc.order_age = kLptRefresh - kLptAfterUpload;
+        else if (dc.order_valid && (dc.remeasure_in == 0u || dc.remeasure_in > kLptAfterUpload)) dc.remeasure_in = kLptAfterUpload;
     }
     return BRT_OK;
 }
@@ -908,6 +805,8 @@ int32_t render_part_device(brt_ctx* ctx, const void* camera80, const void* windo
         stats->scene_in_lds = lp.scene_mode == SCENE_LDS ? 1u : (lp.scene_mode == SCENE_LDS_TOP ? 2u : 0u);
         stats->n_workgroups = lp.grid;
         stats->threads_per_workgroup = lp.block;
+        stats->kernel_variant = lp.variant;
+        stats->measured_tile_costs = lp.measured;
     }
     if (own_stream) {
         // the order of the next frames is built on the same stream behind the frame, BEFORE the one synchronisation of this
@@ -1042,6 +941,8 @@ int32_t render_frame(brt_ctx* ctx, const void* camera80, const void* window16, u
         stats->scene_in_lds = lp.scene_mode == SCENE_LDS ? 1u : (lp.scene_mode == SCENE_LDS_TOP ? 2u : 0u);
         stats->n_workgroups = lp.grid;
         stats->threads_per_workgroup = lp.block;
+        stats->kernel_variant = lp.variant;
+        stats->measured_tile_costs = lp.measured;
     }
     return BRT_OK;
 }
@@ -1179,6 +1080,8 @@ int32_t render_frame_device(brt_ctx* ctx, const void* camera80, const void* wind
         stats->scene_in_lds = lp.scene_mode == SCENE_LDS ? 1u : (lp.scene_mode == SCENE_LDS_TOP ? 2u : 0u);
         stats->n_workgroups = lp.grid;
         stats->threads_per_workgroup = lp.block;
+        stats->kernel_variant = lp.variant;
+        stats->measured_tile_costs = lp.measured;
     }
     return BRT_OK;
 }

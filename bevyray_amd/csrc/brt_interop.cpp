@@ -1,0 +1,282 @@
+// brt_interop.cpp -- the two places where the render node meets memory and processes that are not its own:
+//
+//   * the ONE collective of the path: one process per GPU, every rank's tile to rank 0 in one ncclGather
+//     (/opt/rocm/include/rccl/rccl.h:745), then the de-interleave kernel -- behind the C ABI, so that a host with no RCCL
+//     binding of its own (the Rust node) can run the multi-process form.  librccl is resolved with dlopen at first use:
+//     a single-GPU host needs no RCCL at all, and a process that already has one loaded (PyTorch bundles its own copy
+//     under the same SONAME) keeps using THAT one.
+//   * frame targets that live in another API's memory: the reference's pass renders straight into
+//     post_process.destination (pipeline.rs:191-203); a wgpu/Vulkan host exports that buffer's memory as a file descriptor
+//     (VK_KHR_external_memory_fd) and brt_import_frame_fd maps it, so that brt_render_device writes the frame where the
+//     next pass reads it -- no copy.
+//
+// No ray arithmetic here.
+#include <dlfcn.h>
+#include <unistd.h>
+
+#include <mutex>
+
+#include "brt_ctx.h"
+
+using namespace brt;
+
+namespace {
+
+// ---- RCCL by dlopen --------------------------------------------------------------------------------------------------
+struct NcclId { char internal[128]; };          // ncclUniqueId (rccl.h:43), passed by value to ncclCommInitRank
+constexpr int kNcclFloat = 7;                   // ncclFloat32 (rccl.h:466)
+
+struct Rccl {
+    void* lib = nullptr;
+    int (*get_unique_id)(NcclId*) = nullptr;                                                   // rccl.h:187
+    int (*comm_init_rank)(void**, int, NcclId, int) = nullptr;                                 // rccl.h:220
+    int (*comm_destroy)(void*) = nullptr;                                                      // rccl.h:260
+    int (*gather)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;         // rccl.h:745
+    const char* (*error_string)(int) = nullptr;                                                // rccl.h:339
+    std::string why;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a copy that is already in the process (PyTorch's, or the host's own) first: two RCCLs in one process work, but each
+        // would bring up its own transports
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names)
+            if ((r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+        for (const char* n : names) {
+            if (r.lib) break;
+            r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        }
+        if (!r.lib) { r.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return; }
+        auto sym = [&](const char* name) {
+            void* p = dlsym(r.lib, name);
+            if (!p && r.why.empty()) r.why = std::string("librccl has no ") + name;
+            return p;
+        };
+        r.get_unique_id = reinterpret_cast<decltype(r.get_unique_id)>(sym("ncclGetUniqueId"));
+        r.comm_init_rank = reinterpret_cast<decltype(r.comm_init_rank)>(sym("ncclCommInitRank"));
+        r.comm_destroy = reinterpret_cast<decltype(r.comm_destroy)>(sym("ncclCommDestroy"));
+        r.gather = reinterpret_cast<decltype(r.gather)>(sym("ncclGather"));
+        r.error_string = reinterpret_cast<decltype(r.error_string)>(sym("ncclGetErrorString"));
+        if (!r.why.empty()) r.lib = nullptr;
+    });
+    return r;
+}
+
+int32_t nccl_fail(brt_ctx* ctx, const char* what, int rc) {
+    Rccl& r = rccl();
+    return ctx_fail(ctx, BRT_ERR_RCCL, std::string(what) + ": " + (r.error_string ? r.error_string(rc) : "error") + " (" + std::to_string(rc) + ")");
+}
+
+// ---- external memory -------------------------------------------------------------------------------------------------
+int32_t map_vmm(brt_ctx* ctx, int device, hipMemGenericAllocationHandle_t h, size_t bytes, void** out_ptr) {
+    void* p = nullptr;
+    HIP_TRY(ctx, hipMemAddressReserve(&p, bytes, 0, nullptr, 0));
+    hipError_t e = hipMemMap(p, bytes, 0, h, 0);
+    if (e == hipSuccess) {
+        hipMemAccessDesc ad{};
+        ad.location.type = hipMemLocationTypeDevice;
+        ad.location.id = device;
+        ad.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(p, bytes, &ad, 1);
+        if (e != hipSuccess) (void)hipMemUnmap(p, bytes);
+    }
+    if (e != hipSuccess) {
+        (void)hipMemAddressFree(p, bytes);
+        return ctx_fail(ctx, BRT_ERR_HIP, std::string("mapping the allocation: ") + hipGetErrorString(e));
+    }
+    *out_ptr = p;
+    return BRT_OK;
+}
+
+void release_one(ExternalFrame& f) {
+    if (f.type == BRT_EXTMEM_OPAQUE_FD) {
+        if (f.ptr) (void)hipFree(f.ptr);
+        if (f.ext) (void)hipDestroyExternalMemory(f.ext);
+    } else {
+        if (f.ptr) { (void)hipMemUnmap(f.ptr, f.mapped); (void)hipMemAddressFree(f.ptr, f.mapped); }
+        (void)hipMemRelease(f.vmm);
+    }
+    f = ExternalFrame();
+}
+
+size_t vmm_granularity(int device) {
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    prop.requestedHandleType = hipMemHandleTypePosixFileDescriptor;
+    size_t g = 0;
+    if (hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || g == 0) g = 2u << 20;
+    return g;
+}
+
+}  // namespace
+
+namespace brt {
+void release_external_frames(brt_ctx* ctx) {
+    if (ctx->external.empty()) return;
+    if (hipSetDevice(ctx->devs[0].device) != hipSuccess) return;
+    for (auto& f : ctx->external) release_one(f);
+    ctx->external.clear();
+}
+}  // namespace brt
+
+extern "C" {
+
+int32_t brt_rccl_unique_id(void* out_id128) {
+    if (!out_id128) return fail(BRT_ERR_INVALID_ARGUMENT, "out_id128 is null");
+    Rccl& r = rccl();
+    if (!r.lib) return fail(BRT_ERR_RCCL, r.why);
+    NcclId id;
+    const int rc = r.get_unique_id(&id);
+    if (rc != 0) return nccl_fail(nullptr, "ncclGetUniqueId", rc);
+    std::memcpy(out_id128, &id, sizeof id);
+    return BRT_OK;
+}
+
+int32_t brt_rccl_comm_create(brt_ctx* ctx, const void* id128, int32_t rank, int32_t world, void** out_comm) {
+    if (!ctx || !id128 || !out_comm) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
+    *out_comm = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "rank / world out of range");
+    Rccl& r = rccl();
+    if (!r.lib) return ctx_fail(ctx, BRT_ERR_RCCL, r.why);
+    HIP_TRY(ctx, hipSetDevice(ctx->devs[0].device));       // the communicator binds to the current device: one process per GPU
+    NcclId id;
+    std::memcpy(&id, id128, sizeof id);
+    void* comm = nullptr;
+    const int rc = r.comm_init_rank(&comm, world, id, rank);
+    if (rc != 0) return nccl_fail(ctx, "ncclCommInitRank", rc);
+    *out_comm = comm;
+    return BRT_OK;
+}
+
+int32_t brt_rccl_comm_destroy(brt_ctx* ctx, void* comm) {
+    if (!comm) return BRT_OK;
+    Rccl& r = rccl();
+    if (!r.lib) return ctx_fail(ctx, BRT_ERR_RCCL, r.why);
+    if (ctx) HIP_TRY(ctx, hipSetDevice(ctx->devs[0].device));
+    const int rc = r.comm_destroy(comm);
+    return rc == 0 ? BRT_OK : nccl_fail(ctx, "ncclCommDestroy", rc);
+}
+
+int32_t brt_gather_rccl(brt_ctx* ctx, void* nccl_comm, int32_t rank, int32_t world, const float* d_tile, float* d_tiles_on_root,
+                        uint32_t width, uint32_t height, float* d_frame_on_root, void* hip_stream, uint32_t flags) {
+    if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (!nccl_comm || !d_tile) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "null communicator / tile");
+    if (world < 1 || rank < 0 || rank >= world) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "rank / world out of range");
+    if (rank == 0 && !d_tiles_on_root) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "rank 0 needs the receive buffer");
+    if (width == 0 || height == 0) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "empty frame");
+    Rccl& r = rccl();
+    if (!r.lib) return ctx_fail(ctx, BRT_ERR_RCCL, r.why);
+    DeviceCtx& dc = ctx->devs[0];
+    HIP_TRY(ctx, hipSetDevice(dc.device));
+    const bool own_stream = (hip_stream == nullptr) && !(flags & BRT_FLAG_CALLER_STREAM);
+    hipStream_t stream = own_stream ? dc.stream : static_cast<hipStream_t>(hip_stream);
+    const uint32_t tile_rows = brt_tile_rows(height, (uint32_t)world);
+    const size_t count = (size_t)tile_rows * width * 4;                                           // floats per rank
+    const int rc = r.gather(d_tile, d_tiles_on_root, count, kNcclFloat, 0, nccl_comm, stream);      // THE collective of the path
+    if (rc != 0) return nccl_fail(ctx, "ncclGather", rc);
+    if (rank == 0 && d_frame_on_root)
+        HIP_TRY(ctx, launch_deinterleave(d_tiles_on_root, d_frame_on_root, width, height, (uint32_t)world, tile_rows, stream));
+    if (own_stream) HIP_TRY(ctx, hipStreamSynchronize(stream));
+    return BRT_OK;
+}
+
+int32_t brt_import_frame_fd(brt_ctx* ctx, int32_t fd, uint64_t bytes, uint32_t handle_type, float** out_d_frame) {
+    if (!ctx || !out_d_frame) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
+    *out_d_frame = nullptr;
+    if (fd < 0 || bytes == 0) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "bad file descriptor / zero size");
+    DeviceCtx& dc = ctx->devs[0];
+    HIP_TRY(ctx, hipSetDevice(dc.device));
+    ExternalFrame f;
+    f.type = handle_type;
+    f.bytes = (size_t)bytes;
+    if (handle_type == BRT_EXTMEM_OPAQUE_FD) {
+        // what a Vulkan allocation exported with VK_EXTERNAL_MEMORY_HANDLE_TYPE_OPAQUE_FD_BIT hands over (on success the
+        // runtime owns the descriptor)
+        hipExternalMemoryHandleDesc hd{};
+        hd.type = hipExternalMemoryHandleTypeOpaqueFd;
+        hd.handle.fd = fd;
+        hd.size = bytes;
+        HIP_TRY(ctx, hipImportExternalMemory(&f.ext, &hd));
+        hipExternalMemoryBufferDesc bd{};
+        bd.offset = 0;
+        bd.size = bytes;
+        const hipError_t e = hipExternalMemoryGetMappedBuffer(&f.ptr, f.ext, &bd);
+        if (e != hipSuccess) {
+            (void)hipDestroyExternalMemory(f.ext);
+            return ctx_fail(ctx, BRT_ERR_HIP, std::string("hipExternalMemoryGetMappedBuffer: ") + hipGetErrorString(e));
+        }
+    } else if (handle_type == BRT_EXTMEM_DMABUF_FD) {
+        // a dma-buf of a HIP virtual-memory allocation in another process or API (hipMemExportToShareableHandle)
+        HIP_TRY(ctx, hipMemImportFromShareableHandle(&f.vmm, reinterpret_cast<void*>(static_cast<uintptr_t>(fd)), hipMemHandleTypePosixFileDescriptor));
+        const size_t g = vmm_granularity(dc.device);
+        f.mapped = (f.bytes + g - 1) / g * g;
+        const int32_t rc = map_vmm(ctx, dc.device, f.vmm, f.mapped, &f.ptr);
+        if (rc != BRT_OK) { (void)hipMemRelease(f.vmm); return rc; }
+    } else {
+        return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "unknown external-memory handle type");
+    }
+    ctx->external.push_back(f);
+    *out_d_frame = static_cast<float*>(f.ptr);
+    return BRT_OK;
+}
+
+int32_t brt_release_frame(brt_ctx* ctx, float* d_frame) {
+    if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
+    for (size_t i = 0; i < ctx->external.size(); i++)
+        if (ctx->external[i].ptr == d_frame) {
+            HIP_TRY(ctx, hipSetDevice(ctx->devs[0].device));
+            for (auto& dc : ctx->devs) {          // nothing of this context may still be writing into it
+                if (hipSetDevice(dc.device) == hipSuccess) { (void)hipEventSynchronize(dc.ev_last); (void)hipEventSynchronize(dc.ev_asm); }
+            }
+            HIP_TRY(ctx, hipSetDevice(ctx->devs[0].device));
+            release_one(ctx->external[i]);
+            ctx->external.erase(ctx->external.begin() + (long)i);
+            return BRT_OK;
+        }
+    return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "pointer was not returned by brt_import_frame_fd / brt_debug_export_frame_fd");
+}
+
+int32_t brt_debug_export_frame_fd(brt_ctx* ctx, uint64_t bytes, int32_t* out_fd, float** out_d_ptr) {
+    if (!ctx || !out_fd || !out_d_ptr || bytes == 0) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer / zero size");
+    *out_fd = -1;
+    *out_d_ptr = nullptr;
+    DeviceCtx& dc = ctx->devs[0];
+    HIP_TRY(ctx, hipSetDevice(dc.device));
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dc.device;
+    prop.requestedHandleType = hipMemHandleTypePosixFileDescriptor;
+    const size_t g = vmm_granularity(dc.device);
+    ExternalFrame f;
+    f.type = BRT_EXTMEM_DMABUF_FD;
+    f.bytes = (size_t)bytes;
+    f.mapped = (f.bytes + g - 1) / g * g;
+    HIP_TRY(ctx, hipMemCreate(&f.vmm, f.mapped, &prop, 0));
+    int fd = -1;
+    hipError_t e = hipMemExportToShareableHandle(&fd, f.vmm, hipMemHandleTypePosixFileDescriptor, 0);
+    if (e != hipSuccess) {
+        (void)hipMemRelease(f.vmm);
+        return ctx_fail(ctx, BRT_ERR_HIP, std::string("hipMemExportToShareableHandle: ") + hipGetErrorString(e));
+    }
+    const int32_t rc = map_vmm(ctx, dc.device, f.vmm, f.mapped, &f.ptr);
+    if (rc != BRT_OK) { (void)close(fd); (void)hipMemRelease(f.vmm); return rc; }
+    ctx->external.push_back(f);
+    *out_fd = fd;
+    *out_d_ptr = static_cast<float*>(f.ptr);
+    return BRT_OK;
+}
+
+int32_t brt_debug_copy_to_host(brt_ctx* ctx, const void* d_src, void* h_dst, uint64_t bytes) {
+    if (!ctx || !d_src || !h_dst) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->devs[0].device));
+    HIP_TRY(ctx, hipMemcpy(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return BRT_OK;
+}
+
+}  // extern "C"

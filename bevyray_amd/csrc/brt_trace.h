@@ -163,7 +163,9 @@ BRT_DEV void shade_landed(const ScenePtrs& sc, const FrameParams& fp, bool lande
         need_cam = true;
         if (ps.sample == fp.sample_count) {
             pixel_finish<LEAN != 0>(fp, ps, out_tile, raster_rgba, raster_depth);
-            if (!LEAN && fp.tile_cost) {
+            // (in the LEAN instantiations too since round 4: a view whose camera moves measures every frame -- launch_part -- and
+            //  must not fall back to the general instantiation for it)
+            if (fp.tile_cost) {
                 atomicAdd(&fp.tile_cost[ps.tile], n_rays - ps.rays_begin);
                 atomicMax(&fp.tile_cost[fp.local_strips * fp.tiles_x + ps.tile], n_rays - ps.rays_begin);
             }
@@ -326,8 +328,7 @@ BRT_DEV uint32_t pool_peek(const uint32_t* ctl, int i) { return __atomic_load_n(
 // staging.  D16: 16-bit descriptors and u16 stack entries (always with the LDS modes).  SIMPLE: see raycast
 // (brt_device.h).  TUNABLE: tuning knobs live (FrameParams) instead of folded to their defaults, lane queue built in.
 // LEAN: what the steady-state frame of a Pure-level view needs and nothing else, so that the other checks, registers
-// and kernel arguments leave the round loop.  1: level 3 (no raster inputs, no depth average) and no tile-cost
-// measurement; 2: also no critical tiles (the host can rule them out: launch_part).  (A/B at the time it went in, round 2:
+// and kernel arguments leave the round loop.  1: level 3 (no raster inputs, no depth average); 2: also no critical tiles (the host can rule them out: launch_part).  (A/B at the time it went in, round 2:
 // headline frame 12.87 (0) -> 12.73 (1) -> 12.59 ms (2); current timings: docs/experiments.md.)
 template <int MODE, bool D16, bool SIMPLE, bool COUNTERS, bool TUNABLE, int LEAN>
 __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView sv, FrameParams fp,
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                         rec[0] = make_float4(ps.ndc0x, ps.ndc0y, ps.sum.x, ps.sum.y);
                         rec[1] = make_float4(ps.sum.z, ps.dsum, __uint_as_float(ps.rng), __uint_as_float(ps.sample));
                         rec[2] = make_float4(__uint_as_float(ps.out_index), __uint_as_float(ps.frame_index),
-                                             __uint_as_float(LEAN ? 0u : ps.tile), __uint_as_float(LEAN ? 0u : n_rays - ps.rays_begin));
+                                             __uint_as_float(ps.tile), __uint_as_float(n_rays - ps.rays_begin));
                         rec[3] = make_float4(o.x, o.y, o.z, d.x);
                         rec[4] = make_float4(d.y, d.z, tput.x, tput.y);
                         rec[5] = make_float4(tput.z, __uint_as_float(bounce), first_depth, __uint_as_float((crit ? 1u : 0u) | (need_cam ? 2u : 0u)));
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                         ps.ndc0x = r0.x; ps.ndc0y = r0.y; ps.sum = mk3(r0.z, r0.w, r1.x); ps.dsum = r1.y;
                         ps.rng = __float_as_uint(r1.z); ps.sample = __float_as_uint(r1.w);
                         ps.out_index = __float_as_uint(r2.x); ps.frame_index = __float_as_uint(r2.y);
-                        if (!LEAN) { ps.tile = __float_as_uint(r2.z); ps.rays_begin = n_rays - __float_as_uint(r2.w); }
+                        ps.tile = __float_as_uint(r2.z); ps.rays_begin = n_rays - __float_as_uint(r2.w);
                         o = mk3(r3.x, r3.y, r3.z); d = mk3(r3.w, r4.x, r4.y); tput = mk3(r4.z, r4.w, r5.x);
                         bounce = __float_as_uint(r5.y); first_depth = r5.z;
                         crit = (__float_as_uint(r5.w) & 1u) != 0u; need_cam = (__float_as_uint(r5.w) & 2u) != 0u;

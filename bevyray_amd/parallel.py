@@ -30,12 +30,53 @@ def frame_rows_of_part(height: int, part: int, n_parts: int) -> np.ndarray:
     return rows
 
 
-def gather_frame(tile, height: int, rank: int, world: int, node=None, group=None):
+class RcclGather:
+    """The gather of the path through the C ABI (brt_gather_rccl: ncclGather + de-interleave inside libbevyray_amd.so) -- what a
+    host without an RCCL binding of its own calls; here the communicator's unique id travels over the
+    torch.distributed group that is up anyway.  `RcclGather.create` returns None when the library's RCCL leg is not usable
+    (every rank decides the same way, so that nobody waits in ncclCommInitRank alone); gather_frame then falls back to
+    torch.distributed.gather."""
+
+    def __init__(self, plugin, comm: int, rank: int, world: int):
+        self.plugin, self.comm, self.rank, self.world = plugin, comm, rank, world
+
+    @staticmethod
+    def create(plugin, rank: int, world: int, group=None):
+        import torch
+        import torch.distributed as dist
+        ok, uid = 1, b""
+        if rank == 0:
+            try:
+                uid = plugin.rccl_unique_id()          # also proves that librccl resolves (dlopen) in this process
+            except Exception:                          # noqa: BLE001
+                ok = 0
+        if world > 1:
+            box = [uid if ok else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            if box[0] is None:
+                return None
+            uid = box[0]
+        elif not ok:
+            return None
+        try:
+            comm = plugin.rccl_comm_create(uid, rank, world)
+        except Exception:                              # noqa: BLE001  (every rank fails alike: same library, same node)
+            return None
+        return RcclGather(plugin, comm, rank, world)
+
+    def close(self):
+        if self.comm:
+            self.plugin.rccl_comm_destroy(self.comm)
+            self.comm = 0
+
+
+def gather_frame(tile, height: int, rank: int, world: int, node=None, group=None, rccl: Optional["RcclGather"] = None):
     """Gathers the per-rank tiles (torch tensors [tile_rows, W, 4] f32, same shape on every
     rank) on rank 0 and returns the de-interleaved frame [height, W, 4] there (None elsewhere).
 
     CUDA tensors: one RCCL gather, then the de-interleave HIP kernel of `node`
-    (brt_deinterleave_device).  CPU tensors (gloo, used by the world_size-2 tests): one gloo
+    (brt_deinterleave_device) -- with `rccl` (an RcclGather) both inside the library, one call (brt_gather_rccl); without it
+    the gather is torch.distributed's.  CPU tensors (gloo, used by the world_size-2 tests): one gloo
     gather, then an index copy -- the row mapping under test is the same.
 
     Stream ordering on the GPU path (everything is enqueued on torch's CURRENT stream):
@@ -50,6 +91,16 @@ def gather_frame(tile, height: int, rank: int, world: int, node=None, group=None
     import torch.distributed as dist
 
     width = tile.shape[1]
+    if rccl is not None and tile.is_cuda:
+        # ONE call: ncclGather of the tiles to rank 0 + the de-interleave kernel, both on torch's current stream
+        stream = int(torch.cuda.current_stream().cuda_stream)
+        tiles = torch.empty((world,) + tuple(tile.shape), dtype=tile.dtype, device=tile.device) if rank == 0 else None
+        frame = torch.empty((height, width, 4), dtype=torch.float32, device=tile.device) if rank == 0 else None
+        node.gather_rccl(rccl.comm, rank, world, tile.data_ptr(), tiles.data_ptr() if rank == 0 else 0, width, height,
+                         frame.data_ptr() if rank == 0 else 0, stream=stream)
+        if tiles is not None:
+            tiles.record_stream(torch.cuda.current_stream())
+        return frame
     if world == 1:
         tiles = tile.unsqueeze(0)
     else:

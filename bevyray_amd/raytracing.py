@@ -48,6 +48,7 @@ STRIP_ROWS = 8
 FLAG_COUNTERS = 1
 FLAG_KERNEL_SIMPLE = 2
 POLICY_OR_SHORT_CIRCUIT = 1   # brt_set_policy: the WGSL-spec reading of `||` in raytrace.wgsl:269 (default: both operands evaluated)
+EXTMEM_OPAQUE_FD, EXTMEM_DMABUF_FD = 1, 2   # brt_import_frame_fd handle types
 FLAG_CALLER_STREAM = 4   # device entry points: `stream` is the caller's stream even when its handle is 0
 
 SCENE_COVER, SCENE_RTIOW_FINAL, SCENE_STRESS_GRID = 0, 1, 2
@@ -347,6 +348,45 @@ class RaytracePlugin:
                                                       C.byref(ms)), self._ctx)
         return _trim(nodes, out_n.value), ms.value
 
+    # -- frame targets in another API's memory (brt_import_frame_fd) --------------------------------------------------
+    def import_frame_fd(self, fd: int, nbytes: int, handle_type: int = 2) -> int:
+        """brt_import_frame_fd: maps the memory behind a file descriptor (EXTMEM_OPAQUE_FD = 1: a Vulkan opaque-fd export;
+        EXTMEM_DMABUF_FD = 2: a dma-buf of a HIP virtual-memory allocation) and returns the device pointer."""
+        ptr = C.c_void_p()
+        _lib.check(self._lib.brt_import_frame_fd(self._ctx, int(fd), int(nbytes), int(handle_type), C.byref(ptr)), self._ctx)
+        return int(ptr.value)
+
+    def release_frame(self, d_frame: int) -> None:
+        _lib.check(self._lib.brt_release_frame(self._ctx, d_frame), self._ctx)
+
+    def debug_export_frame_fd(self, nbytes: int):
+        """(fd, device pointer) of a fresh exportable allocation on the first device (the other side of import_frame_fd in tests)."""
+        fd, ptr = C.c_int32(-1), C.c_void_p()
+        _lib.check(self._lib.brt_debug_export_frame_fd(self._ctx, int(nbytes), C.byref(fd), C.byref(ptr)), self._ctx)
+        return int(fd.value), int(ptr.value)
+
+    def debug_copy_to_host(self, d_src: int, shape, dtype=np.float32) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        _lib.check(self._lib.brt_debug_copy_to_host(self._ctx, d_src, out.ctypes.data, out.nbytes), self._ctx)
+        return out
+
+    # -- the RCCL gather behind the C ABI (one process per GPU) -----------------------------------------------------------
+    @staticmethod
+    def rccl_unique_id() -> bytes:
+        """brt_rccl_unique_id (ncclGetUniqueId): on one rank; the 128 bytes go to the other ranks by the host's own means."""
+        buf = (C.c_char * 128)()
+        _lib.check(_lib.load().brt_rccl_unique_id(buf))
+        return bytes(buf.raw)
+
+    def rccl_comm_create(self, unique_id: bytes, rank: int, world: int) -> int:
+        assert len(unique_id) == 128
+        comm = C.c_void_p()
+        _lib.check(self._lib.brt_rccl_comm_create(self._ctx, unique_id, rank, world, C.byref(comm)), self._ctx)
+        return int(comm.value)
+
+    def rccl_comm_destroy(self, comm: int) -> None:
+        _lib.check(self._lib.brt_rccl_comm_destroy(self._ctx, comm), self._ctx)
+
     def debug_profile(self) -> dict:
         """Lane-utilisation profile of the last FLAG_COUNTERS launch: section -> (executions, lanes)."""
         raw = (C.c_uint64 * 64)()
@@ -468,3 +508,11 @@ class RayTracingNode:
         p = self._p
         _lib.check(p._lib.brt_deinterleave_device(p._ctx, d_tiles, n_parts, width, height, d_frame, stream or None,
                                                   0 if stream is None else FLAG_CALLER_STREAM), p._ctx)
+
+    def gather_rccl(self, comm: int, rank: int, world: int, d_tile: int, d_tiles_on_root: int, width: int, height: int,
+                    d_frame_on_root: int = 0, stream: Optional[int] = None):
+        """brt_gather_rccl: ONE ncclGather of every rank's tile to rank 0 and, there, the de-interleave kernel behind it on the
+        same stream.  Stream rule as for render_part_device."""
+        p = self._p
+        _lib.check(p._lib.brt_gather_rccl(p._ctx, comm, rank, world, d_tile, d_tiles_on_root or None, width, height,
+                                          d_frame_on_root or None, stream or None, 0 if stream is None else FLAG_CALLER_STREAM), p._ctx)

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define BRT_ABI_VERSION 3u
+#define BRT_ABI_VERSION 4u
 
 /* Rows per strip of the interleaved row tiling. */
 #define BRT_STRIP_ROWS 8u
@@ -57,7 +57,8 @@ enum {
     BRT_ERR_EMPTY_SCENE = -6,      /* zero spheres: the reference skips the pass (pipeline.rs:141-151) */
     BRT_ERR_NO_SCENE = -7,         /* render before upload */
     BRT_ERR_UNSUPPORTED = -8,      /* e.g. orthographic projection (extract.rs:148) */
-    BRT_ERR_CAPACITY = -9          /* caller buffer too small */
+    BRT_ERR_CAPACITY = -9,         /* caller buffer too small */
+    BRT_ERR_RCCL = -10             /* librccl could not be loaded, or an RCCL call failed; text in brt_last_error */
 };
 
 /* Raytracing level, reference src/raytracing/mod.rs:94-101 (#[repr(u32)]). */
@@ -98,6 +99,10 @@ typedef struct brt_stats {
     uint32_t threads_per_workgroup;
     double   prepass_ms;       /* kernel time of the dispatch-order pre-pass that ran before this frame (first frame
                                   of a view on the synchronous paths; else 0).  Not part of kernel_ms. */
+    uint32_t kernel_variant;   /* instantiation of the trace kernel that ran: 0 general, 1 / 2 the LEAN ones (Pure level; 2: no
+                                  pixel chain can be critical), + 16: knobs live (a tuning knob off its default) */
+    uint32_t measured_tile_costs; /* 1: this frame measured the per-tile ray counts for the dispatch order of the next ones
+                                  (first frames of a view, every frame while the camera moves, after scene uploads) */
 } brt_stats;
 
 uint32_t brt_abi_version(void);
@@ -199,6 +204,42 @@ uint32_t brt_tile_rows(uint32_t height, uint32_t n_parts);
  * the copy kernel is not ordered behind the gather. */
 int32_t brt_deinterleave_device(brt_ctx* ctx, const float* d_tiles, uint32_t n_parts,
                                 uint32_t width, uint32_t height, float* d_frame, void* hip_stream, uint32_t flags);
+
+/* ---- the one collective of the path: one process per GPU, one RCCL gather per frame -----------------
+ * For a host that runs one process per GPU (instead of one N-device context, brt_render_device): every rank renders its part
+ * with brt_render_part_device, then all ranks call brt_gather_rccl -- ONE ncclGather (rccl.h:745) of the tiles to rank 0, and on
+ * rank 0 the de-interleave kernel (brt_deinterleave_device) behind it on the same stream.  librccl is resolved with dlopen at
+ * the first of these calls (a copy already in the process is used; a single-GPU host needs none); BRT_ERR_RCCL if that fails.
+ *   brt_rccl_unique_id    ncclGetUniqueId: on ONE rank; hand the 128 bytes to the others by whatever the host has (a pipe, MPI, a file)
+ *   brt_rccl_comm_create  ncclCommInitRank on the context's first device; every rank calls it (it blocks until all have)
+ *   brt_gather_rccl       d_tile: this rank's tile (brt_tile_rows(height, world) x width x 4 floats); d_tiles_on_root: `world` such
+ *                         tiles on rank 0 (NULL elsewhere); d_frame_on_root: width x height x 4 floats on rank 0, or NULL to skip
+ *                         the de-interleave.  Stream rule as for brt_render_part_device (NULL without BRT_FLAG_CALLER_STREAM = the
+ *                         context's own stream, synchronous).  The tile must not be rendered into again before the gather is done.
+ * A communicator created elsewhere (ncclComm_t of the host's own RCCL binding) may be passed as `nccl_comm` as well. */
+int32_t brt_rccl_unique_id(void* out_id128);
+int32_t brt_rccl_comm_create(brt_ctx* ctx, const void* id128, int32_t rank, int32_t world, void** out_comm);
+int32_t brt_rccl_comm_destroy(brt_ctx* ctx, void* comm);
+int32_t brt_gather_rccl(brt_ctx* ctx, void* nccl_comm, int32_t rank, int32_t world, const float* d_tile, float* d_tiles_on_root,
+                        uint32_t width, uint32_t height, float* d_frame_on_root, void* hip_stream, uint32_t flags);
+
+/* ---- a frame target in another API's memory -----------------------------------------------------------
+ * Replaces: the pass writing straight into post_process.destination (pipeline.rs:191-203).  The host exports the memory behind
+ * its colour target (or a buffer it copies from on the GPU) as a file descriptor; brt_import_frame_fd maps it on the context's
+ * first device and returns a device pointer that brt_render_device / brt_render_part_device / brt_gather_rccl accept as
+ * d_frame.  handle_type: BRT_EXTMEM_OPAQUE_FD = a Vulkan allocation exported with
+ * VK_EXTERNAL_MEMORY_HANDLE_TYPE_OPAQUE_FD_BIT (hipImportExternalMemory; the runtime owns the descriptor on success);
+ * BRT_EXTMEM_DMABUF_FD = a dma-buf of a HIP virtual-memory allocation (hipMemImportFromShareableHandle; the caller keeps and
+ * closes its descriptor).  brt_release_frame unmaps (after the context's pending work); brt_destroy releases what is left. */
+enum { BRT_EXTMEM_OPAQUE_FD = 1, BRT_EXTMEM_DMABUF_FD = 2 };
+int32_t brt_import_frame_fd(brt_ctx* ctx, int32_t fd, uint64_t bytes, uint32_t handle_type, float** out_d_frame);
+int32_t brt_release_frame(brt_ctx* ctx, float* d_frame);
+/* Diagnostic (tests): allocates `bytes` of exportable device memory on the first device (hipMemCreate), maps it and exports it
+ * as a dma-buf descriptor -- the other side of brt_import_frame_fd when no Vulkan is at hand.  Release with brt_release_frame;
+ * the caller closes the descriptor. */
+int32_t brt_debug_export_frame_fd(brt_ctx* ctx, uint64_t bytes, int32_t* out_fd, float** out_d_ptr);
+/* Diagnostic: hipMemcpy device -> host on the context's first device (for pointers that are no tensor of the caller's). */
+int32_t brt_debug_copy_to_host(brt_ctx* ctx, const void* d_src, void* h_dst, uint64_t bytes);
 
 /* Diagnostic: evaluates one device function of the ray loop on n inputs (16 floats in,
  * 8 floats out per element; op codes BRT_DBG_* below) so that tests can compare single

@@ -22,9 +22,9 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/bevyray_amd.h but not exported"
     assert declared == set(_lib.EXPORTS), "ctypes prototypes out of sync with the header"
-    assert _lib.load().brt_abi_version() == 3
+    assert _lib.load().brt_abi_version() == 4
     import ctypes
-    assert ctypes.sizeof(_lib.BrtStats) == 96          # 9 x 8 + 4 x 4 + prepass_ms (include/bevyray_amd.h, ABI 2 and later)
+    assert ctypes.sizeof(_lib.BrtStats) == 104         # 9 x 8 + 4 x 4 + prepass_ms + kernel_variant, measured_tile_costs (include/bevyray_amd.h, ABI 4)
 
 
 def test_wire_layouts_match_the_wgsl_structs():
