@@ -212,7 +212,10 @@ int32_t brt_import_frame_fd(brt_ctx* ctx, int32_t fd, uint64_t bytes, uint32_t h
         }
     } else if (handle_type == BRT_EXTMEM_DMABUF_FD) {
         // a dma-buf of a HIP virtual-memory allocation in another process or API (hipMemExportToShareableHandle)
-        HIP_TRY(ctx, hipMemImportFromShareableHandle(&f.vmm, reinterpret_cast<void*>(static_cast<uintptr_t>(fd)), hipMemHandleTypePosixFileDescriptor));
+        // (HIP reads the descriptor THROUGH the pointer -- `*(int*)osHandle` -- where CUDA's driver API takes the descriptor cast
+        //  to a pointer: passing the value itself faults inside the runtime)
+        int os_fd = fd;
+        HIP_TRY(ctx, hipMemImportFromShareableHandle(&f.vmm, &os_fd, hipMemHandleTypePosixFileDescriptor));
         const size_t g = vmm_granularity(dc.device);
         f.mapped = (f.bytes + g - 1) / g * g;
         const int32_t rc = map_vmm(ctx, dc.device, f.vmm, f.mapped, &f.ptr);

@@ -1124,7 +1124,7 @@ def test_moving_camera_measures_every_frame_in_the_lean_kernel(oracle):
             lvl, cam, win = cams[3]
             got = p.node.run(lvl, cam, win, w, h)
             assert p.node.last_stats["measured_tile_costs"] == 1 and p.node.last_stats["kernel_variant"] == 0
-            assert_frames_equal(got, oracle.render(b, lvl, cam, win, w, h)[0])
+            assert_frames_equal(got, oracle.render(brt.Buffers(moved, b.materials, b.bvh), lvl, cam, win, w, h)[0])
 
 
 def test_short_circuit_policy_switch_matches_the_oracle_under_that_policy(oracle, monkeypatch):
