@@ -41,7 +41,23 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, ch
 N_CUS, SIMDS_PER_CU, SIMD_LANES, CLOCK_HZ = 256, 4, 32, 2.4e9
 VALU_PEAK_TLANEOPS = N_CUS * SIMDS_PER_CU * SIMD_LANES * CLOCK_HZ / 1e12   # 78.6: one f32 lane-op per lane per cycle
 
+# Lane-operations one unit of work costs when every lane of a wave does useful work: the per-lane VALU instruction counts of the
+# kernel's bodies as they stood when this table was fixed (round 4; counted in the ISA).  FIXED from here on:
+# `roofline.frac_work` = sum(units x cost) / kernel time / peak prices the WORK a frame contains (counted exactly by the
+# COUNTERS instantiation, equal to the oracle's counters), so a faster kernel at equal work raises it -- unlike `frac`, which
+# prices the lane-operations the kernel happened to EXECUTE and falls when an optimisation removes instructions.
+WORK_COST = {"rays": 150.0,             # per raycast call: walk begin (1 / d, granule offsets), hit normal or sky normalize, path bookkeeping
+             "interior_visits": 54.0,   # one interior step: 24 sub / mul, 8 min / max, 2 compares, address, push / pop moves
+             "sphere_tests": 63.0,      # one leaf step: discriminant, correctly rounded sqrt and divide, accept
+             "hits": 180.0,             # material lottery, second normalize, reflect / refract / Schlick, throughput
+             "paths": 100.0,            # per sample: camera ray (two draws, normalize), gamma sqrt x 3, accumulation
+             "ball_iterations": 43.0}   # one iteration of the rejection sampler: three hash draws, |p|^2, accept
+
 WORKLOAD = dict(width=1920, height=1080, spp=64, bounces=8, scene_seed=1, random_seed=0.5)
+WORKLOAD3 = dict(width=1920, height=1080, spp=256, bounces=50, scene_seed=1, random_seed=0.5)   # BASELINE.json configs[2]
+WORKLOAD5 = dict(width=1920, height=1080, spp=64, bounces=8, scene_seed=1, random_seed=0.5)     # BASELINE.json configs[4]
+PMC_WORKLOAD3_TAG = "rtiow_1920x1080_256spp_50b"
+PMC_WORKLOAD5_TAG = "grid10k_1920x1080_64spp_8b"
 WORKLOAD4 = dict(width=3840, height=2160, spp=1024, bounces=8, scene_seed=1, random_seed=0.5)   # BASELINE.json configs[3]
 PMC_WORKLOAD_TAG = "cover_1920x1080_64spp_8b"
 PMC_WORKLOAD4_TAG = "rtiow_3840x2160_1024spp_8b"
@@ -61,7 +77,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time target of the CPU baseline sample")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc pass (N = 1 only)")
-    ap.add_argument("--no-extras", action="store_true", help="skip first-frame / reseeded / config-4 measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip first-frame / reseeded / moving-camera / config-4 measurements")
+    ap.add_argument("--no-configs", action="store_true", help="skip the config 3 / config 5 blocks (N = 1)")
     return ap.parse_args(argv)
 
 
@@ -114,7 +131,7 @@ def main():
     import torch
     import torch.distributed as dist
     import bevyray_amd as brt
-    from bevyray_amd.parallel import end_of_frame, frame_rows_of_part, gather_frame
+    from bevyray_amd.parallel import RcclGather, end_of_frame, frame_rows_of_part, gather_frame
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -142,6 +159,11 @@ def main():
 
     plugin = brt.RaytracePlugin([local_rank]) if stub is None else stub(rank, world)
     node = plugin.node
+    # the one collective of the path through the product boundary (brt_gather_rccl: ncclGather + de-interleave inside the library);
+    # BRT_BENCH_GATHER=torch keeps torch.distributed's gather (which is also the fallback when the library's RCCL leg is not usable)
+    rccl = None
+    if stub is None and world > 1 and os.environ.get("BRT_BENCH_GATHER", "abi") != "torch":
+        rccl = RcclGather.create(plugin, rank, world)
 
     def sync():
         if dev.type == "cuda":
@@ -196,7 +218,7 @@ def main():
             if timed and dev.type == "cuda":   # gather + de-interleave run on torch's current stream: time them there
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            frame = gather_frame(tile, H, rank, world, node=node)
+            frame = gather_frame(tile, H, rank, world, node=node, rccl=rccl)
             if timed and dev.type == "cuda":
                 e1.record()
                 gather_events.append((e0, e1))
@@ -204,15 +226,20 @@ def main():
             return st, frame
 
         counted, frame = step(brt.FLAG_COUNTERS) if counters else (None, None)
+        if counted is not None and stub is None:
+            # lane-level iterations of the rejection sampler = active lanes summed over the executions of its section
+            counted["ball_iterations"] = plugin.debug_profile()["ball"][1]
         for _ in range(warmup):
             step()
         barrier()
         t0 = time.perf_counter()
-        kernel_ms, rays = [], 0
+        kernel_ms, rays, variants, measuring = [], 0, [], 0
         for _ in range(steps):
             st, frame = step(timed=True)
             kernel_ms.append(st["kernel_ms"])
             rays += st["rays"]
+            variants.append(st.get("kernel_variant", 0))
+            measuring += st.get("measured_tile_costs", 0)
         barrier()
         elapsed = all_max(time.perf_counter() - t0)
         total_rays = all_sum(rays)
@@ -221,7 +248,7 @@ def main():
                "kernel_ms": float(np.mean(kernel_ms)), "kernel_ms_per_rank": all_list(float(np.mean(kernel_ms))),
                "rays_per_rank": all_list(rays / steps),
                "gather_ms": float(np.mean([a.elapsed_time(b) for a, b in gather_events])) if gather_events else 0.0,
-               "step": step, "tile": tile, "last_stats": st}
+               "step": step, "tile": tile, "last_stats": st, "variants": sorted(set(variants)), "measuring_frames": measuring}
         return res
 
     head = run_workload(WORKLOAD, brt.SCENE_COVER, args.steps, args.warmup)
@@ -268,6 +295,49 @@ def main():
         extras["animated_scene_ms"] = [round(all_max(k), 3) for k in ks[4:]]
         extras["animated_scene_upload_wall_ms"] = round(float(np.median(ups)), 3)
         node.write_buffers(head["upload"])
+        for _ in range(3):
+            step()
+        # (e) a moving camera: the reference's demo is a fly-camera app (src/main.rs:40) and re-extracts the camera every frame
+        #     (extract.rs:118-157).  The cover camera orbits the origin 0.5 degrees per frame for 24 frames, a new seed each; every
+        #     such frame measures its tile costs (in the LEAN instantiation) and runs in the order measured one frame earlier
+        lvl0 = head["lvl"]
+        ks, kinds = [], {"prepass": 0, "general": 0, "lean": 0, "measuring": 0}
+        for i in range(1, 25):
+            a = np.deg2rad(0.5 * i)
+            pos = (13.0 * np.cos(a) - 3.0 * np.sin(a), 2.0, 13.0 * np.sin(a) + 3.0 * np.cos(a))
+            cam_i = brt.CameraExtract.extract_component(brt.RaytracedCamera(level=brt.Raytracing.Pure, sample_count=spp, bounces=WORKLOAD["bounces"]),
+                                                        brt.Transform(tuple(float(x) for x in pos), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)),
+                                                        brt.PerspectiveProjection(fov=0.4, aspect_ratio=W / H, near=0.1, far=1000.0))[1]
+            st = node.render_part_device(lvl0, cam_i, brt.WindowExtract.extract_component(H, 0.03 + 0.04 * i), W, H, rank, world, head["tile"].data_ptr())
+            ks.append(st["kernel_ms"] + st.get("prepass_ms", 0.0))
+            kinds["prepass"] += int(st.get("prepass_ms", 0.0) > 0)
+            kinds["lean" if st.get("kernel_variant", 0) in (1, 2) else "general"] += 1
+            kinds["measuring"] += st.get("measured_tile_costs", 0)
+        extras["moving_camera_ms"] = [round(all_max(k), 3) for k in ks]
+        extras["moving_camera_median_ms"] = round(float(np.median([all_max(k) for k in ks])), 3)
+        extras["moving_camera_frames"] = kinds
+        for _ in range(3):
+            step()
+        # (f) the same re-upload-every-frame loop on the 10 004-sphere scene (config 5's): the callee builds the SAH tree ON THE GPU
+        #     (brt_sah.hip) inside brt_upload_scene; round 3 built it on one host core (8-9 ms per upload)
+        if world == 1:
+            g = brt.generate_scene(brt.SCENE_STRESS_GRID, 1)
+            gm = g.models.copy()
+            node.write_buffers(brt.Buffers(gm, g.materials, None))
+            lvl5, cam5, win5 = brt.cover_camera(W, H, spp, WORKLOAD["bounces"], brt.Raytracing.Pure, WORKLOAD["random_seed"])
+            ks, ups = [], []
+            for i in range(10):
+                gm["position"][7, 0] += np.float32(0.002)
+                t0 = time.perf_counter()
+                node.write_buffers(brt.Buffers(gm, g.materials, None))
+                ups.append((time.perf_counter() - t0) * 1e3)
+                ks.append(node.render_part_device(lvl5, cam5, win5, W, H, rank, world, head["tile"].data_ptr())["kernel_ms"])
+            extras["animated_scene_10k_ms"] = [round(k, 3) for k in ks[4:]]
+            extras["animated_scene_10k_upload_wall_ms"] = round(float(np.median(ups[2:])), 3)
+            extras["animated_scene_10k_gpu_bvh_build_ms"] = round(min(plugin.build_bvh_sah(gm)[1] for _ in range(3)), 3)
+            node.write_buffers(head["upload"])
+            for _ in range(3):
+                step()
     cfg4 = None
     if not args.no_extras and world > 1:
         # config 2's longest pixel chains take ~5 ms whatever N is; BASELINE.json's own
@@ -277,12 +347,24 @@ def main():
                 "value": r4["total_rays"] / r4["elapsed"] / 1e6, "unit": "Mrays/s", "ms_per_step": r4["elapsed"] / r4["steps"] * 1e3,
                 "steps": r4["steps"], "warmup": 1, "kernel_ms_per_rank": r4["kernel_ms_per_rank"], "gather_ms": r4["gather_ms"]}
 
+    cfg_blocks = {}
+    if world == 1 and stub is None and not args.no_configs:
+        # BASELINE.json's other one-GPU configs under the driver's own run: a few frames each, kernel time from HIP events, own
+        # counter pass for the roofline, sampled rows against the oracle (the -m gpu suite checks the WHOLE frames)
+        for key, wl, kind, tag, name in (("config3", WORKLOAD3, brt.SCENE_RTIOW_FINAL, PMC_WORKLOAD3_TAG,
+                                          "RTIOW final scene 1920x1080, 256 spp, 50 bounces (BASELINE.json configs[2])"),
+                                         ("config5", WORKLOAD5, brt.SCENE_STRESS_GRID, PMC_WORKLOAD5_TAG,
+                                          "10 004-sphere grid 1920x1080, 64 spp, 8 bounces (BASELINE.json configs[4])")):
+            r = run_workload(wl, kind, 3, 2)
+            cfg_blocks[key] = (name, tag, r)
+        node.write_buffers(head["upload"])
+
     if rank == 0:
         counted = head["counted"]
         my_rows = int((frame_rows_of_part(H, 0, world) >= 0).sum())
         alg = bytes_alg(counted, W, my_rows)
         kernel_ms = max(head["kernel_ms_per_rank"])          # the slowest rank's kernel bounds the frame
-        roof = roofline_block(args, world, stub is not None, kernel_ms, alg, PMC_WORKLOAD_TAG)
+        roof = roofline_block(args, world, stub is not None, kernel_ms, alg, PMC_WORKLOAD_TAG, counted=counted, paths=W * H * spp)
         out = {
             "metric": "Mrays/s at 1920x1080, 64 spp, 8 bounces", "value": head["total_rays"] / head["elapsed"] / 1e6,
             "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -299,6 +381,13 @@ def main():
             "mpaths_per_s": W * H * spp * args.steps / head["elapsed"] / 1e6,
             "kernel_ms_per_rank": head["kernel_ms_per_rank"], "rays_per_frame_per_rank": head["rays_per_rank"],
             "gather_ms": head["gather_ms"],   # rank 0: RCCL gather (N > 1) + de-interleave copy kernel, per frame
+            "gather_via": ("brt_gather_rccl (ncclGather + de-interleave inside libbevyray_amd.so)" if rccl is not None else
+                           ("torch.distributed.gather + brt_deinterleave_device" if world > 1 else "brt_deinterleave_device (one rank)")),
+            # the timed frames: which instantiation(s) of the trace kernel ran and how many of them measured tile costs.  A view whose
+            # camera and scene stand still never measures again (round 4), so the timed window IS the amortised steady state; a moving
+            # camera measures every frame: `moving_camera_ms`
+            "steady_state": {"kernel_variants_timed": head["variants"], "measuring_frames_timed": head["measuring_frames"],
+                             "amortised_ms_per_frame": head["elapsed"] / args.steps * 1e3},
             "roofline": roof,
             "kernel": {"lds_bytes": counted["lds_bytes"], "scene_in_lds": counted["scene_in_lds"],
                        "workgroups": counted["n_workgroups"], "threads": counted["threads_per_workgroup"]},
@@ -307,6 +396,15 @@ def main():
         if cfg4 is not None:
             cfg4["roofline"] = roofline_block(args, world, stub is not None, max(cfg4["kernel_ms_per_rank"]), None, PMC_WORKLOAD4_TAG)
             out["config4"] = cfg4
+        for key, (name, tag, r) in cfg_blocks.items():
+            c = r["counted"]
+            alg_c = bytes_alg(c, r["W"], r["H"])
+            blk = {"workload": name, "spheres": int(len(r["buffers"].models)), "steps": r["steps"], "warmup": 2,
+                   "value": r["total_rays"] / r["elapsed"] / 1e6, "unit": "Mrays/s", "ms_per_step": r["elapsed"] / r["steps"] * 1e3,
+                   "kernel_ms": r["kernel_ms"], "rays_per_frame": r["total_rays"] / r["steps"], "scene_in_lds": c["scene_in_lds"],
+                   "roofline": roofline_block(args, 1, False, r["kernel_ms"], alg_c, tag, counted=c, paths=r["W"] * r["H"] * r["spp"]),
+                   "sampled_rows_bit_exact": sampled_rows_exact(r)}
+            out[key] = blk
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(head["buffers"], head["lvl"], head["cam"], head["win"], W, H, head["frame"],
                                                args.cpu_seconds, is_stub=stub is not None)
@@ -387,7 +485,22 @@ def live_pmc(timeout_s=90.0, workload=PMC_WORKLOAD_TAG, passes=None):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def roofline_block(args, world, is_stub, kernel_ms, alg, workload):
+def sampled_rows_exact(r, n_rows=4):
+    """A few rows of the last timed frame of a config block against the oracle, bit for bit (the oracle as checker)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_loader
+    oracle = oracle_loader.load()
+    H = r["H"]
+    g = r["frame"].cpu().numpy()
+    ok = True
+    for y in [int(x) for x in np.linspace(H // 3, H - 5, n_rows)]:
+        want, _ = oracle.render(r["buffers"], r["lvl"], r["cam"], r["win"], r["W"], H, rows=(y, y + 1), threads=oracle_loader.usable_cores())
+        ok = ok and bool(np.array_equal(g[y].view(np.uint32), want[y].view(np.uint32)))
+    return ok
+
+
+def roofline_block(args, world, is_stub, kernel_ms, alg, workload, counted=None, paths=None):
     """The roofline object of one workload.  kernel_ms: the slowest rank's mean kernel time.  Counters: of the WHOLE frame
     on ONE GPU (a live rocprofv3 --pmc pass made now by rank 0 in a one-GPU child process, or the committed summary taken on
     the same device code); for N > 1 the frame's lane-operations are set against N GPUs' peak."""
@@ -395,15 +508,18 @@ def roofline_block(args, world, is_stub, kernel_ms, alg, workload):
     code_hash = None if is_stub else _lib.kernel_code_hash()
     pmc, source, why = None, None, None
     head = workload == PMC_WORKLOAD_TAG
-    if not is_stub and not args.no_pmc:
-        # (config 4 renders for seconds per pass: its SQ set only)
+    if not is_stub and not args.no_pmc and workload != PMC_WORKLOAD4_TAG:
+        # (config 4 renders for seconds per frame and minutes per counter pass: its block takes the committed, hash-checked summary
+        #  directly instead of a live pass that would hit its time budget; the config 3 / 5 blocks are secondary: their SQ set only)
         pmc, why = live_pmc(workload=workload, passes=None if head else PMC_PASSES[:1], timeout_s=90.0 if head else 60.0)
         if pmc and "SQ_INSTS_VALU" in pmc:
             source = "live: rocprofv3 --pmc passes made by this run after the timed region (scripts/pmc_frame.py, one GPU, last dispatch)"
         else:
             pmc = None
     if pmc is None and not is_stub:
-        path = os.path.join(ROOT, "profiles", "pmc_summary.json" if head else "pmc_summary_config4.json")
+        path = os.path.join(ROOT, "profiles", {PMC_WORKLOAD_TAG: "pmc_summary.json", PMC_WORKLOAD4_TAG: "pmc_summary_config4.json",
+                                               PMC_WORKLOAD3_TAG: "pmc_summary_config3.json",
+                                               PMC_WORKLOAD5_TAG: "pmc_summary_config5.json"}[workload])
         try:
             rec = json.load(open(path))
             if rec.get("workload") == workload and rec.get("kernel_code_hash") == code_hash:
@@ -415,7 +531,7 @@ def roofline_block(args, world, is_stub, kernel_ms, alg, workload):
             why = (why + "; " if why else "") + f"{os.path.relpath(path, ROOT)}: {e}"
     secs = kernel_ms * 1e-3
     peak = VALU_PEAK_TLANEOPS * world
-    roof = {"bound": "valu", "achieved": None, "peak": peak, "unit": "Tlane-op/s", "frac": None, "traffic": None,
+    roof = {"bound": "valu", "achieved": None, "peak": peak, "unit": "Tlane-op/s", "frac": None, "frac_work": None, "traffic": None,
             "kernel": "k_trace_persistent", "kernel_ms": kernel_ms, "kernel_code_hash": code_hash, "n_gpus": world,
             "algorithmic_bytes_per_launch": alg, "algorithmic_GBs": alg / secs / 1e9 if (alg and secs > 0) else None,
             "hbm_peak_GBs": HBM_PEAK_GBS * world, "hbm_frac_measured": None,
@@ -427,6 +543,20 @@ def roofline_block(args, world, is_stub, kernel_ms, alg, workload):
                     "`traffic` (measured HBM bytes of the frame) / kernel time is `hbm_frac_measured` of the HBM peak; the SURVEY 8(d) "
                     "algorithmic bytes are informational (they are served from LDS/registers)",
             "counter_source": source, "counter_note": why}
+    if world > 1:
+        roof["estimate"] = ("N > 1: `achieved` is an ESTIMATE -- the counters are those of the WHOLE frame on one GPU (its useful lane-operations do "
+                            "not depend on how the rows are dealt out) set against the slowest rank's kernel time and N GPUs' peak; per-rank "
+                            "counters are not collected")
+    if counted is not None and secs > 0 and "ball_iterations" in counted:
+        units = {k: float(counted[k]) for k in ("rays", "interior_visits", "sphere_tests", "hits", "ball_iterations")}
+        units["paths"] = float(paths)
+        work = sum(units[k] * WORK_COST[k] for k in WORK_COST)
+        roof["work"] = {"units_per_launch": units, "lane_ops_per_unit": WORK_COST, "lane_ops_per_launch": work,
+                        "note": "frac_work = (exactly counted work x a FIXED lane-op cost per unit) / kernel time / peak: rises when the kernel "
+                                "gets faster at equal work; `frac` prices the lane-operations actually executed (counters) and falls when "
+                                "an optimisation removes instructions"}
+        roof["achieved_work"] = work / secs / 1e12
+        roof["frac_work"] = roof["achieved_work"] / peak
     if pmc:
         valu, act, thr = pmc.get("SQ_INSTS_VALU"), pmc.get("SQ_ACTIVE_INST_VALU"), pmc.get("SQ_THREAD_CYCLES_VALU")
         lanes = thr / act if act else None

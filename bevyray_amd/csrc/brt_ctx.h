@@ -59,6 +59,11 @@ struct DeviceCtx {
     bool order_valid = false;
     uint32_t remeasure_in = 0;                    // frames until the costs are measured again (0: nothing pending); set by scene uploads
     uint64_t order_cam = 0;                       // hash of the camera the costs were last measured with
+    // the last measurement itself stays in d_tile_cost until the next one: a frame whose camera has moved since re-ranks the
+    // tiles from it with a neighbourhood radius that covers the motion (attach_tile_order, brt_order.hip)
+    bool costs_valid = false;
+    float cost_cam_pos[3] = {0, 0, 0}, cost_cam_dir[3] = {0, 0, 0};
+    uint32_t cost_spp = 0;
     uint32_t order_key[6] = {0, 0, 0, 0, 0, 0};   // width, height, part, n_parts, scene epoch, n_tiles
     std::vector<uint32_t> h_cost;
     std::vector<uint32_t> h_order;
@@ -78,7 +83,7 @@ struct DeviceCtx {
 enum Knob : int {
     K_BOTTOM_UP, K_REFILL_MIN, K_WALK_EXIT, K_LEAF_VOTE, K_DRAIN_DONATE, K_POOL_ADOPT, K_WGQ_BATCH, K_LPT_LANE_PERMILLE, K_TUNABLE,
     K_FORCE_GLOBAL_SCENE, K_FORCE_LDS_TOP, K_BLOCK_THREADS, K_WG_PER_CU, K_POOL_CAP, K_LPT, K_LPT_SORT, K_LPT_SKY_SLACK, K_CRIT,
-    K_ORDER_ON_HOST, K_NO_LEAN, K_PREPASS_SPP, K_NO_DIRTY_TRACKING, K_CPU_BVH, K_PLOC_ONE_BLOCK_MAX, K_BVH_QUALITY, K_POOL_FORCE, K_LPT_REFRESH_EVERY, K_LEAN_MEASURE, K_COUNT
+    K_ORDER_ON_HOST, K_NO_LEAN, K_PREPASS_SPP, K_NO_DIRTY_TRACKING, K_CPU_BVH, K_PLOC_ONE_BLOCK_MAX, K_BVH_QUALITY, K_POOL_FORCE, K_LPT_REFRESH_EVERY, K_LEAN_MEASURE, K_LPT_DILATE, K_COUNT
 };
 struct KnobDef { const char* name; uint32_t dflt; };
 constexpr KnobDef kKnobs[K_COUNT] = {
@@ -87,7 +92,7 @@ constexpr KnobDef kKnobs[K_COUNT] = {
     {"BRT_TUNABLE", 0}, {"BRT_FORCE_GLOBAL_SCENE", 0}, {"BRT_FORCE_LDS_TOP", 0}, {"BRT_BLOCK_THREADS", 0}, {"BRT_WG_PER_CU", 0},
     {"BRT_POOL_CAP", 384}, {"BRT_LPT", 1}, {"BRT_LPT_SORT", 1}, {"BRT_LPT_SKY_SLACK", 20}, {"BRT_CRIT", 1}, {"BRT_ORDER_ON_HOST", 0},
     {"BRT_NO_LEAN", 0}, {"BRT_PREPASS_SPP", 2}, {"BRT_NO_DIRTY_TRACKING", 0}, {"BRT_CPU_BVH", 0},
-    {"BRT_PLOC_ONE_BLOCK_MAX", kPlocOneBlockMax}, {"BRT_BVH_QUALITY", 1}, {"BRT_POOL_FORCE", 0}, {"BRT_LPT_REFRESH_EVERY", 0}, {"BRT_LEAN_MEASURE", 1}};
+    {"BRT_PLOC_ONE_BLOCK_MAX", kPlocOneBlockMax}, {"BRT_BVH_QUALITY", 1}, {"BRT_POOL_FORCE", 0}, {"BRT_LPT_REFRESH_EVERY", 0}, {"BRT_LEAN_MEASURE", 1}, {"BRT_LPT_DILATE", 3}};
 struct Knobs {
     uint32_t v[K_COUNT];
     Knobs() { for (int i = 0; i < K_COUNT; i++) v[i] = kKnobs[i].dflt; }
@@ -117,6 +122,7 @@ struct brt_ctx {
     std::vector<std::pair<char*, size_t>> pinned;   // brt_host_alloc blocks
     // bytes of the last successful upload (dirty tracking: an unchanged scene is not re-sent)
     std::vector<char> last_models, last_materials, last_bvh;
+    float scene_centre[3] = {0, 0, 0};   // mean centre of the scene's ordinary spheres (radius <= 100): what a camera translation is judged against
     brt::Knobs knobs;           // tuning knobs (brt_set_tuning; environment once at brt_create under BRT_ENABLE_TUNING=1)
     uint32_t policy_flags = 0;  // brt_set_policy
     std::string last_error;

@@ -15,6 +15,10 @@ def main():
     workload = os.environ.get("BRT_PMC_WORKLOAD", "cover_1920x1080_64spp_8b")
     if workload == "rtiow_3840x2160_1024spp_8b":      # BASELINE.json configs[3], the whole frame on one GPU
         scene, (w, h, spp, bounces), cam_fn, dflt_frames = brt.SCENE_RTIOW_FINAL, (3840, 2160, 1024, 8), brt.rtiow_camera, 2
+    elif workload == "rtiow_1920x1080_256spp_50b":    # BASELINE.json configs[2]
+        scene, (w, h, spp, bounces), cam_fn, dflt_frames = brt.SCENE_RTIOW_FINAL, (1920, 1080, 256, 50), brt.rtiow_camera, 3
+    elif workload == "grid10k_1920x1080_64spp_8b":    # BASELINE.json configs[4]
+        scene, (w, h, spp, bounces), cam_fn, dflt_frames = brt.SCENE_STRESS_GRID, (1920, 1080, 64, 8), brt.cover_camera, 3
     else:
         scene = int(os.environ.get("BRT_PMC_SCENE", str(brt.SCENE_COVER)))
         (w, h, spp, bounces), cam_fn, dflt_frames = (1920, 1080, 64, 8), brt.cover_camera, 3
