@@ -301,7 +301,9 @@ int32_t attach_tile_order(brt_ctx* ctx, DeviceCtx& dc, FrameParams& fp, hipStrea
         // the camera has moved since the costs were measured (one frame ago, while it keeps moving): rank every tile by its
         // neighbourhood of the radius the motion covers.  Behind the previous frame's work, ahead of this frame's launch.
         uint32_t r = dilation_tiles(ctx, dc, fp);
-        if (r <= kMaxDilate && ctx->knobs[K_LPT_DILATE] >= 2u && r < ctx->knobs[K_LPT_DILATE] - 1u) r = ctx->knobs[K_LPT_DILATE] - 1u;
+        if (r <= kMaxDilate && ctx->knobs[K_LPT_DILATE] >= 2u && r < ctx->knobs[K_LPT_DILATE] - 1u &&
+            (uint64_t)n_tiles >= 6u * (uint64_t)dc.num_cus * (BRT_BLOCK / 64u))
+            r = ctx->knobs[K_LPT_DILATE] - 1u;
         if (r <= kMaxDilate) {
             HIP_TRY(ctx, hipStreamWaitEvent(stream, dc.ev_last, 0));
             const int32_t rc = build_order_on_device(ctx, dc, n_tiles, fp.tiles_x, dc.cost_spp, r, (r + fp.n_parts - 1u) / fp.n_parts, stream);
@@ -349,7 +351,11 @@ int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hi
         // the view the costs were measured in: same box A/B, config 2 10.88 -> 10.64 ms, config 3 68.4 -> 66.7, config 5 25.4 -> 24.3
         // (profiles/r04/static_dilate_configs.txt) -- expensive pixels come in clusters (glass and metal silhouettes), and handing out
         // a cluster's tiles together starts all of its long chains early instead of ranking each tile on one noisy maximum.
-        const uint32_t r0 = ctx->knobs[K_LPT_DILATE] >= 2u ? ctx->knobs[K_LPT_DILATE] - 1u : 0u;
+        // Only for launches of at least 6 tiles per wave slot: a rank's share of a frame split 2 or 4 ways hands every wave 2-4 tiles, there
+        // the truly longest tiles must be in the first hand-out and neighbours ranked up beside them push some of them into the second
+        // (slowest share of config 2 in 2 / 4 parts 6.24 / 5.13 ms without, 6.60 / 5.31 with; profiles/r04/parts_dilate.txt).
+        const uint64_t wave_slots = (uint64_t)dc.num_cus * (BRT_BLOCK / 64u);
+        const uint32_t r0 = (ctx->knobs[K_LPT_DILATE] >= 2u && (uint64_t)n_tiles >= 6u * wave_slots) ? ctx->knobs[K_LPT_DILATE] - 1u : 0u;
         rc = build_order_on_device(ctx, dc, n_tiles, fp.tiles_x, tp.sample_count, r0, r0 ? (r0 + fp.n_parts - 1u) / fp.n_parts : 0u, stream);
         if (rc != BRT_OK) return rc;
         dc.order_lane = 0;

@@ -22,7 +22,8 @@ SETS = [
   "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM",
   "FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE GRBM_COUNT",
   "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC SQ_WAVES SQ_IFETCH"]
-for tag, name, sets, budget in ((bench.PMC_WORKLOAD_TAG, "pmc_summary.json", SETS, 600.0), (bench.PMC_WORKLOAD4_TAG, "pmc_summary_config4.json", SETS[:2], 400.0)):
+for tag, name, sets, budget in ((bench.PMC_WORKLOAD_TAG, "pmc_summary.json", SETS, 600.0), (bench.PMC_WORKLOAD4_TAG, "pmc_summary_config4.json", SETS[:2], 400.0),
+                               (bench.PMC_WORKLOAD3_TAG, "pmc_summary_config3.json", SETS[:2], 200.0), (bench.PMC_WORKLOAD5_TAG, "pmc_summary_config5.json", SETS[:2], 200.0)):
     got, why = bench.live_pmc(timeout_s=budget, workload=tag, passes=sets)
     rec = {"workload": tag, "n_gpus": 1, "kernel_code_hash": _lib.kernel_code_hash(), "counters": got, "note": why,
            "method": "rocprofv3 --pmc, one pass per counter set over scripts/pmc_frame.py, values of the LAST k_trace_persistent "

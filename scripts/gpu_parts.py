@@ -26,8 +26,12 @@ def main():
     ap.add_argument("--configs", type=int, nargs="*", default=[2, 4])
     ap.add_argument("--parts", type=int, nargs="*", default=[1, 2, 4, 8, 16])
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--knob", nargs="*", default=[], help="tuning knobs NAME=VALUE")
     a = ap.parse_args()
     with brt.RaytracePlugin([0]) as p:
+        for kv in a.knob:
+            k, v = kv.split("=", 1)
+            p.set_tuning(k, int(v))
         for c in a.configs:
             name, kind, W, H, spp, bounces, camera = CONFIGS[c]
             b = brt.generate_scene(kind, 1)
