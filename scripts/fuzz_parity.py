@@ -9,7 +9,7 @@ infinite radii and positions, coincident spheres (exact ties, raytrace.wgsl:353 
 materials outside [0,1], ior 0 and inf, cameras inside spheres, degenerate up vectors, window
 height 0 (infinite jitter), NaN / huge / negative random_seed, sample_count 0, bounce counts past the
 stack size, hand-made trees deeper than the 32-entry stack, multi-sphere leaves, and callee-built
-trees (GPU PLOC, checked byte for byte against the CPU builder).  A failing case is dumped to
+trees (GPU SAH and GPU PLOC, each checked byte for byte against its CPU builder).  A failing case is dumped to
 gpurun_out/fuzz_fail_<n>.npz.  Needs an MI355X; the oracle is the checker (test infrastructure).
 """
 import argparse
@@ -206,8 +206,13 @@ def main():
                 quality = int(rng.integers(0, 2))
                 for pl in (plugin, multi):
                     pl.set_tuning("BRT_BVH_QUALITY", quality)
-                if quality:
-                    ob = brt.Buffers(b.models, b.materials, brt.build_bvh_sah(b.models))
+                if quality:     # the tree brt_upload_scene builds on the GPU (brt_sah.hip) must be the CPU statement of the rule, byte for byte
+                    cpu_nodes = brt.build_bvh_sah(b.models)
+                    gpu_nodes, _ = plugin.build_bvh_sah(b.models)
+                    ploc_checked += 1
+                    ob = brt.Buffers(b.models, b.materials, cpu_nodes)
+                    if cpu_nodes.tobytes() != gpu_nodes.tobytes():
+                        raise AssertionError("GPU SAH tree differs from the CPU builder's")
                 else:
                     cpu_nodes = brt.build_bvh(b.models)
                     gpu_nodes, _ = plugin.build_bvh(b.models)
