@@ -245,8 +245,14 @@ int32_t build_bvh_sah(const Model* models, uint32_t n_models, std::vector<BVHNod
     const uint32_t n = n_models;
     std::vector<SahKeyBox> box(n);
     std::vector<double> cen(3 * (size_t)n);
+    uint32_t scale_key = kSahKeyMaxIdentity;      // the scene's scale: max over its ordinary spheres (an order-independent integer max)
     for (uint32_t i = 0; i < n; i++) {
-        const PlocBox b = ploc_model_box(models[i].position, models[i].radius);
+        const uint32_t k = sah_key_max(sah_scale_term(models[i].position, models[i].radius));
+        scale_key = k > scale_key ? k : scale_key;
+    }
+    const float scale = sah_unkey_max(scale_key);
+    for (uint32_t i = 0; i < n; i++) {
+        const PlocBox b = sah_model_box(models[i].position, models[i].radius, scale);
         box[i] = sah_keybox(b);
         for (int k = 0; k < 3; k++) cen[3 * (size_t)i + k] = sah_centroid(b, k);
     }

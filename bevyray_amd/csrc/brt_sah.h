@@ -8,7 +8,8 @@
 // root, an interior node's children are `index`, `index + 1`, a leaf has model_count 1 and `index` = model id.
 //
 // The rule (top down, one node = one range [begin, end) of the index list, depth d, preorder rank r among interior nodes):
-//   * node box = union of the padded sphere boxes (Model::aabb, extract.rs:220-227) of the range;
+//   * node box = union of the sphere boxes of the range; a sphere's box is its bounds padded by sah_model_pad (below; the
+//     reference's Model::aabb, extract.rs:220-227, pads by a flat 0.1);
 //   * count == 1: leaf.  Else the children live in slots 1 + 2r and 2 + 2r (what a depth-first builder that allocates two
 //     slots per interior node in preorder hands out); left child: rank r + 1, right child: rank r + (left count);
 //   * split position `mid`: halves of the current order, unless a binned-SAH split applies: count > 2, the depth budget is
@@ -75,6 +76,43 @@ BRT_HD PlocBox sah_unkeybox(const SahKeyBox& b) {
 }
 
 BRT_HD bool sah_finite(double x) { return x - x == 0.0; }   // false for +-inf and NaN
+
+// ---- leaf boxes of the tree the CALLEE builds -----------------------------------------------------------------------------
+// The reference pads a sphere's box by a flat 0.1 (Model::aabb, extract.rs:220-227) before it hands the boxes to obvhs.  Boxes only
+// cull: a pixel is the closest accepted sphere test among the leaves the walk reaches, and it reaches every sphere a ray can be
+// accepted by as long as the box is CONSERVATIVE for the float arithmetic of the two tests -- a ray that the f32 sphere test accepts
+// must pass the f32 slab test of the sphere's box.  A caller's tree is honoured as it comes; the tree this library builds itself pads
+// by what that needs instead of by 0.1, because the pad is most of a small sphere's box (r = 0.2: half-width 0.3 -> 0.21, half the
+// surface) and the walk pays for it: interior visits per ray 12.7 -> 11.2 (cover), 19.5 -> 17.1 (10 k grid), sphere tests 2.3 -> 1.8.
+// What it needs: the sphere test's discriminant h*h - a*c carries a rounding error of ~2^-24 of its terms, dist^2 * a, i.e. it can
+// accept a ray whose true distance from the centre exceeds r by up to ~2^-24 * dist^2 / (2 r), dist = the distance the ray has
+// travelled to the sphere; the slab arithmetic's own error, ~2^-22 * dist, is small beside it.  With dist bounded by twice the
+// scene's scale S (the largest |c|_1 + r over its ordinary spheres, r <= 100: a ground sphere of radius 1000 is not a distance rays
+// travel): pad = clamp(2^-24 * (2 S)^2 / r, 0.01, 0.1) -- the reference's own 0.1 where the model asks for more (there the
+// reference's culling is as marginal as any), never less than 0.01.  Measured: on the 10 k grid (S = 100, pad 0.012) the first pixel
+// of a 640 x 360 x 16 spp frame differs from the brute-force frame at a pad of 1e-4, none at 1e-3 (docs/experiments.md); the -m gpu
+// suite compares the frames of configs 2 and 5 in this tree with the oracle's frames in the caller's 0.1-padded PLOC tree at full size.
+BRT_HD float sah_scale_term(const float* position, float radius) {      // |c|_1 + r of an ordinary sphere, else NaN (ignored by the max)
+    const float s = ((__builtin_fabsf(position[0]) + __builtin_fabsf(position[1])) + __builtin_fabsf(position[2])) + radius;
+    return (radius > 0.0f && radius <= 100.0f && s - s == 0.0f) ? s : __builtin_nanf("");
+}
+BRT_HD float sah_model_pad(float radius, float scale) {
+    if (!(radius > 0.0f) || !(radius <= 100.0f) || !(scale - scale == 0.0f)) return 0.1f;
+    const float d = 2.0f * scale;
+    float p = (5.9604645e-8f * (d * d)) / radius;      // 2^-24
+    p = p > 0.01f ? p : 0.01f;
+    return p < 0.1f ? p : 0.1f;                         // (a NaN stays out by the tests above)
+}
+BRT_HD PlocBox sah_model_box(const float* position, float radius, float scale) {
+    const float pad = radius + sah_model_pad(radius, scale);
+    PlocBox b;
+    for (int k = 0; k < 3; k++) {
+        const float lo = position[k] - pad, hi = position[k] + pad;
+        b.mn[k] = (lo == lo) ? lo : __builtin_nanf("");
+        b.mx[k] = (hi == hi) ? hi : __builtin_nanf("");
+    }
+    return b;
+}
 
 // half the surface area in f64; a box that is not finite costs "everything" (never chosen: the winner must be < DBL_MAX)
 BRT_HD double sah_half_area(const SahKeyBox& kb) {

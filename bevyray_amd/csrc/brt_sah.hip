@@ -435,7 +435,18 @@ __device__ void sah_coop_phase(const Store& st, BVHNode* out, const SahTask& roo
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void k_sah_prep(const Model* __restrict__ models, uint32_t n, SahKeyBox* kbox, double* cen,
+// the scene's scale (brt_sah.h sah_scale_term): an integer max over keys, the same bits in whatever order the atomics land
+__global__ __launch_bounds__(256) void k_sah_scale(const Model* __restrict__ models, uint32_t n, uint32_t* scale_key) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t k = i < n ? sah_key_max(sah_scale_term(models[i].position, models[i].radius)) : kSahKeyMaxIdentity;
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_xor(k, off, 64);
+        k = o > k ? o : k;
+    }
+    if ((threadIdx.x & 63u) == 0u && k != kSahKeyMaxIdentity) atomicMax(scale_key, k);
+}
+
+__global__ __launch_bounds__(256) void k_sah_prep(const Model* __restrict__ models, uint32_t n, const uint32_t* scale_key, SahKeyBox* kbox, double* cen,
                                                   uint32_t* idx0, SahTask* tasks, uint32_t* n_tasks, SahTask* top_list, uint32_t* top_n,
                                                   uint32_t* info) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -450,7 +461,7 @@ __global__ __launch_bounds__(256) void k_sah_prep(const Model* __restrict__ mode
         info[1] = 0u;
     }
     if (i >= n) return;
-    const PlocBox b = ploc_model_box(models[i].position, models[i].radius);
+    const PlocBox b = sah_model_box(models[i].position, models[i].radius, sah_unkey_max(*scale_key));
     kbox[i] = sah_keybox(b);
     for (int k = 0; k < 3; k++) cen[3 * (size_t)i + k] = sah_centroid(b, k);
     idx0[i] = i;
@@ -581,8 +592,12 @@ hipError_t launch_build_sah(const Model* d_models, uint32_t n, char* d_scratch, 
     // (a node the build failed to write would be a leaf of 2^32 - 1 spheres at sphere 2^32 - 1: brt_upload_scene's validation refuses it)
     hipError_t e = hipMemsetAsync(g.out, 0xff, (2 * (size_t)n - 1) * sizeof(BVHNode), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_sah_prep, dim3((n + 255u) / 256u), dim3(256), 0, stream, d_models, n, kbox, cen, g.st.idx[0], g.tasks, g.n_tasks,
-                       top_list[0], top_n, info);
+    uint32_t* scale_key = top_n + kTopCounters;                      // behind the level counters (zero = the max's identity)
+    e = hipMemsetAsync(scale_key, 0, 4, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_sah_scale, dim3((n + 255u) / 256u), dim3(256), 0, stream, d_models, n, scale_key);
+    hipLaunchKernelGGL(k_sah_prep, dim3((n + 255u) / 256u), dim3(256), 0, stream, d_models, n, scale_key, kbox, cen, g.st.idx[0], g.tasks,
+                       g.n_tasks, top_list[0], top_n, info);
     if (n > kSubMax) {
         // the top of the tree level by level, the nodes of a level side by side (a block each); then one block for the rest
         const uint32_t levels = sah_top_levels(n);

@@ -184,7 +184,7 @@ def main():
         return got, node.last_stats
     rng = np.random.default_rng(args.seed)
     t_start = time.time()
-    fails, done, pixels, rays, ploc_checked, rejected = 0, 0, 0, 0, 0, 0
+    fails, done, pixels, rays, ploc_checked, rejected, tight_checked = 0, 0, 0, 0, 0, 0, 0
     lines = []
     t_progress = time.time()
     for case in range(args.cases):
@@ -233,6 +233,16 @@ def main():
             bad = frames_differ(got, want)
             if bad:
                 raise AssertionError(f"{bad} of {got.size} frame values differ")
+            # the callee's SAH tree pads its leaf boxes by less than the reference's 0.1 (brt_sah.h sah_model_pad): on tame scenes without
+            # coincident spheres (exact ties are decided by the visiting order) the frame must also be the one of the caller's
+            # 0.1-padded PLOC tree -- i.e. the tighter boxes culled nothing a ray is accepted by
+            if b.bvh is None and quality and not c["wild"] and len(b.models) <= 3000 and \
+                    len(np.unique(b.models.view(np.uint8).reshape(len(b.models), -1)[:, :16], axis=0)) == len(b.models):
+                want_ref, _ = oracle.render(brt.Buffers(b.models, b.materials, brt.build_bvh(b.models)), c["level"], c["camera"], c["window"],
+                                            c["w"], c["h"], raster_rgba=c["raster"], raster_depth=c["depth"])
+                tight_checked += 1
+                if frames_differ(got, want_ref):
+                    raise AssertionError("frame in the callee's tight-box SAH tree differs from the frame in the 0.1-padded PLOC tree")
             keys = COUNTER_KEYS if c["mode"] != "parts" else ("rays",)
             if {k: stats[k] for k in keys} != {k: cnt[k] for k in keys}:
                 raise AssertionError(f"counters differ: gpu { {k: stats[k] for k in keys} } oracle {cnt}")
@@ -252,7 +262,7 @@ def main():
                      window=np.asarray(c["window"]).view(np.uint8), size=np.array([c["w"], c["h"]]),
                      raster=np.zeros(0) if c["raster"] is None else c["raster"], depth=np.zeros(0) if c["depth"] is None else c["depth"])
     summary = (f"fuzz_parity seed {args.seed}: {done} cases bit-exact (frames + 5 counters), {fails} failed, {rejected} refused; "
-               f"{pixels} pixels, {rays} rays; {ploc_checked} callee-built trees byte-identical CPU vs GPU; "
+               f"{pixels} pixels, {rays} rays; {ploc_checked} callee-built trees byte-identical CPU vs GPU, {tight_checked} tight-box SAH frames equal to the PLOC-tree frame; "
                f"{time.time() - t_start:.0f} s")
     print(summary, flush=True)
     if args.log:

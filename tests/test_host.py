@@ -303,14 +303,29 @@ def test_sah_builder_contract_depth_cap_and_determinism():
         assert np.all(leaves["model_count"] == 1) and sorted(leaves["index"].tolist()) == list(range(n))
         inner = nodes[nodes["model_count"] == 0]
         assert len(inner) == n - 1 and np.all(inner["index"] % 2 == 1)                         # children at odd / even slot pairs
-    # finite scenes: every leaf box is Model::aabb (extract.rs:220-227) and every parent holds its children
+    # finite scenes: every leaf box is the sphere's bounds padded by the rule of brt_sah.h -- clamp(2^-24 (2 S)^2 / r, 0.01, 0.1), S the
+    # largest |c|_1 + r over the spheres of radius <= 100; larger spheres keep Model::aabb's 0.1 (extract.rs:220-227) -- and every
+    # parent holds its children
     m = cases[0]
     nodes = brt.build_bvh_sah(m)
+    f32 = np.float32
+    ordinary = m["radius"] <= 100
+    ap = np.abs(m["position"][ordinary]).astype(f32)
+    scale = (((ap[:, 0] + ap[:, 1]) + ap[:, 2]) + m["radius"][ordinary]).max()
+    pads = set()
     for nd in nodes:
         if nd["model_count"]:
-            c, r = m[nd["index"]]["position"], m[nd["index"]]["radius"]
-            pad = np.float32(r) + np.float32(0.1)
+            c, r = m[nd["index"]]["position"], f32(m[nd["index"]]["radius"])
+            if r <= 100:
+                d = f32(2.0) * f32(scale)
+                p = (f32(5.9604645e-8) * (d * d)) / r
+                p = f32(min(max(p, f32(0.01)), f32(0.1)))
+            else:
+                p = f32(0.1)
+            pads.add(float(p))
+            pad = r + p
             assert np.array_equal(nd["bounds_min"], c - pad) and np.array_equal(nd["bounds_max"], c + pad)
         else:
             for ch in (nodes[nd["index"]], nodes[nd["index"] + 1]):
                 assert np.all(ch["bounds_min"] >= nd["bounds_min"]) and np.all(ch["bounds_max"] <= nd["bounds_max"])
+    assert min(pads) == float(f32(0.01)) and max(pads) == float(f32(0.1))      # the small spheres and the ground sphere of the cover scene
