@@ -233,10 +233,13 @@ def main():
             bad = frames_differ(got, want)
             if bad:
                 raise AssertionError(f"{bad} of {got.size} frame values differ")
-            # the callee's SAH tree pads its leaf boxes by less than the reference's 0.1 (brt_sah.h sah_model_pad): on tame scenes without
-            # coincident spheres (exact ties are decided by the visiting order) the frame must also be the one of the caller's
-            # 0.1-padded PLOC tree -- i.e. the tighter boxes culled nothing a ray is accepted by
-            if b.bvh is None and quality and not c["wild"] and len(b.models) <= 3000 and \
+            # the callee's SAH tree pads its leaf boxes by less than the reference's 0.1 (brt_sah.h sah_model_pad): on well-conditioned scenes
+            # without coincident spheres (exact ties are decided by the visiting order) the frame must also be the one of the caller's
+            # 0.1-padded PLOC tree -- i.e. the tighter boxes culled nothing a ray is accepted by.  Well-conditioned = no sphere of radius
+            # > 10: this generator's giant spheres (radius 20-2000, hundreds of them overlapping at coordinates in the thousands) are
+            # beyond what the f32 sphere test resolves -- there the reference's OWN 0.1-padded tree disagrees with its brute-force loop
+            # (profiles/r04/fuzz_soak.txt: PLOC tree vs one leaf of all spheres differ in up to half the pixels), so no two trees agree.
+            if b.bvh is None and quality and not c["wild"] and len(b.models) <= 3000 and float(b.models["radius"].max()) <= 10.0 and \
                     len(np.unique(b.models.view(np.uint8).reshape(len(b.models), -1)[:, :16], axis=0)) == len(b.models):
                 want_ref, _ = oracle.render(brt.Buffers(b.models, b.materials, brt.build_bvh(b.models)), c["level"], c["camera"], c["window"],
                                             c["w"], c["h"], raster_rgba=c["raster"], raster_depth=c["depth"])

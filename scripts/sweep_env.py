@@ -15,7 +15,8 @@ def main():
     b = brt.generate_scene(scene, 1)
     lvl, cam, win = brt.cover_camera(w, h, spp, bounces)
     with brt.RaytracePlugin([0]) as p:
-        p.node.write_buffers(b)
+        # SWEEP_CALLEE_TREE=1: upload without a BVH (the callee builds its SAH tree on the GPU: what bench.py times)
+        p.node.write_buffers(brt.Buffers(b.models, b.materials, None) if os.environ.get("SWEEP_CALLEE_TREE") == "1" else b)
         out = p.alloc_frame(w, h)
         ref = None
         for rnd in range(2):          # two passes over the settings: the second is the one to read (clocks warm)
