@@ -411,6 +411,9 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+    if rccl is not None:
+        rccl.close()
+    if world > 1:
         dist.destroy_process_group()
     plugin.close()
 
