@@ -5,22 +5,28 @@
 // the rule (brt_host.cpp build_bvh_sah; tests compare with memcmp).
 //
 // A top-down build is a tree of dependent splits whose sizes fall from n to 2, so the work is cut where its shape changes:
-//   k_sah_prep   grid      padded sphere boxes as keys (brt_sah.h), f64 centroids, identity index list, the root task;
-//   k_sah_top    1 block   (scenes of more than kSubMax spheres) splits every node of more than kSubMax spheres with all
-//                          1024 threads -- a handful of nodes, each a few barrier-separated passes over its range -- and
-//                          emits the subtrees below as tasks;
-//   k_sah_sub    a block per subtree task (<= kSubMax spheres): nodes above kCoopMin spheres again by the whole block, then
-//                          level by level ONE WAVE PER NODE, the nodes of a level side by side on the block's 16 waves
-//                          (no barrier inside a split: a wave is its own team), until the level is empty.
-// Three launches, no host round trip, no grid-wide synchronisation; subtrees are independent, so the bottom of the tree --
-// where nearly all the n - 1 splits are -- runs on as many CUs as there are subtrees.
+//   k_sah_scale  grid      the scene's scale (an integer max over keys) for the leaf boxes' padding (brt_sah.h sah_model_pad);
+//   k_sah_prep   grid      sphere boxes as keys (brt_sah.h), f64 centroids, identity index list, the root task;
+//   k_sah_top    per level (scenes of more than kSubMax spheres) A WORKGROUP PER NODE of more than kSubMax spheres, the nodes of a
+//                          level side by side: each split a few barrier-separated passes of all 1024 threads over the node's range
+//                          in global memory; children of more than kSubMax spheres go to the next level's list, smaller ones become
+//                          subtree tasks.  ceil(log2(n / kSubMax)) + 2 levels are launched, then ONE workgroup finishes whatever a
+//                          lopsided top has left (depth first);
+//   k_sah_sub    a workgroup per subtree task (<= kSubMax spheres), the subtree's boxes, centroids and index lists STAGED IN LDS:
+//                          level by level, A WAVE PER NODE for nodes of more than kLaneMax spheres (no barrier inside a split: a wave
+//                          is its own team) and A LANE PER NODE below that -- seven of eight interior nodes of a tree hold at most 8
+//                          spheres, and as wave splits each is ~2.5 us of dependent latency.
+// No host round trip, no grid-wide synchronisation; subtrees are independent, so the bottom of the tree -- where nearly all the
+// n - 1 splits are -- runs on as many CUs as there are subtrees.  10 004 spheres: scale + prep 8 us, top 5 levels 76 / 74 / 50 / 38 /
+// 30 us, subtrees 190 us (profiles/r04/sah_build_kernel_breakdown.txt).
 //
-// One split (sah_split): (1) node box and centroid extent of the range -- lanes stride over the range, wave shuffles (and LDS
-// across waves for a block team) reduce; (2) binning: a lane per sphere, LDS atomics (integer min / max on keys, add on the
-// counts) into 3 x 16 bins; (3) 48 lanes evaluate the 3 x 15 split candidates (left / right box and count of candidate
-// (axis, bin) from the bins), a wave argmin over (cost, axis, bin) picks the reference builder's winner; (4) stable partition
-// of the range into the other index buffer by ballot + mbcnt ranks.  Every quantity is an integer or a min / max over a
-// set, so the order in which lanes arrive does not show in the result.
+// One split by a team (sah_split): (1) node box and centroid extent of the range -- lanes stride over the range, wave shuffles (and
+// LDS across waves for a block team) reduce; (2) binning: a lane per sphere, LDS atomics (integer min / max on keys, add on the counts)
+// into 3 x 16 bins, each bound LOOKED AT before the atomic (a bound only moves one way: clustered spheres then cost a broadcast read
+// instead of a 64-way serialised atomic); (3) 48 lanes evaluate the 3 x 15 split candidates (left / right box and count of candidate
+// (axis, bin) from the bins), a wave argmin over (cost, axis, bin) picks the CPU loop's winner; (4) stable partition of the range into
+// the other index buffer by ballot + mbcnt ranks.  Every quantity is an integer or a min / max over a set, so the order in which
+// lanes arrive does not show in the result.
 #include <hip/hip_runtime.h>
 
 #include "brt_kernels.h"

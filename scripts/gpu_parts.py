@@ -37,7 +37,8 @@ def main():
             b = brt.generate_scene(kind, 1)
             cam_fn = brt.rtiow_camera if camera == "rtiow" and hasattr(brt, "rtiow_camera") else brt.cover_camera
             lvl, cam, win = cam_fn(W, H, spp, bounces)
-            p.node.write_buffers(b)
+            # the tree the callee builds (what bench.py times); BRT_CALLER_TREE=1: the caller's PLOC tree
+            p.node.write_buffers(b if os.environ.get("BRT_CALLER_TREE") == "1" else brt.Buffers(b.models, b.materials, None))
             print(f"== {name}", flush=True)
             one = None
             for n in a.parts:

@@ -20,7 +20,8 @@ a = ap.parse_args()
 b = brt.generate_scene(a.scene, 1)
 lvl, cam, win = (brt.rtiow_camera if a.camera == "rtiow" else brt.cover_camera)(a.w, a.h, a.spp, a.bounces)
 with brt.RaytracePlugin([0]) as p:
-    p.node.write_buffers(b)
+    # the tree the callee builds (what bench.py times); BRT_CALLER_TREE=1: the caller's PLOC tree
+    p.node.write_buffers(b if os.environ.get("BRT_CALLER_TREE") == "1" else brt.Buffers(b.models, b.materials, None))
     for i in range(a.reps):
         f = p.node.run(lvl, cam, win, a.w, a.h, flags=a.flags)
         s = p.node.last_stats

@@ -15,7 +15,8 @@ def main():
     bounces = int(sys.argv[3]) if len(sys.argv) > 3 else 8
     b = brt.generate_scene(scene, 1)
     with brt.RaytracePlugin([0]) as p:
-        p.node.write_buffers(b)
+        # the tree the callee builds (what bench.py times); BRT_CALLER_TREE=1: the caller's PLOC tree
+        p.node.write_buffers(b if os.environ.get("BRT_CALLER_TREE") == "1" else brt.Buffers(b.models, b.materials, None))
         for (w, h) in ((1, 1), (2, 1), (4, 1), (8, 1), (8, 2), (8, 4), (8, 8)):
             # a tiny frame of the same camera sees the scene centre: spheres and ground, paths of several bounces
             lvl, cam, win = (brt.rtiow_camera if scene == 1 else brt.cover_camera)(w, h, spp, bounces)
