@@ -341,6 +341,7 @@ int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hi
     tp.sky_slack_permille = ctx->knobs[K_LPT_SKY_SLACK];
     tp.lane_permille = ctx->knobs[K_LPT_LANE_PERMILLE];
     tp.critical = ctx->knobs[K_CRIT];
+    tp.tiles_x = fp.tiles_x;
     int32_t rc = ensure(ctx, &dc.d_tile_order, &dc.tile_order_cap, (size_t)n_tiles * 4);
     if (rc != BRT_OK) return rc;
     const bool on_device = tp.sorted == 1u && tp.critical == 1u && tp.lane_permille == 0u && ctx->knobs[K_ORDER_ON_HOST] == 0u;
@@ -356,7 +357,9 @@ int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hi
         // (slowest share of config 2 in 2 / 4 parts 6.24 / 5.13 ms without, 6.60 / 5.31 with; profiles/r04/parts_dilate.txt).
         const uint64_t wave_slots = (uint64_t)dc.num_cus * (BRT_BLOCK / 64u);
         const uint32_t r0 = (ctx->knobs[K_LPT_DILATE] >= 2u && (uint64_t)n_tiles >= 6u * wave_slots) ? ctx->knobs[K_LPT_DILATE] - 1u : 0u;
-        rc = build_order_on_device(ctx, dc, n_tiles, fp.tiles_x, tp.sample_count, r0, r0 ? (r0 + fp.n_parts - 1u) / fp.n_parts : 0u, stream);
+        tp.dilate_x = r0;
+        tp.dilate_y = r0 ? (r0 + fp.n_parts - 1u) / fp.n_parts : 0u;
+        rc = build_order_on_device(ctx, dc, n_tiles, fp.tiles_x, tp.sample_count, tp.dilate_x, tp.dilate_y, stream);
         if (rc != BRT_OK) return rc;
         dc.order_lane = 0;
         dc.order_crit = 0;
@@ -1269,9 +1272,11 @@ int32_t brt_debug_profile(brt_ctx* ctx, uint64_t* out64) {
 }
 
 int32_t brt_debug_tile_order(brt_ctx* ctx, const uint32_t* ray_sum, const uint32_t* longest_pixel, uint32_t n_tiles,
-                             uint32_t sample_count, uint64_t grid_lanes, uint32_t* out_order, uint32_t* out_info2) {
+                             uint32_t sample_count, uint64_t grid_lanes, uint32_t tiles_x, uint32_t dilate, uint32_t* out_order,
+                             uint32_t* out_info2) {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (!ray_sum || !longest_pixel || !out_order || !out_info2 || n_tiles == 0) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "null buffer / no tiles");
+    if (dilate != 0u && (tiles_x == 0u || n_tiles % tiles_x != 0u)) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "dilate needs a tiles_x that divides n_tiles");
     DeviceCtx& dc = ctx->devs[0];
     HIP_TRY(ctx, hipSetDevice(dc.device));
     uint32_t* d_cost = nullptr;
@@ -1286,7 +1291,7 @@ int32_t brt_debug_tile_order(brt_ctx* ctx, const uint32_t* ray_sum, const uint32
         HIP_TRY(ctx, hipMemcpyAsync(d_cost, ray_sum, (size_t)n_tiles * 4, hipMemcpyHostToDevice, dc.stream));
         HIP_TRY(ctx, hipMemcpyAsync(d_cost + n_tiles, longest_pixel, (size_t)n_tiles * 4, hipMemcpyHostToDevice, dc.stream));
         const uint64_t sky_cost = (uint64_t)64 * sample_count * (1000 + 20) / 1000;
-        HIP_TRY(ctx, launch_build_order(d_cost, d_cost + n_tiles, n_tiles, sky_cost, grid_lanes, 0u, 0u, 0u, d_order, d_meta, d_scratch, dc.stream));
+        HIP_TRY(ctx, launch_build_order(d_cost, d_cost + n_tiles, n_tiles, sky_cost, grid_lanes, tiles_x, dilate, dilate, d_order, d_meta, d_scratch, dc.stream));
         HIP_TRY(ctx, hipMemcpyAsync(out_order, d_order, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, dc.stream));
         HIP_TRY(ctx, hipMemcpyAsync(out_info2, d_meta, 8, hipMemcpyDeviceToHost, dc.stream));
         HIP_TRY(ctx, hipStreamSynchronize(dc.stream));

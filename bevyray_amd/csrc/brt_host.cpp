@@ -515,25 +515,47 @@ void build_tile_order(const uint32_t* ray_sum, const uint32_t* longest, uint32_t
     o = TileOrder();
     o.order.resize(n_tiles);
     const uint64_t sky_cost = (uint64_t)64 * p.sample_count * (1000 + p.sky_slack_permille) / 1000;
-    std::vector<uint64_t> keys;                                                // non-sky tiles: (~longest pixel, index)
+    // what a tile is ranked by: itself, or its neighbourhood (brt_order.hip tile_cost_at)
+    std::vector<uint32_t> rank(n_tiles);
+    std::vector<uint8_t> is_sky(n_tiles);
+    const bool dilated = (p.dilate_x | p.dilate_y) != 0u && p.tiles_x != 0u;
+    const uint32_t tiles_y = dilated ? n_tiles / p.tiles_x : 0u;
+    for (uint32_t i = 0; i < n_tiles; i++) {
+        uint32_t lp = longest[i];
+        bool sky = ray_sum[i] <= sky_cost;
+        if (dilated) {
+            const uint32_t ty = i / p.tiles_x, tx = i - ty * p.tiles_x;
+            const uint32_t x0 = tx > p.dilate_x ? tx - p.dilate_x : 0u, x1 = std::min(tx + p.dilate_x, p.tiles_x - 1u);
+            const uint32_t y0 = ty > p.dilate_y ? ty - p.dilate_y : 0u, y1 = std::min(ty + p.dilate_y, tiles_y - 1u);
+            for (uint32_t y = y0; y <= y1 && y < tiles_y; y++)
+                for (uint32_t x = x0; x <= x1; x++) {
+                    const uint32_t j = y * p.tiles_x + x;
+                    lp = std::max(lp, longest[j]);
+                    sky = sky && ray_sum[j] <= sky_cost;
+                }
+        }
+        rank[i] = lp;
+        is_sky[i] = sky ? 1 : 0;
+    }
+    std::vector<uint64_t> keys;                                                // non-sky tiles: (~rank, index)
     uint64_t sum = 0;
     for (uint32_t i = 0; i < n_tiles; i++) {
         sum += ray_sum[i];
         o.longest_pixel = longest[i] > o.longest_pixel ? longest[i] : o.longest_pixel;
-        if (ray_sum[i] > sky_cost) keys.push_back(((uint64_t)(~longest[i]) << 32) | i);
+        if (!is_sky[i]) keys.push_back(((uint64_t)(~rank[i]) << 32) | i);
     }
     if (p.sorted) std::sort(keys.begin(), keys.end());                         // longest first, then by index
     uint32_t k = 0;
     for (uint64_t key : keys) o.order[k++] = (uint32_t)(key & 0xffffffffu);
     for (uint32_t tile = 0; tile < n_tiles; tile++)                            // sky tiles: raster order
-        if (ray_sum[tile] <= sky_cost) o.order[k++] = tile;
+        if (is_sky[tile]) o.order[k++] = tile;
     o.n_lane = (uint32_t)((uint64_t)keys.size() * p.lane_permille / 1000u);
     if (o.n_lane > keys.size()) o.n_lane = (uint32_t)keys.size();
     if (p.sorted && p.critical && p.grid_lanes != 0) {
         const uint64_t per_lane = sum / p.grid_lanes;
         const uint64_t thr = per_lane / 2 > o.longest_pixel / 2 ? per_lane / 2 : o.longest_pixel / 2;
         if (o.longest_pixel >= per_lane / 2)
-            while (o.n_critical < keys.size() && longest[o.order[o.n_critical]] >= thr) o.n_critical++;
+            while (o.n_critical < keys.size() && rank[o.order[o.n_critical]] >= thr) o.n_critical++;
     }
 }
 
@@ -644,11 +666,13 @@ int32_t brt_host_material(const float* base_color_srgb3, float metallic, float p
 }
 
 int32_t brt_host_tile_order(const uint32_t* ray_sum, const uint32_t* longest_pixel, uint32_t n_tiles, uint32_t sample_count,
-                            uint64_t grid_lanes, uint32_t sorted, uint32_t lane_permille, uint32_t* out_order, uint32_t* out_info3) {
+                            uint64_t grid_lanes, uint32_t sorted, uint32_t lane_permille, uint32_t tiles_x, uint32_t dilate,
+                            uint32_t* out_order, uint32_t* out_info3) {
     if (!ray_sum || !longest_pixel || !out_order || !out_info3) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
+    if (dilate != 0u && (tiles_x == 0u || n_tiles % tiles_x != 0u)) return fail(BRT_ERR_INVALID_ARGUMENT, "dilate needs a tiles_x that divides n_tiles");
     TileOrderParams tp{};
     tp.sample_count = sample_count; tp.grid_lanes = grid_lanes; tp.sorted = sorted; tp.sky_slack_permille = 20;
-    tp.lane_permille = lane_permille; tp.critical = 1;
+    tp.lane_permille = lane_permille; tp.critical = 1; tp.tiles_x = tiles_x; tp.dilate_x = tp.dilate_y = dilate;
     TileOrder to;
     build_tile_order(ray_sum, longest_pixel, n_tiles, tp, &to);
     std::memcpy(out_order, to.order.data(), (size_t)n_tiles * 4);

@@ -43,6 +43,9 @@ struct TileOrderParams {
     uint32_t sky_slack_permille; // a tile is "sky" when it needed <= 64 * spp * (1 + slack) rays
     uint32_t lane_permille;      // share of the non-sky tiles (the front of the order) that goes to the lane queue
     uint32_t critical;           // 1: mark critical tiles
+    // a tile is ranked by the longest pixel of its (2 dilate_x + 1) x (2 dilate_y + 1) neighbourhood in the tiles_x-wide tile grid and
+    // is "sky" only if that whole neighbourhood was (0, 0: by itself); brt_order.hip has the why
+    uint32_t tiles_x = 0, dilate_x = 0, dilate_y = 0;
 };
 struct TileOrder {
     std::vector<uint32_t> order; // order[k] = k-th tile to hand out

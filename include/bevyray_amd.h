@@ -275,7 +275,8 @@ int32_t brt_debug_profile(brt_ctx* ctx, uint64_t* out64);
  * frame with default settings) for given per-tile ray counts: out_order as brt_host_tile_order's, out_info2 =
  * {critical tiles at the front, longest pixel}.  Tests compare it with brt_host_tile_order.  Host pointers, synchronous. */
 int32_t brt_debug_tile_order(brt_ctx* ctx, const uint32_t* ray_sum, const uint32_t* longest_pixel, uint32_t n_tiles,
-                             uint32_t sample_count, uint64_t grid_lanes, uint32_t* out_order, uint32_t* out_info2);
+                             uint32_t sample_count, uint64_t grid_lanes, uint32_t tiles_x, uint32_t dilate, uint32_t* out_order,
+                             uint32_t* out_info2);
 
 /* ---- host-only helpers (no GPU needed) --------------------------------------------- */
 
@@ -283,11 +284,13 @@ int32_t brt_debug_tile_order(brt_ctx* ctx, const uint32_t* ray_sum, const uint32
  * 8x8 tile): out_order[k] = k-th tile to hand out -- the non-sky tiles (longest pixel
  * first when `sorted`), then the one-ray-per-sample "sky" tiles; out_info3 = {tiles at the front that go to the
  * lane queue (pixel by pixel to single lanes; the rest are handed out as whole tiles), critical tiles at the
- * front, longest pixel}.  grid_lanes = CUs x threads per workgroup.  No reference counterpart: the reference
- * draws one fullscreen triangle (pipeline.rs:206-215). */
+ * front, longest pixel}.  grid_lanes = CUs x threads per workgroup.  dilate > 0: a tile is ranked by the longest pixel of the
+ * (2 dilate + 1)^2 tiles around it in the tiles_x-wide tile grid, and is "sky" only if all of them were (what brt_render does by
+ * default with radius 2, and with the radius the motion covers when the camera has moved since the costs were measured).  No
+ * reference counterpart: the reference draws one fullscreen triangle (pipeline.rs:206-215). */
 int32_t brt_host_tile_order(const uint32_t* ray_sum, const uint32_t* longest_pixel, uint32_t n_tiles, uint32_t sample_count,
-                            uint64_t grid_lanes, uint32_t sorted, uint32_t lane_permille, uint32_t* out_order,
-                            uint32_t* out_info3);
+                            uint64_t grid_lanes, uint32_t sorted, uint32_t lane_permille, uint32_t tiles_x, uint32_t dilate,
+                            uint32_t* out_order, uint32_t* out_info3);
 
 /* Replaces: obvhs::ploc::build_ploc::<24>(aabbs, identity, SortPrecision::U64, 0) and the
  * flatten into BVHNode (extract.rs:315-332), including Model::aabb's 0.1 pad

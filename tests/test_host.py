@@ -227,13 +227,36 @@ def test_create_fails_loudly_without_a_gpu():
     assert e.value.code == -2 and "no CPU path" in e.value.text
 
 
-def _tile_order(ray_sum, longest, spp, grid_lanes, sorted_=1, lane_permille=0):
+def test_new_exports_fail_with_codes_not_crashes_without_a_context():
+    """ABI 4 entry points called the wrong way (no GPU needed): null contexts and pointers come back as BRT_ERR_INVALID_ARGUMENT,
+    never as a crash; the RCCL id either works (librccl resolves by dlopen: rank 0 of any host may call it without a context) or
+    reports BRT_ERR_RCCL with a text."""
+    import ctypes as C
+    lib = _lib.load()
+    ptr, fd = C.c_void_p(), C.c_int32(-1)
+    assert lib.brt_gather_rccl(None, None, 0, 1, None, None, 8, 8, None, None, 0) == -1
+    assert lib.brt_rccl_comm_create(None, None, 0, 1, C.byref(ptr)) == -1
+    assert lib.brt_rccl_comm_destroy(None, None) == 0                      # nothing to destroy
+    assert lib.brt_import_frame_fd(None, 3, 64, 2, C.byref(ptr)) == -1
+    assert lib.brt_release_frame(None, None) == -1
+    assert lib.brt_debug_export_frame_fd(None, 64, C.byref(fd), C.byref(ptr)) == -1
+    assert lib.brt_debug_copy_to_host(None, None, None, 0) == -1
+    assert lib.brt_build_bvh_sah_device(None, None, 0, None, 0, None, None) == -1
+    assert lib.brt_rccl_unique_id(None) == -1
+    buf = (C.c_char * 128)()
+    rc = lib.brt_rccl_unique_id(buf)
+    assert rc in (0, -10)
+    if rc == -10:
+        assert lib.brt_last_error(None)
+
+
+def _tile_order(ray_sum, longest, spp, grid_lanes, sorted_=1, lane_permille=0, tiles_x=0, dilate=0):
     ray_sum = np.ascontiguousarray(ray_sum, np.uint32)
     longest = np.ascontiguousarray(longest, np.uint32)
     order = np.zeros(len(ray_sum), np.uint32)
     info = np.zeros(3, np.uint32)
     _lib.check(_lib.load().brt_host_tile_order(ray_sum.ctypes.data, longest.ctypes.data, len(ray_sum), spp, grid_lanes, sorted_,
-                                               lane_permille, order.ctypes.data, info.ctypes.data))
+                                               lane_permille, tiles_x, dilate, order.ctypes.data, info.ctypes.data))
     return order, dict(zip(("n_lane", "n_critical", "longest_pixel"), (int(x) for x in info)))
 
 

@@ -1270,13 +1270,17 @@ def test_gpu_tile_order_equals_host_tile_order(plugin):
             if flavour == 1 and n > 10:
                 k = len(longest[1::5])
                 longest[0:5 * k:5] = longest[1::5]           # ties: raster order among equals
-            want = np.zeros(n, np.uint32); info3 = np.zeros(3, np.uint32)
-            _lib.check(lib.brt_host_tile_order(ray_sum.ctypes.data, longest.ctypes.data, n, spp, lanes, 1, 0, want.ctypes.data, info3.ctypes.data))
-            got = np.zeros(n, np.uint32); info2 = np.zeros(2, np.uint32)
-            _lib.check(lib.brt_debug_tile_order(plugin._ctx, ray_sum.ctypes.data, longest.ctypes.data, n, spp, lanes, got.ctypes.data,
-                                                info2.ctypes.data), plugin._ctx)
-            assert np.array_equal(got, want), (n, spp, flavour)
-            assert int(info2[0]) == int(info3[1]) and int(info2[1]) == int(info3[2]), (n, spp, flavour, info2, info3)
+            # ranked by itself, and by the neighbourhood of radius 2 / 5 in a tile grid of some width that divides n (brt_render's default / a moved camera)
+            widths = [t for t in (240, 120, 37, 16, 8, 5, 1) if n % t == 0]
+            for tiles_x, dilate in [(0, 0)] + [(widths[0], d) for d in (2, 5)]:
+                want = np.zeros(n, np.uint32); info3 = np.zeros(3, np.uint32)
+                _lib.check(lib.brt_host_tile_order(ray_sum.ctypes.data, longest.ctypes.data, n, spp, lanes, 1, 0, tiles_x, dilate, want.ctypes.data,
+                                                   info3.ctypes.data))
+                got = np.zeros(n, np.uint32); info2 = np.zeros(2, np.uint32)
+                _lib.check(lib.brt_debug_tile_order(plugin._ctx, ray_sum.ctypes.data, longest.ctypes.data, n, spp, lanes, tiles_x, dilate,
+                                                    got.ctypes.data, info2.ctypes.data), plugin._ctx)
+                assert np.array_equal(got, want), (n, spp, flavour, tiles_x, dilate)
+                assert int(info2[0]) == int(info3[1]) and int(info2[1]) == int(info3[2]), (n, spp, flavour, tiles_x, dilate, info2, info3)
 
 
 def test_order_built_on_host_and_on_gpu_render_the_same_frames(oracle, monkeypatch):
