@@ -302,7 +302,6 @@ struct ScenePtrs {
     uint32_t near_bytes;
     uint32_t near_base;      // LDS byte address of the tile (SCENE_LDS: of the pair records)
     uint32_t sph_base;       // SCENE_LDS: LDS byte address of the spheres
-    uint32_t pair_slots;     // SCENE_LDS: LDS byte address of this wave's 32 slot words (walk_wave_lds_pair_asm)
     bool boxes_ordered;      // every child box finite with min <= max (decided at upload)
     const float4* spheres;
     const uint32_t* sphere_material;
@@ -739,11 +738,7 @@ BRT_DEV void walk_wave_lds_asm(uint32_t& cur, uint32_t& spa, float& closest, uin
 #endif
 }
 
-BRT_DEV void walk_wave_lds_pair_asm(uint32_t& cur, uint32_t& spa, float& closest, uint32_t& closest_idx, uint32_t gofs_x, uint32_t gofs_y,
-                                    uint32_t gofs_z, f3 o, f3 inv, f3 d, float a, uint32_t sph, uint32_t exit_at, uint32_t vote,
-                                    uint32_t rank, uint32_t n_walk, uint32_t slot_base);
-
-template <bool D16, bool SIMPLE_TREE, bool PAIR, typename StackT>
+template <bool D16, bool SIMPLE_TREE, typename StackT>
 BRT_DEV void walk_loop_wave_lds(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, uint32_t ox, uint32_t oy, uint32_t oz,
                                 float& closest, uint32_t& closest_idx, uint32_t& cur, StackT*& sp, uint32_t& n,
                                 uint32_t exit_at, uint32_t vote, HitCounters& hc) {
@@ -751,22 +746,6 @@ BRT_DEV void walk_loop_wave_lds(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv
     typedef __attribute__((address_space(3))) StackT lds_stack;
     uint32_t spa = (uint32_t)(uintptr_t)(lds_stack*)sp;
     const uint32_t sph = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.sph_base);
-    if (PAIR) {
-        // at most 32 rays walk: two lanes per ray (walk_wave_lds_pair_asm).  The walkers are the lanes that run this call.
-        const uint64_t walkers = __ballot(cur != Desc<D16>::DONE);
-        const uint32_t n_walk = (uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(walkers));
-        if (n_walk <= 32u && walkers == __ballot(true)) {     // (every lane that runs the call walks: no unsafe ray went through the repairing loop)
-            const uint64_t mine = walkers;
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(walkers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)walkers, 0u));
-            const uint32_t slots = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.pair_slots);
-            typedef __attribute__((address_space(3))) uint32_t lds_u32;
-            (void)mine;
-            *reinterpret_cast<lds_u32*>((uintptr_t)(slots + 4u * rank)) = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-            walk_wave_lds_pair_asm(cur, spa, closest, closest_idx, ox, oy, oz, o, inv, d, a, sph, exit_at, vote, rank, n_walk, slots);
-            sp = (StackT*)reinterpret_cast<lds_stack*>((uintptr_t)spa);
-            return;
-        }
-    }
     // (the leaf step runs when at least `vote` of the lanes that walked at the last leaf step wait at a leaf -- walk_loop_wave
     //  counts the leaf lanes instead; the rules differ only when a lane ends its walk inside a run of interior steps, and only
     //  in when the leaf step runs)
@@ -774,206 +753,7 @@ BRT_DEV void walk_loop_wave_lds(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv
     sp = (StackT*)reinterpret_cast<lds_stack*>((uintptr_t)spa);
 }
 
-// ---- the same loop for a THIN wave: two lanes per ray ---------------------------------------------------------------------------
-// A wave with at most 32 walking rays (the last waves of a frame, a rank's share at 8 GPUs, the one pixel chain config 3 is as
-// long as) pays the full instruction count of every step for a few lanes.  Here lane l tests child L and lane l + 32 child R of
-// the ray of rank l: per lane 12 sub / mul, 4 min / max and ONE compare instead of 24 / 8 / 2, three ds_read2_b32 (my child's
-// {near, far} per axis: dwords side and side + 2 of the granule) instead of three ds_read_b128; the two compare results of a ray are
-// vcc_lo and vcc_hi, so the masks {none, only L, R, both} are four 32-bit scalar instructions and each goes to both halves of
-// EXEC.  Timed in isolation (tests/tools/pair_step_bench.hip): 155.8 -> 133.8 ns per step for one ray in a wave alone on its CU.
-// Both lanes of a ray carry its whole walk state and make the same pops and pushes on the ray's own stack column, the leaf step is
-// the wide loop's (both lanes compute it): per ray the same steps in the same order, pixels and counters cannot change.
-// The rays come in packed: the walkers' lane ids stand in slot[rank] (LDS, 32 words of this wave), lane l and l + 32 fetch the state
-// of the ray of rank l with ds_bpermute_b32 -- with EXEC forced to all ones, because the pair lanes need not be lanes the caller
-// runs (registers of such lanes that this block writes are its own outputs, temporaries and clobbers: dead there) -- and the four
-// results travel back to the owners the same way.  v[100:113] as in the wide loop, v[114:126] the ray's constants.
-BRT_DEV void walk_wave_lds_pair_asm(uint32_t& cur, uint32_t& spa, float& closest, uint32_t& closest_idx, uint32_t gofs_x, uint32_t gofs_y,
-                                    uint32_t gofs_z, f3 o, f3 inv, f3 d, float a, uint32_t sph, uint32_t exit_at, uint32_t vote,
-                                    uint32_t rank, uint32_t n_walk, uint32_t slot_base) {
-#if BRT_HAND_ASM
-    uint32_t t0, tx, ty, tz, pop, cnt, nw, thr, take, any, both, only_l;
-    float below;
-    uint64_t s_own, s_p2, s_any, s_both;
-    const uint32_t rec_bytes = PAIR_BYTES, c_tiny = 0x0f800000u /* 2^-96 */, c_eps = 0x3a83126fu /* 0.001f */, c_cls = 0x260u /* +-0, +inf */;
-    const uint32_t exit2 = 2u * exit_at, vote2 = 2u * vote;
-    asm volatile(
-        "s_waitcnt lgkmcnt(0)\n"                                // the slot table is written, nothing of the compiler's is in flight
-        "s_mov_b64 %[s_own], exec\n"
-        "s_mov_b64 exec, -1\n"
-        // ---- the rays into pairs -----------------------------------------------------------------------------------------------
-        "v_mbcnt_lo_u32_b32 v100, -1, 0\n"
-        "v_mbcnt_hi_u32_b32 v100, -1, v100\n"                   // lane id
-        "v_and_b32_e32 v101, 31, v100\n"                        // the rank of the ray this lane works on
-        "v_lshrrev_b32_e32 v102, 5, v100\n"                     // 0: child L, 1: child R
-        "v_lshl_add_u32 v103, v101, 2, %[slot_base]\n"
-        "ds_read_b32 v103, v103\n"                              // its owner's lane id
-        "v_lshlrev_b32_e32 v102, 2, v102\n"                     // my child's dword inside a granule, as bytes
-        "s_waitcnt lgkmcnt(0)\n"
-        "v_lshlrev_b32_e32 v103, 2, v103\n"
-        "ds_bpermute_b32 %[cur], v103, %[cur]\n"
-        "ds_bpermute_b32 %[spa], v103, %[spa]\n"
-        "ds_bpermute_b32 %[closest], v103, %[closest]\n"
-        "ds_bpermute_b32 %[cidx], v103, %[cidx]\n"
-        "ds_bpermute_b32 v114, v103, %[ox]\n ds_bpermute_b32 v115, v103, %[oy]\n ds_bpermute_b32 v116, v103, %[oz]\n"
-        "ds_bpermute_b32 v117, v103, %[ix]\n ds_bpermute_b32 v118, v103, %[iy]\n ds_bpermute_b32 v119, v103, %[iz]\n"
-        "ds_bpermute_b32 v120, v103, %[dx]\n ds_bpermute_b32 v121, v103, %[dy]\n ds_bpermute_b32 v122, v103, %[dz]\n"
-        "ds_bpermute_b32 v123, v103, %[a]\n"
-        "ds_bpermute_b32 v124, v103, %[gofs_x]\n ds_bpermute_b32 v125, v103, %[gofs_y]\n ds_bpermute_b32 v126, v103, %[gofs_z]\n"
-        "v_cmp_le_u32_e32 vcc, %[n_walk], v101\n"               // pair lanes beyond the last ray
-        "s_waitcnt lgkmcnt(0)\n"
-        "v_add_u32_e32 v124, v124, v102\n v_add_u32_e32 v125, v125, v102\n v_add_u32_e32 v126, v126, v102\n"
-        "s_mov_b64 exec, vcc\n"
-        "v_mov_b32_e32 %[cur], -1\n"                            // ... hold no walk
-        "s_mov_b64 exec, -1\n"
-        "v_add_u32_e32 %[below], -1, %[closest]\n"
-        // ---- outer loop: leave when at most exit_at rays still walk (two lanes each) -----------------------------------------
-        "3:\n"
-        "v_cmp_ne_u32_e32 vcc, -1, %[cur]\n"
-        "s_bcnt1_i32_b64 %[nw], vcc\n"
-        "s_cmp_le_u32 %[nw], %[exit2]\n"
-        "s_cbranch_scc1 9f\n"
-        "s_max_u32 %[thr], %[nw], %[vote2]\n"
-        "s_sub_u32 %[thr], %[thr], %[vote2]\n"
-        "v_cmp_lt_i32_e32 vcc, -1, %[cur]\n"
-        "s_bcnt1_i32_b64 %[cnt], vcc\n"
-        "s_cmp_le_u32 %[cnt], %[thr]\n"
-        "s_cbranch_scc1 5f\n"
-        // ---- interior steps, one child per lane --------------------------------------------------------------------------------
-        "1:\n"
-        "s_mov_b32 %[take], vcc_lo\n"                           // (both halves alike: a ray's two lanes are in one state)
-        "s_mov_b64 exec, vcc\n"
-        "ds_read_i16 %[pop], %[spa]\n"
-        "v_mul_lo_u32 %[t0], %[cur], %[rec_bytes]\n"
-        "v_add_u32_e32 %[tx], %[t0], v124\n"
-        "ds_read2_b32 v[100:101], %[tx] offset1:2\n"            // { near, far } of my child, x
-        "v_add_u32_e32 %[ty], %[t0], v125\n"
-        "ds_read2_b32 v[102:103], %[ty] offset1:2\n"
-        "v_add_u32_e32 %[tz], %[t0], v126\n"
-        "ds_read2_b32 v[104:105], %[tz] offset1:2\n"
-        "ds_read_b64 v[112:113], %[t0] offset:96\n"             // descriptors of L and R
-        "s_waitcnt lgkmcnt(3)\n"
-        "v_sub_f32_e32 v100, v100, v114\n v_sub_f32_e32 v101, v101, v114\n v_mul_f32_e32 v100, v100, v117\n v_mul_f32_e32 v101, v101, v117\n"
-        "s_waitcnt lgkmcnt(2)\n"
-        "v_sub_f32_e32 v102, v102, v115\n v_sub_f32_e32 v103, v103, v115\n v_mul_f32_e32 v102, v102, v118\n v_mul_f32_e32 v103, v103, v118\n"
-        "s_waitcnt lgkmcnt(1)\n"
-        "v_sub_f32_e32 v104, v104, v116\n v_sub_f32_e32 v105, v105, v116\n v_mul_f32_e32 v104, v104, v119\n v_mul_f32_e32 v105, v105, v119\n"
-        "v_max_f32_e32 v100, v100, v102\n"
-        "v_min_f32_e32 v101, v101, v103\n"
-        "v_max3_f32 v100, v100, v104, 1\n"                      // t_near = max(.., denorm_min)
-        "v_min3_f32 v101, v101, v105, %[below]\n"               // t_far = min(.., below(closest))
-        "s_waitcnt lgkmcnt(0)\n"
-        "ds_write_b16 %[spa], v112 offset:128\n"                // child L above the top (both lanes: the same word, the same value)
-        "v_cmp_le_f32_e32 vcc, v100, v101\n"                    // vcc_lo: L pushed (raytrace.wgsl:331), vcc_hi: R pushed (:338), bit = ray
-        "s_or_b32 %[any], vcc_lo, vcc_hi\n"
-        "s_and_b32 %[both], vcc_lo, vcc_hi\n"
-        "s_andn2_b32 %[only_l], vcc_lo, vcc_hi\n"
-        "s_andn2_b32 exec_lo, %[take], %[any]\n s_andn2_b32 exec_hi, %[take], %[any]\n"      // no child pushed: pop
-        "v_mov_b32_e32 %[cur], %[pop]\n"
-        "v_add_u32_e32 %[spa], 0xffffff80, %[spa]\n"
-        "s_mov_b32 exec_lo, %[only_l]\n s_mov_b32 exec_hi, %[only_l]\n"
-        "v_mov_b32_e32 %[cur], v112\n"
-        "s_mov_b32 exec_lo, vcc_hi\n s_mov_b32 exec_hi, vcc_hi\n"                             // R (pushed last, popped first)
-        "v_mov_b32_e32 %[cur], v113\n"
-        "s_mov_b32 exec_lo, %[both]\n s_mov_b32 exec_hi, %[both]\n"                           // both: L stays on the stack
-        "v_add_u32_e32 %[spa], 0x80, %[spa]\n"
-        "s_mov_b64 exec, -1\n"
-        "v_cmp_lt_i32_e32 vcc, -1, %[cur]\n"
-        "s_bcnt1_i32_b64 %[cnt], vcc\n"
-        "s_cmp_gt_u32 %[cnt], %[thr]\n"
-        "s_cbranch_scc1 1b\n"
-        // ---- one leaf step for every ray that waits at a leaf (both lanes of a ray compute it: the wide loop's step) ----------
-        "5:\n"
-        "v_cmp_gt_i32_e32 vcc, -1, %[cur]\n"                    // leaf descriptors are < -1
-        "s_mov_b64 exec, vcc\n"
-        "v_and_b32_e32 v112, 0x3fff, %[cur]\n"                  // the leaf's sphere
-        "v_lshl_add_u32 %[t0], v112, 4, %[sph]\n"
-        "ds_read_b128 v[100:103], %[t0]\n"                      // { centre, r^2 }
-        "ds_read_i16 %[cur], %[spa]\n"                          // pop
-        "s_waitcnt lgkmcnt(1)\n"
-        "v_sub_f32_e32 v104, v100, v114\n"                      // oc = centre - origin
-        "v_sub_f32_e32 v105, v101, v115\n"
-        "v_sub_f32_e32 v106, v102, v116\n"
-        "v_mul_f32_e32 v107, v120, v104\n"                      // h = dot(d, oc) = (dx ocx + dy ocy) + dz ocz
-        "v_mul_f32_e32 v108, v121, v105\n"
-        "v_mul_f32_e32 v104, v104, v104\n"                      // dot(oc, oc)
-        "v_mul_f32_e32 v105, v105, v105\n"
-        "v_add_f32_e32 v104, v104, v105\n"
-        "v_mul_f32_e32 v105, v106, v106\n"
-        "v_mul_f32_e32 v109, v122, v106\n"
-        "v_add_f32_e32 v107, v107, v108\n"
-        "v_add_f32_e32 v104, v105, v104\n"
-        "v_add_f32_e32 v107, v109, v107\n"                      // h
-        "v_sub_f32_e32 v104, v104, v103\n"                      // c = dot(oc, oc) - r^2
-        "v_mul_f32_e32 v105, v107, v107\n"                      // h h
-        "v_mul_f32_e32 v104, v123, v104\n"                      // a c
-        "v_sub_f32_e32 v104, v105, v104\n"                      // discriminant
-        "v_cmp_gt_f32_e32 vcc, %[c_tiny], v104\n"               // sqrt, correctly rounded: hipcc's expansion (walk_wave_lds_asm)
-        "v_mul_f32_e32 v105, 0x4f800000, v104\n"
-        "v_add_u32_e32 %[spa], 0xffffff80, %[spa]\n"            // (the pop's pointer move)
-        "v_cndmask_b32_e32 v104, v104, v105, vcc\n"
-        "v_sqrt_f32_e32 v105, v104\n"
-        "v_cmp_class_f32_e64 %[s_both], v104, %[c_cls]\n"
-        "v_add_u32_e32 v106, -1, v105\n"
-        "v_add_u32_e32 v109, 1, v105\n"
-        "v_fma_f32 v108, -v106, v105, v104\n"
-        "v_fma_f32 v110, -v109, v105, v104\n"
-        "v_cmp_ge_f32_e64 %[s_p2], 0, v108\n"
-        "v_cmp_lt_f32_e64 %[s_any], 0, v110\n"
-        "s_nop 0\n"
-        "v_cndmask_b32_e64 v106, v105, v106, %[s_p2]\n"
-        "v_cndmask_b32_e64 v105, v106, v109, %[s_any]\n"
-        "v_mul_f32_e32 v106, 0x37800000, v105\n"
-        "v_cndmask_b32_e32 v105, v105, v106, vcc\n"
-        "v_cndmask_b32_e64 v104, v105, v104, %[s_both]\n"
-        "v_sub_f32_e32 v104, v107, v104\n"                      // h - sqrt(discriminant)
-        "v_div_scale_f32 v105, %[s_p2], v123, v123, v104\n"     // ... / a, correctly rounded: hipcc's expansion
-        "v_rcp_f32_e32 v106, v105\n"
-        "v_div_scale_f32 v107, vcc, v104, v123, v104\n"
-        "v_fma_f32 v109, -v105, v106, 1.0\n"
-        "v_fmac_f32_e32 v106, v109, v106\n"
-        "v_mul_f32_e32 v108, v107, v106\n"
-        "v_fma_f32 v109, -v105, v108, v107\n"
-        "v_fmac_f32_e32 v108, v109, v106\n"
-        "v_fma_f32 v105, -v105, v108, v107\n"
-        "v_div_fmas_f32 v105, v105, v106, v108\n"
-        "v_div_fixup_f32 v104, v105, v123, v104\n"              // t
-        "v_cmp_lt_f32_e32 vcc, %[c_eps], v104\n"                // accepted iff t > 0.001 && t < closest (raytrace.wgsl:353-354)
-        "v_cmp_lt_f32_e64 %[s_p2], v104, %[closest]\n"
-        "s_and_b64 exec, vcc, %[s_p2]\n"
-        "v_mov_b32_e32 %[closest], v104\n"
-        "v_mov_b32_e32 %[cidx], v112\n"
-        "v_add_u32_e32 %[below], -1, v104\n"
-        "s_mov_b64 exec, -1\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "s_branch 3b\n"
-        // ---- the results back to the rays' owners ---------------------------------------------------------------------------------
-        "9:\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "v_lshlrev_b32_e32 v100, 2, %[rank]\n"                  // an owner's ray sits in lane `rank` (and rank + 32)
-        "ds_bpermute_b32 v101, v100, %[cur]\n"
-        "ds_bpermute_b32 v102, v100, %[spa]\n"
-        "ds_bpermute_b32 v103, v100, %[closest]\n"
-        "ds_bpermute_b32 v104, v100, %[cidx]\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "s_mov_b64 exec, %[s_own]\n"
-        "v_mov_b32_e32 %[cur], v101\n"
-        "v_mov_b32_e32 %[spa], v102\n"
-        "v_mov_b32_e32 %[closest], v103\n"
-        "v_mov_b32_e32 %[cidx], v104\n"
-        : [cur] "+v"(cur), [spa] "+v"(spa), [closest] "+v"(closest), [cidx] "+v"(closest_idx), [below] "=&v"(below), [t0] "=&v"(t0),
-          [tx] "=&v"(tx), [ty] "=&v"(ty), [tz] "=&v"(tz), [pop] "=&v"(pop), [cnt] "=&s"(cnt), [nw] "=&s"(nw), [thr] "=&s"(thr),
-          [take] "=&s"(take), [any] "=&s"(any), [both] "=&s"(both), [only_l] "=&s"(only_l), [s_own] "=&s"(s_own), [s_p2] "=&s"(s_p2),
-          [s_any] "=&s"(s_any), [s_both] "=&s"(s_both)
-        : [gofs_x] "v"(gofs_x), [gofs_y] "v"(gofs_y), [gofs_z] "v"(gofs_z), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [ix] "v"(inv.x),
-          [iy] "v"(inv.y), [iz] "v"(inv.z), [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z), [a] "v"(a), [rank] "v"(rank), [sph] "s"(sph),
-          [exit2] "s"(exit2), [vote2] "s"(vote2), [rec_bytes] "s"(rec_bytes), [c_tiny] "s"(c_tiny), [c_eps] "s"(c_eps), [c_cls] "s"(c_cls),
-          [n_walk] "s"(n_walk), [slot_base] "s"(slot_base)
-        : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112",
-          "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126");
-#endif
-}
-
-template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, int MODE, bool PAIR = false, typename StackT>
+template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, int MODE, typename StackT>
 BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, f3 o, f3 d,
                       uint32_t exit_lanes, uint32_t leaf_vote, HitCounters& hc) {
     using DS = Desc<D16>;
@@ -1018,7 +798,7 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, f3
                 walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, true, MODE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp,
                                                                        n, exit_at, vote, hc);
             if constexpr (kByHand)
-                walk_loop_wave_lds<D16, SIMPLE_TREE, PAIR>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp, n, exit_at, vote, hc);
+                walk_loop_wave_lds<D16, SIMPLE_TREE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp, n, exit_at, vote, hc);
             else if (!any_unsafe)
                 walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, false, MODE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp,
                                                                         n, exit_at, vote, hc);

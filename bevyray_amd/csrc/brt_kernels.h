@@ -32,7 +32,6 @@ struct TraceLaunch {
 size_t trace_lds_bytes(const DeviceSceneView& sv, int scene_mode, uint32_t block, uint32_t pool_cap);
 constexpr uint32_t POOL_RECORD_BYTES = 96;   // one path in the drain pool (k_trace_persistent)
 constexpr uint32_t WGQ_BYTES = 64;           // a workgroup's share of the pixel queue: 8 control words + 8 tile ids
-constexpr uint32_t PAIR_SLOT_BYTES = 128;    // per wave (SCENE_LDS): owner lane of each of up to 32 rays of a thin wave (walk_wave_lds_pair_asm)
 hipError_t launch_trace_persistent(const TraceLaunch& tl);
 hipError_t launch_trace_simple(const TraceLaunch& tl);
 hipError_t launch_passthrough(const FrameParams& fp, float* out_tile, const float* raster_rgba, hipStream_t stream);

@@ -48,7 +48,6 @@ __global__ __launch_bounds__(256) void k_trace_simple(DeviceSceneView sv, FrameP
     sc.near_bytes = 0u;
     sc.near_base = 0u;
     sc.sph_base = 0u;
-    sc.pair_slots = 0u;
     sc.boxes_ordered = sv.boxes_ordered != 0u;
     sc.spheres = reinterpret_cast<const float4*>(sv.spheres);
     sc.sphere_material = sv.sphere_material;
@@ -225,7 +224,6 @@ size_t trace_lds_bytes(const DeviceSceneView& sv, int scene_mode, uint32_t block
     bytes += (size_t)(block / 64) * (sv.stack_entries + 2) * 64 * (sv.desc16 ? 2 : 4);   // + 2: DONE sentinel, one spare entry
     bytes = (bytes + 15) & ~(size_t)15;
     bytes += WGQ_BYTES;                                                                  // workgroup share of the pixel queue
-    if (scene_mode == SCENE_LDS) bytes += (size_t)(block / 64) * PAIR_SLOT_BYTES;        // lane-pair slots of thin waves
     if (pool_cap) bytes += 16 + (size_t)pool_cap * POOL_RECORD_BYTES;                    // drain pool: control words + records
     return bytes;
 }

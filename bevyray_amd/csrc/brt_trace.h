@@ -11,9 +11,6 @@
 #include "brt_device.h"
 #include "brt_kernels.h"
 
-#ifndef BRT_PAIR_WALK
-#define BRT_PAIR_WALK 1       // thin waves walk with two lanes per ray (brt_device.h walk_wave_lds_pair_asm); 0: the wide loop always
-#endif
 #ifndef BRT_PHASE_PRIO_AT
 #define BRT_PHASE_PRIO_AT 2   // 0: no phase priorities; 1: raised for the walk; 2: raised from the top of the round (walk begin included)
 #endif
@@ -352,7 +349,6 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     sc.near_bytes = 0u;
     sc.near_base = 0u;
     sc.sph_base = 0u;
-    sc.pair_slots = 0u;
     if (MODE == SCENE_LDS) {
         // carve: pair records | spheres | leaf_table | sphere_material | stacks
         const uint32_t pair_granules = (uint32_t)(pair_array_bytes(sv.n_pairs) / 16);
@@ -408,10 +404,6 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     off = (off + 15u) & ~15u;
     uint32_t* const wgq = reinterpret_cast<uint32_t*>(lds + off);
     off += WGQ_BYTES;
-    if (MODE == SCENE_LDS) {      // 32 slot words per wave: the rays of a thin wave packed into lane pairs (walk_wave_lds_pair_asm)
-        sc.pair_slots = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + off) + wave * PAIR_SLOT_BYTES;
-        off += n_waves * PAIR_SLOT_BYTES;
-    }
     uint32_t* pool_ctl = nullptr;
     float4* pool = nullptr;
     if (fp.pool_cap != 0u) {
@@ -657,9 +649,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         if (fresh) walk_begin<D16>(walk, sc, sv.root_desc, stk, d);
         if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_pre += now - t_mark; t_mark = now; }
         if (kPhasePrio == 1 && !wave_crit) __builtin_amdgcn_s_setprio(1);
-        // (two lanes per ray for waves of at most 32 walkers: every instantiation but LEAN = 2, the steady state of a whole frame, whose
-        //  waves are full -- brt_device.h walk_wave_lds_pair_asm)
-        if (active) walk_run<64, COUNTERS, D16, SIMPLE, MODE, BRT_PAIR_WALK && LEAN != 2>(sc, walk, stk, o, d, finish_walks ? 0u : walk_exit_lanes, leaf_vote, hc);
+        if (active) walk_run<64, COUNTERS, D16, SIMPLE, MODE>(sc, walk, stk, o, d, finish_walks ? 0u : walk_exit_lanes, leaf_vote, hc);
         in_flight = active && walk_pending<D16, SIMPLE>(walk);
         if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_walk += now - t_mark; t_mark = now; }
         const bool landed = active && !in_flight;      // walk finished: shade this segment now
