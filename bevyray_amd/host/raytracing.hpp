@@ -180,6 +180,19 @@ public:
                                 d_destination, hip_stream, flags, stats), ctx_);
         return true;
     }
+    // One process per GPU: this rank's strips into a device tile, then ONE ncclGather of the tiles to rank 0 and the
+    // de-interleave kernel behind it, both inside the library (brt_gather_rccl; `comm` from RaytracePlugin::rccl_comm).
+    bool run_part(const std::optional<std::pair<RaytraceLevelExtract, CameraExtract>>& view, const WindowExtract& window, uint32_t width,
+                  uint32_t height, uint32_t rank, uint32_t world, float* d_tile, brt_stats* stats = nullptr, uint32_t flags = 0) {
+        if (!view) return false;
+        check(brt_render_part_device(ctx_, &view->second, &window, view->first.level, width, height, rank, world, nullptr, nullptr, d_tile,
+                                     nullptr, flags, stats), ctx_);
+        return true;
+    }
+    void gather(void* comm, int32_t rank, int32_t world, const float* d_tile, float* d_tiles_on_root, uint32_t width, uint32_t height,
+                float* d_frame_on_root, void* hip_stream = nullptr, uint32_t flags = 0) {
+        check(brt_gather_rccl(ctx_, comm, rank, world, d_tile, d_tiles_on_root, width, height, d_frame_on_root, hip_stream, flags), ctx_);
+    }
 private:
     brt_ctx* ctx_;
 };
@@ -203,6 +216,26 @@ public:
     // the reading of `||` in raytrace.wgsl:269 (BRT_POLICY_OR_SHORT_CIRCUIT or 0); scheduling knobs (never change a pixel)
     void set_policy(uint32_t flags) { check(brt_set_policy(ctx_, flags), ctx_); }
     void set_tuning(const char* name, uint32_t value) { check(brt_set_tuning(ctx_, name, value), ctx_); }
+    // the colour target's memory, exported by the host's graphics API as a file descriptor (pipeline.rs:191-203 renders straight
+    // into post_process.destination): a device pointer that run_device / gather accept as the frame (brt_import_frame_fd)
+    float* import_frame(int32_t fd, uint64_t bytes, uint32_t handle_type = BRT_EXTMEM_OPAQUE_FD) {
+        float* d = nullptr;
+        check(brt_import_frame_fd(ctx_, fd, bytes, handle_type, &d), ctx_);
+        return d;
+    }
+    void release_frame(float* d_frame) { check(brt_release_frame(ctx_, d_frame), ctx_); }
+    // the communicator of the one-process-per-GPU form: `id` from rccl_unique_id() on rank 0, handed to the others by the host's means
+    static std::array<char, 128> rccl_unique_id() {
+        std::array<char, 128> id{};
+        check(brt_rccl_unique_id(id.data()));
+        return id;
+    }
+    void* rccl_comm(const std::array<char, 128>& id, int32_t rank, int32_t world) {
+        void* comm = nullptr;
+        check(brt_rccl_comm_create(ctx_, id.data(), rank, world, &comm), ctx_);
+        return comm;
+    }
+    void rccl_comm_destroy(void* comm) { check(brt_rccl_comm_destroy(ctx_, comm), ctx_); }
     brt_ctx* context() { return ctx_; }
 private:
     brt_ctx* ctx_ = nullptr;
