@@ -357,6 +357,8 @@ int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hi
         // (slowest share of config 2 in 2 / 4 parts 6.24 / 5.13 ms without, 6.60 / 5.31 with; profiles/r04/parts_dilate.txt).
         const uint64_t wave_slots = (uint64_t)dc.num_cus * (BRT_BLOCK / 64u);
         const uint32_t r0 = (ctx->knobs[K_LPT_DILATE] >= 2u && (uint64_t)n_tiles >= 6u * wave_slots) ? ctx->knobs[K_LPT_DILATE] - 1u : 0u;
+        // (the same radius for the costs of a first frame's pre-pass: radius 0 / 1 / 2 / 3 / 4 / 6 there gave 11.2 / 11.6 / 11.6 / 12.0 /
+        //  12.5 / 13.2 ms for pre-pass + frame, profiles/r04/first_frame_prepass.txt)
         tp.dilate_x = r0;
         tp.dilate_y = r0 ? (r0 + fp.n_parts - 1u) / fp.n_parts : 0u;
         rc = build_order_on_device(ctx, dc, n_tiles, fp.tiles_x, tp.sample_count, tp.dilate_x, tp.dilate_y, stream);
@@ -458,18 +460,21 @@ int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const fl
     return BRT_OK;
 }
 
-// The first frame of a view has no measured dispatch order (raster order: 16.0 instead of 13.3 ms on the headline
-// frame).  A pre-pass of the same view at BRT_PREPASS_SPP samples per pixel (default 2; 0 = off) measures the tile
-// costs first -- pixels are sequential chains of samples, so k samples predict the chain lengths of the full frame
-// -- and the frame itself then runs in that order (and measures again, for the frames that follow).  Enqueued on the
-// context's own stream ahead of the frame (the order is built on the GPU behind it: no host round trip); only on the
-// entry points that own their stream, only when the frame is at least 16x the pre-pass.  The pre-pass renders into the
-// frame's own tile buffer; the frame overwrites every pixel of it afterwards.
+// The first frame of a view has no measured dispatch order (raster order: 12.9 instead of 9.6 ms on the headline
+// frame).  A pre-pass of the same view at a few samples per pixel measures the tile costs first -- pixels are sequential
+// chains of samples, so k samples predict the chain lengths of the full frame -- and the frame itself then runs in that
+// order (and measures again, for the frames that follow).  k = min(BRT_PREPASS_SPP, samples / 16): default 4, 0 = off;
+// measured on the headline frame (pre-pass + frame, ms): none 12.9, k = 1 14.2 (worse than raster order: one sample ranks
+// the wrong tiles first), 2 11.5, 3 11.3, 4 11.0, 5 11.2, 6 11.3, 8 11.7 (profiles/r04/first_frame_prepass.txt) -- so no
+// pre-pass where the rule would leave k = 1.  Enqueued on the context's own stream ahead of the frame (the order is built
+// on the GPU behind it: no host round trip); only on the entry points that own their stream.  The pre-pass renders into
+// the frame's own tile buffer; the frame overwrites every pixel of it afterwards.
 int32_t prepass_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const float* d_raster_rgba,
                       const float* d_raster_depth, float* d_out_tile, hipStream_t stream, uint32_t flags, bool* ran) {
     *ran = false;
-    const uint32_t k = ctx->knobs[K_PREPASS_SPP];
-    if (k == 0u || !lpt_enabled(ctx) || fp.level == 0u || fp.sample_count < 16u * k || (flags & BRT_FLAG_KERNEL_SIMPLE)) return BRT_OK;
+    const uint32_t knob = ctx->knobs[K_PREPASS_SPP];
+    const uint32_t k = knob < fp.sample_count / 16u ? knob : fp.sample_count / 16u;
+    if (k == 0u || (k == 1u && knob != 1u) || !lpt_enabled(ctx) || fp.level == 0u || (flags & BRT_FLAG_KERNEL_SIMPLE)) return BRT_OK;
     uint32_t key[6];
     order_key_of(ctx, fp, key);
     // history matches and the camera has not jumped out of its reach: nothing to do

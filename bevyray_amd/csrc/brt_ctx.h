@@ -91,7 +91,7 @@ constexpr KnobDef kKnobs[K_COUNT] = {
     {"BRT_DRAIN_DONATE", kDrainDonate}, {"BRT_POOL_ADOPT", kPoolAdopt}, {"BRT_WGQ_BATCH", 0}, {"BRT_LPT_LANE_PERMILLE", 0},
     {"BRT_TUNABLE", 0}, {"BRT_FORCE_GLOBAL_SCENE", 0}, {"BRT_FORCE_LDS_TOP", 0}, {"BRT_BLOCK_THREADS", 0}, {"BRT_WG_PER_CU", 0},
     {"BRT_POOL_CAP", 384}, {"BRT_LPT", 1}, {"BRT_LPT_SORT", 1}, {"BRT_LPT_SKY_SLACK", 20}, {"BRT_CRIT", 1}, {"BRT_ORDER_ON_HOST", 0},
-    {"BRT_NO_LEAN", 0}, {"BRT_PREPASS_SPP", 2}, {"BRT_NO_DIRTY_TRACKING", 0}, {"BRT_CPU_BVH", 0},
+    {"BRT_NO_LEAN", 0}, {"BRT_PREPASS_SPP", 4}, {"BRT_NO_DIRTY_TRACKING", 0}, {"BRT_CPU_BVH", 0},
     {"BRT_PLOC_ONE_BLOCK_MAX", kPlocOneBlockMax}, {"BRT_BVH_QUALITY", 1}, {"BRT_POOL_FORCE", 0}, {"BRT_LPT_REFRESH_EVERY", 0}, {"BRT_LEAN_MEASURE", 1}, {"BRT_LPT_DILATE", 3}};
 struct Knobs {
     uint32_t v[K_COUNT];

@@ -1163,7 +1163,7 @@ def _short_circuit_policy_case(plugin, oracle, monkeypatch):
 
 
 def test_first_frame_prepass_orders_tiles_without_changing_pixels(oracle, monkeypatch):
-    """The first frame of a view runs a 2-spp dispatch-order pre-pass into the frame's own tile buffer and then
+    """The first frame of a view runs a dispatch-order pre-pass of min(4, samples / 16) samples per pixel into the frame's own tile buffer and then
     the frame itself: same pixels and counters as the oracle, prepass_ms reported; BRT_PREPASS_SPP=0 turns it
     off; the second frame of the view needs none."""
     b = brt.generate_scene(brt.SCENE_COVER, 1)
@@ -1191,17 +1191,18 @@ def test_first_frame_prepass_orders_tiles_without_changing_pixels(oracle, monkey
         assert p.node.last_stats["prepass_ms"] > 0.0
     monkeypatch.setenv("BRT_ENABLE_TUNING", "1")
     with brt.RaytracePlugin([0]) as p:
-        assert p.get_tuning("BRT_PREPASS_SPP") == (0, 2)
+        assert p.get_tuning("BRT_PREPASS_SPP") == (0, 4)
         monkeypatch.setenv("BRT_PREPASS_SPP", "2")          # after brt_create: ignored
         p.node.run(lvl, cam, win, w, h, buffers=b)
         assert p.node.last_stats["prepass_ms"] == 0.0
     monkeypatch.delenv("BRT_ENABLE_TUNING")
     monkeypatch.delenv("BRT_PREPASS_SPP")
-    # frames of fewer than 16x the pre-pass samples run without one
-    lvl, cam, win = brt.cover_camera(w, h, 8, 8)
-    with brt.RaytracePlugin([0]) as p:
-        p.node.run(lvl, cam, win, w, h, buffers=b)
-        assert p.node.last_stats["prepass_ms"] == 0.0
+    # frames of fewer than 32 samples (the rule would leave a pre-pass of 0 or 1) run without one
+    for spp in (8, 24):
+        lvl, cam, win = brt.cover_camera(w, h, spp, 8)
+        with brt.RaytracePlugin([0]) as p:
+            p.node.run(lvl, cam, win, w, h, buffers=b)
+            assert p.node.last_stats["prepass_ms"] == 0.0
 
 
 # ---- the shared-reciprocal division (brt_device.h) against the compiler's correctly rounded `/` ---------------------
