@@ -183,20 +183,22 @@ BRT_DEV f3 rng_unit_ball(uint32_t& state) {
 
 // The rejection sampler of a ROUND by hand (random.wgsl:19-24 + raytrace.wgsl:238 / :285), for the lanes active at the call:
 // lanes of m2 need two balls (diffuse: acc = normal + ball, then + roughness * ball), lanes of m1 one (metal: acc = -0 + roughness * ball).
-// Every iteration draws a candidate p for each lane that still needs one and, where |p|^2 <= 1, does acc += scale * p.  What the
-// compiler's version (shade_landed, COUNTERS builds) spends per iteration beside the three draws -- four v_cndmask, a counter
-// with borrow, a compare on it -- is here: the 6 instructions of acc += scale * p under EXEC = accepted lanes, one v_mov for the
-// lanes that go from two needed to one, and the bookkeeping of who needs how many as two scalar masks (the scalar unit runs beside
-// the vector pipe: tests/tools/issue_bench.hip).  43 vector instructions per iteration instead of 50, none of them a 4-cycle select.
-// Per lane: the same draws and the same mul / add, in the same order.
+// Every iteration draws a candidate p for each lane that still needs one; the loop itself only KEEPS the accepted points: a lane that is
+// done drops out of EXEC, so its last candidate -- the accepted one -- stays in x, y, z, and the first point of a lane that needs two is
+// moved aside (three v_mov under EXEC = "two needed -> one").  The sums are made once behind the loop: acc += p1 (the shader's 1.0 * p1
+// is p1), acc += roughness * p.  What the compiler's version (shade_landed, COUNTERS builds) spends per iteration beside the three
+// draws -- four v_cndmask, a counter with borrow, a compare on it, acc + scale * p -- is here those three moves and the bookkeeping of
+// who needs how many as two scalar masks (the scalar unit runs beside the vector pipe: tests/tools/issue_bench.hip): 39 vector
+// instructions per iteration instead of 50 (43 with the sums inside the loop: a round runs ~8 iterations, the sums are 9 instructions),
+// none of them a 4-cycle select.  Per lane: the same draws and the same mul / add, in the same order.
 #ifndef BRT_BALL_ASM
 #define BRT_BALL_ASM BRT_HAND_ASM
 #endif
-BRT_DEV void ball_loop_asm(uint32_t& rng, f3& acc, float scale, float rough, uint64_t m2, uint64_t m1) {
+BRT_DEV void ball_loop_asm(uint32_t& rng, f3& acc, float rough, uint64_t m2, uint64_t m1) {
 #if BRT_HAND_ASM
     uint32_t t;
-    float x, y, z, q, r;
-    uint64_t s_all, s_up;
+    float x, y, z, x1, y1, z1, q, r;
+    uint64_t s_all, s_up, s_two, s_part;
     const uint32_t c_mul = 277803737u, c_2m31 = 0x30000000u /* 2^-31 */;
 #define BRT_RNG_DRAW(dst)                                                                                                   \
     "v_add_u32_e32 %[rng], 0xd8e8c2ba, %[rng]\n"          /* random.wgsl:9: state + 747796405 + 2891336453 */             \
@@ -209,41 +211,53 @@ BRT_DEV void ball_loop_asm(uint32_t& rng, f3& acc, float scale, float rough, uin
     "v_xor_b32_e32 %[rng], %[t], %[rng]\n"                                                                                  \
     "v_cvt_f32_u32_e32 " dst ", %[rng]\n"                                                                                  \
     "v_fma_f32 " dst ", " dst ", %[c_2m31], -1.0\n"       /* rng_ball_coord: 2 * (state * 2^-32) - 1, rounded once */
+#define BRT_BALL_ITERATION                                                                                                  \
+        BRT_RNG_DRAW("%[x]")                                                                                                \
+        BRT_RNG_DRAW("%[y]")                                                                                                \
+        BRT_RNG_DRAW("%[z]")                                                                                                \
+        "v_mul_f32_e32 %[q], %[x], %[x]\n"                  /* dot3(p, p) = (x*x + y*y) + z*z */                           \
+        "v_mul_f32_e32 %[r], %[y], %[y]\n"                                                                                  \
+        "v_add_f32_e32 %[q], %[q], %[r]\n"                                                                                  \
+        "v_mul_f32_e32 %[r], %[z], %[z]\n"                                                                                  \
+        "v_add_f32_e32 %[q], %[q], %[r]\n"                                                                                  \
+        "v_cmp_ge_f32_e32 vcc, 1.0, %[q]\n"                 /* accepted (inactive lanes: 0) */                             \
+        "s_and_b64 %[s_up], %[m2], vcc\n"                   /* two needed -> one */                                        \
+        "s_andn2_b64 %[m1], %[m1], vcc\n"                   /* one needed -> none */                                       \
+        "s_andn2_b64 %[m2], %[m2], vcc\n"                                                                                   \
+        "s_or_b64 %[m1], %[m1], %[s_up]\n"                                                                                  \
+        "s_mov_b64 exec, %[s_up]\n"                                                                                         \
+        "v_mov_b32_e32 %[x1], %[x]\n"                       /* the first of two points */                                  \
+        "v_mov_b32_e32 %[y1], %[y]\n"                                                                                       \
+        "v_mov_b32_e32 %[z1], %[z]\n"                                                                                       \
+        "s_or_b64 exec, %[m2], %[m1]\n"                     /* SCC: somebody still needs one */
     asm volatile(
         "s_mov_b64 %[s_all], exec\n"
-        "s_or_b64 exec, %[m2], %[m1]\n"
+        "s_mov_b64 %[s_two], %[m2]\n"
+        "s_or_b64 %[s_part], %[m2], %[m1]\n"
+        "s_mov_b64 exec, %[s_part]\n"
         "s_cbranch_execz 2f\n"
         "1:\n"
-        BRT_RNG_DRAW("%[x]")
-        BRT_RNG_DRAW("%[y]")
-        BRT_RNG_DRAW("%[z]")
-        "v_mul_f32_e32 %[q], %[x], %[x]\n"                  // dot3(p, p) = (x*x + y*y) + z*z
-        "v_mul_f32_e32 %[r], %[y], %[y]\n"
-        "v_add_f32_e32 %[q], %[q], %[r]\n"
-        "v_mul_f32_e32 %[r], %[z], %[z]\n"
-        "v_add_f32_e32 %[q], %[q], %[r]\n"
-        "v_cmp_ge_f32_e32 vcc, 1.0, %[q]\n"                 // accepted (inactive lanes: 0)
-        "s_and_b64 %[s_up], %[m2], vcc\n"                   // two needed -> one
-        "s_andn2_b64 %[m1], %[m1], vcc\n"                   // one needed -> none
-        "s_andn2_b64 %[m2], %[m2], vcc\n"
-        "s_or_b64 %[m1], %[m1], %[s_up]\n"
-        "s_mov_b64 exec, vcc\n"
-        "v_mul_f32_e32 %[x], %[scale], %[x]\n"              // acc = acc + scale * p
-        "v_mul_f32_e32 %[y], %[scale], %[y]\n"
-        "v_mul_f32_e32 %[z], %[scale], %[z]\n"
+        BRT_BALL_ITERATION
+        "s_cbranch_scc1 1b\n"                               // (two iterations per trip with a fall-through exit between them: measured, no gain)
+        "s_mov_b64 exec, %[s_two]\n"                        // diffuse: acc = normal + 1.0 * p1 ...
+        "v_add_f32_e32 %[ax], %[ax], %[x1]\n"
+        "v_add_f32_e32 %[ay], %[ay], %[y1]\n"
+        "v_add_f32_e32 %[az], %[az], %[z1]\n"
+        "s_mov_b64 exec, %[s_part]\n"                       // ... + roughness * p2; metal: -0 + roughness * p
+        "v_mul_f32_e32 %[x], %[rough], %[x]\n"
+        "v_mul_f32_e32 %[y], %[rough], %[y]\n"
+        "v_mul_f32_e32 %[z], %[rough], %[z]\n"
         "v_add_f32_e32 %[ax], %[ax], %[x]\n"
         "v_add_f32_e32 %[ay], %[ay], %[y]\n"
         "v_add_f32_e32 %[az], %[az], %[z]\n"
-        "s_mov_b64 exec, %[s_up]\n"
-        "v_mov_b32_e32 %[scale], %[rough]\n"                // the second ball is scaled by the roughness
-        "s_or_b64 exec, %[m2], %[m1]\n"                     // SCC: somebody still needs one
-        "s_cbranch_scc1 1b\n"
         "2:\n"
         "s_mov_b64 exec, %[s_all]\n"
-        : [rng] "+v"(rng), [ax] "+v"(acc.x), [ay] "+v"(acc.y), [az] "+v"(acc.z), [scale] "+v"(scale), [m2] "+s"(m2), [m1] "+s"(m1),
-          [t] "=&v"(t), [x] "=&v"(x), [y] "=&v"(y), [z] "=&v"(z), [q] "=&v"(q), [r] "=&v"(r), [s_all] "=&s"(s_all), [s_up] "=&s"(s_up)
+        : [rng] "+v"(rng), [ax] "+v"(acc.x), [ay] "+v"(acc.y), [az] "+v"(acc.z), [m2] "+s"(m2), [m1] "+s"(m1),
+          [t] "=&v"(t), [x] "=&v"(x), [y] "=&v"(y), [z] "=&v"(z), [x1] "=&v"(x1), [y1] "=&v"(y1), [z1] "=&v"(z1), [q] "=&v"(q), [r] "=&v"(r),
+          [s_all] "=&s"(s_all), [s_up] "=&s"(s_up), [s_two] "=&s"(s_two), [s_part] "=&s"(s_part)
         : [rough] "v"(rough), [c_mul] "s"(c_mul), [c_2m31] "s"(c_2m31)
         : "vcc", "scc", "memory");
+#undef BRT_BALL_ITERATION
 #undef BRT_RNG_DRAW
 #endif
 }

@@ -207,7 +207,7 @@ BRT_DEV void shade_landed(const ScenePtrs& sc, const FrameParams& fp, bool lande
         unsigned long long t_ball = 0;
         if (COUNTERS) t_ball = wall_clock64();
         if (BRT_BALL_ASM && !COUNTERS) {
-            ball_loop_asm(ps.rng, acc, scale, m1.x, __builtin_amdgcn_ballot_w64(diffuse), __builtin_amdgcn_ballot_w64(metal));
+            ball_loop_asm(ps.rng, acc, m1.x, __builtin_amdgcn_ballot_w64(diffuse), __builtin_amdgcn_ballot_w64(metal));
             need = 0u;
         }
         while (need != 0u) {                                                      // random.wgsl:19-24
