@@ -700,6 +700,11 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             if (te) { atomicMax(&counters[25], ~te); atomicMax(&counters[26], te); atomicAdd(&counters[28], t_end - te); }
             atomicMax(&counters[27], t_end);
             atomicAdd(&counters[29], 1ull);
+            atomicAdd(&counters[45], t_end - t_start);                       // wave lifetimes (their mean against the kernel's span: the tail)
+            {   // histogram of the lifetimes: bins of 2^15 ticks (0.33 ms), four 16-bit counts to a word, words 46..61
+                const unsigned long long bin = (t_end - t_start) >> 15;
+                if (bin < 64ull) atomicAdd(&counters[46 + (bin >> 2)], 1ull << (16 * (bin & 3ull)));
+            }
             atomicAdd(&counters[30], drain_lane_rounds & 0xffffffffull);   // live lanes summed over the rounds after "empty"
             atomicAdd(&counters[31], drain_lane_rounds >> 32);              // those rounds
             atomicAdd(&counters[5], ticks_refill);    // wave time in: the pixel refill loop (queue atomic, tile order, pixel_begin)

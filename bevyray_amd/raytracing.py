@@ -404,6 +404,8 @@ class RaytracePlugin:
                 "last_empty_ms": (int(raw[26]) - t0) / 1e5 if raw[26] else None,
                 "end_ms": (int(raw[27]) - t0) / 1e5,
                 "mean_wave_drain_ms": int(raw[28]) / 1e5 / int(raw[29]),
+                "mean_wave_life_ms": int(raw[45]) / 1e5 / int(raw[29]),       # against end_ms: what the tail of the launch leaves idle
+                "wave_life_hist_0.33ms": [(int(raw[46 + (b >> 2)]) >> (16 * (b & 3))) & 0xffff for b in range(64)],
                 "drain_rounds": int(raw[31]),
                 "drain_live_lanes_per_round": int(raw[30]) / max(1, int(raw[31])),
                 # mean per wave, ms: pixel refill | walk loop | shading (of which the rejection-sampler loop) | drain
