@@ -85,7 +85,7 @@ _PROTOTYPES = {
     "brt_debug_copy_to_host": (_I32, [_VP, _VP, _VP, C.c_uint64]),
     "brt_debug_eval": (_I32, [_VP, _U32, _VP, _VP, _U32]),
     "brt_debug_profile": (_I32, [_VP, C.POINTER(C.c_uint64)]),
-    "brt_debug_tile_order": (_I32, [_VP, _VP, _VP, _U32, _U32, C.c_uint64, _U32, _U32, _VP, _VP]),
+    "brt_debug_tile_order": (_I32, [_VP, _VP, _VP, _U32, _U32, C.c_uint64, _U32, _U32, _U32, _VP, _VP]),
     "brt_build_bvh": (_I32, [_VP, _U32, _VP, _U32, C.POINTER(_U32)]),
     "brt_build_bvh_sah": (_I32, [_VP, _U32, _VP, _U32, C.POINTER(_U32)]),
     "brt_build_bvh_device": (_I32, [_VP, _VP, _U32, _VP, _U32, C.POINTER(_U32), C.POINTER(C.c_double)]),
@@ -95,7 +95,7 @@ _PROTOTYPES = {
     "brt_host_camera_extract": (_I32, [C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _F, _F, _F, _F, _U32, _U32, _VP]),
     "brt_host_window_extract": (_I32, [_F, _U32, _VP]),
     "brt_host_material": (_I32, [C.POINTER(_F), _F, _F, _F, _F, _F, _VP]),
-    "brt_host_tile_order": (_I32, [_VP, _VP, _U32, _U32, C.c_uint64, _U32, _U32, _U32, _U32, _VP, _VP]),
+    "brt_host_tile_order": (_I32, [_VP, _VP, _U32, _U32, C.c_uint64, _U32, _U32, _U32, _U32, _U32, _VP, _VP]),
 }
 EXPORTS = tuple(_PROTOTYPES)
 

@@ -89,6 +89,9 @@ int32_t make_frame_params(brt_ctx* ctx, const void* camera80, const void* window
     fp.pool_adopt = ctx->knobs[K_POOL_ADOPT];
     if (fp.pool_adopt > 63u) fp.pool_adopt = 63u;
     fp.crit_begin = fp.crit_end = 0;   // set by attach_tile_order
+    fp.split_nonsky = fp.split_tiles = 0;
+    fp.slice_state = nullptr;
+    fp.slice_serial = 0;
     fp.wgq_batch = ctx->knobs[K_WGQ_BATCH] & ~63u;
     if (fp.wgq_batch > 512u) fp.wgq_batch = 512u;
     fp.policy_flags = ctx->policy_flags & BRT_POLICY_OR_SHORT_CIRCUIT;
@@ -274,15 +277,32 @@ bool camera_jumped(const brt_ctx* ctx, const DeviceCtx& dc, const FrameParams& f
     return dc.costs_valid && camera_hash(fp) != dc.order_cam && dilation_tiles(ctx, dc, fp) > kMaxDilate;
 }
 
+// Tiles at the end of the order that are handed out as two half-sample jobs (brt_host.cpp build_tile_order): BRT_SPLIT_TAIL quarters of
+// the wave slots.  Default 16, the last four tiles per wave slot: the second halves must come up late enough behind the first ones to
+// find their states (headline frame, 0 / 4 / 8 / 12 / 16 / 24: 9.49 / 9.53 / 9.40 / 9.33 / 9.21 / 9.28 ms; with 8, 1 % of the second
+// halves come too early, leave the pixel to its first-half lane, and those lanes are the new stragglers;
+// profiles/r04/split_tail.txt).  Only for launches of at least 6 tiles per wave slot, like the neighbourhood ranking: a rank's share
+// of a frame split 2 or 4 ways has nothing to balance at its end.
+uint32_t split_tail_of(const brt_ctx* ctx, const DeviceCtx& dc, uint32_t n_tiles) {
+    const uint64_t wave_slots = (uint64_t)dc.num_cus * (BRT_BLOCK / 64u);
+    if (ctx->knobs[K_SPLIT_FORCE] != 0u) return ctx->knobs[K_SPLIT_FORCE] < n_tiles ? ctx->knobs[K_SPLIT_FORCE] : n_tiles;   // (tests: that many tiles, whatever the frame)
+    if ((uint64_t)n_tiles < 6u * wave_slots) return 0u;
+    const uint64_t r = (uint64_t)ctx->knobs[K_SPLIT_TAIL] * wave_slots / 4u;
+    return (uint32_t)(r < n_tiles ? r : n_tiles);
+}
+
 // the order of brt_order.hip from the costs in d_tile_cost (measured at `spp` samples per pixel), on `stream`
 int32_t build_order_on_device(brt_ctx* ctx, DeviceCtx& dc, uint32_t n_tiles, uint32_t tiles_x, uint32_t spp, uint32_t rx, uint32_t ry,
                               hipStream_t stream) {
     if (!dc.d_order_meta) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dc.d_order_meta), 256));
     int32_t rc = ensure(ctx, &dc.d_order_scratch, &dc.order_scratch_cap, order_scratch_bytes(n_tiles));
     if (rc != BRT_OK) return rc;
+    const uint32_t split_tail = split_tail_of(ctx, dc, n_tiles);
+    rc = ensure(ctx, &dc.d_tile_order, &dc.tile_order_cap, ((size_t)n_tiles + split_tail) * 4);
+    if (rc != BRT_OK) return rc;
     const uint64_t sky_cost = (uint64_t)64 * spp * (1000 + ctx->knobs[K_LPT_SKY_SLACK]) / 1000;   // as build_tile_order
     HIP_TRY(ctx, launch_build_order(dc.d_tile_cost, dc.d_tile_cost + n_tiles, n_tiles, sky_cost, (uint64_t)dc.num_cus * BRT_BLOCK, tiles_x, rx,
-                                    ry, dc.d_tile_order, dc.d_order_meta, dc.d_order_scratch, stream));
+                                    ry, split_tail, dc.d_tile_order, dc.d_order_meta, dc.d_order_scratch, stream));
     HIP_TRY(ctx, hipEventRecord(dc.ev_last, stream));   // a later launch on another stream starts behind the order build
     return BRT_OK;
 }
@@ -316,6 +336,21 @@ int32_t attach_tile_order(brt_ctx* ctx, DeviceCtx& dc, FrameParams& fp, hipStrea
         fp.crit_begin = 0u;
         fp.crit_end = dc.order_crit * 64u;
         fp.order_meta = dc.order_on_device ? dc.d_order_meta : nullptr;   // then the kernel reads the critical count there
+        // half-sample jobs at the end of the order: where they are (a GPU-built order says so in d_order_meta) and where the pixel
+        // states wait between a tile's two jobs
+        if (split_tail_of(ctx, dc, n_tiles) != 0u) {
+            const size_t bytes = (size_t)fp.local_strips * BRT_STRIP_ROWS * fp.width * 32u;
+            const bool fresh = bytes > dc.slice_state_cap;
+            int32_t rc = ensure(ctx, &dc.d_slice_state, &dc.slice_state_cap, bytes);
+            if (rc != BRT_OK) return rc;
+            if (fresh || dc.slice_serial == 0xffffffffu) {      // stamps of a new buffer (or after 2^32 launches) must not look valid
+                HIP_TRY(ctx, hipMemsetAsync(dc.d_slice_state, 0, dc.slice_state_cap, stream));
+                dc.slice_serial = 0u;
+            }
+            fp.slice_state = dc.d_slice_state;
+            fp.slice_serial = ++dc.slice_serial;
+            if (!dc.order_on_device) { fp.split_nonsky = dc.order_nonsky; fp.split_tiles = dc.order_split; }
+        }
     }
     bool due = !match || camera_hash(fp) != dc.order_cam || ctx->knobs[K_LPT_REFRESH_EVERY] == 1u;
     if (may_measure && match && dc.remeasure_in != 0u && --dc.remeasure_in == 0u) due = true;
@@ -342,7 +377,8 @@ int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hi
     tp.lane_permille = ctx->knobs[K_LPT_LANE_PERMILLE];
     tp.critical = ctx->knobs[K_CRIT];
     tp.tiles_x = fp.tiles_x;
-    int32_t rc = ensure(ctx, &dc.d_tile_order, &dc.tile_order_cap, (size_t)n_tiles * 4);
+    tp.split_tail = split_tail_of(ctx, dc, n_tiles);
+    int32_t rc = ensure(ctx, &dc.d_tile_order, &dc.tile_order_cap, ((size_t)n_tiles + tp.split_tail) * 4);
     if (rc != BRT_OK) return rc;
     const bool on_device = tp.sorted == 1u && tp.critical == 1u && tp.lane_permille == 0u && ctx->knobs[K_ORDER_ON_HOST] == 0u;
     dc.costs_valid = false;
@@ -379,7 +415,9 @@ int32_t update_tile_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, hi
         dc.order_lane = to.n_lane;
         dc.order_crit = to.n_critical;
         dc.order_on_device = false;
-        HIP_TRY(ctx, hipMemcpyAsync(dc.d_tile_order, dc.h_order.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, stream));
+        dc.order_nonsky = to.n_nonsky;
+        dc.order_split = to.n_split;
+        HIP_TRY(ctx, hipMemcpyAsync(dc.d_tile_order, dc.h_order.data(), dc.h_order.size() * 4, hipMemcpyHostToDevice, stream));
         HIP_TRY(ctx, hipStreamSynchronize(stream));   // h_order may be reused by the next call
     }
     order_key_of(ctx, fp, dc.order_key);
@@ -553,6 +591,7 @@ void free_device(DeviceCtx& dc) {
     if (dc.d_tile_order) (void)hipFree(dc.d_tile_order);
     if (dc.d_order_meta) (void)hipFree(dc.d_order_meta);
     if (dc.d_order_scratch) (void)hipFree(dc.d_order_scratch);
+    if (dc.d_slice_state) (void)hipFree(dc.d_slice_state);
     if (dc.d_bvh_models) (void)hipFree(dc.d_bvh_models);
     if (dc.ev0) (void)hipEventDestroy(dc.ev0);
     if (dc.ev1) (void)hipEventDestroy(dc.ev1);
@@ -1266,21 +1305,23 @@ int32_t brt_debug_profile(brt_ctx* ctx, uint64_t* out64) {
     HIP_TRY(ctx, hipMemcpy(out64, dc.d_ctrl, 512, hipMemcpyDeviceToHost));
     // [40], [41]: critical tiles and longest pixel (rays) of the view's last MEASURED frame, when the order was built on the GPU
     out64[40] = out64[41] = 0;
+    out64[42] = (dc.order_valid && !dc.order_on_device) ? dc.order_split : 0u;      // [42]: tiles handed out as two half-sample jobs
     if (dc.order_valid && dc.order_on_device && dc.d_order_meta) {
-        uint32_t meta[2] = {0u, 0u};
+        uint32_t meta[4] = {0u, 0u, 0u, 0u};
         HIP_TRY(ctx, hipStreamSynchronize(dc.stream));
         HIP_TRY(ctx, hipMemcpy(meta, dc.d_order_meta, sizeof meta, hipMemcpyDeviceToHost));
         out64[40] = meta[0];
         out64[41] = meta[1];
+        out64[42] = meta[3];
     }
     return BRT_OK;
 }
 
 int32_t brt_debug_tile_order(brt_ctx* ctx, const uint32_t* ray_sum, const uint32_t* longest_pixel, uint32_t n_tiles,
-                             uint32_t sample_count, uint64_t grid_lanes, uint32_t tiles_x, uint32_t dilate, uint32_t* out_order,
-                             uint32_t* out_info2) {
+                             uint32_t sample_count, uint64_t grid_lanes, uint32_t tiles_x, uint32_t dilate, uint32_t split_tail,
+                             uint32_t* out_order, uint32_t* out_info4) {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
-    if (!ray_sum || !longest_pixel || !out_order || !out_info2 || n_tiles == 0) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "null buffer / no tiles");
+    if (!ray_sum || !longest_pixel || !out_order || !out_info4 || n_tiles == 0) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "null buffer / no tiles");
     if (dilate != 0u && (tiles_x == 0u || n_tiles % tiles_x != 0u)) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "dilate needs a tiles_x that divides n_tiles");
     DeviceCtx& dc = ctx->devs[0];
     HIP_TRY(ctx, hipSetDevice(dc.device));
@@ -1290,16 +1331,16 @@ int32_t brt_debug_tile_order(brt_ctx* ctx, const uint32_t* ray_sum, const uint32
     char* d_scratch = nullptr;
     auto body = [&]() -> int32_t {
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_cost), (size_t)n_tiles * 8));
-        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_order), (size_t)n_tiles * 4));
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_order), ((size_t)n_tiles + split_tail) * 4));
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_meta), 256));
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_scratch), order_scratch_bytes(n_tiles)));
         HIP_TRY(ctx, hipMemcpyAsync(d_cost, ray_sum, (size_t)n_tiles * 4, hipMemcpyHostToDevice, dc.stream));
         HIP_TRY(ctx, hipMemcpyAsync(d_cost + n_tiles, longest_pixel, (size_t)n_tiles * 4, hipMemcpyHostToDevice, dc.stream));
         const uint64_t sky_cost = (uint64_t)64 * sample_count * (1000 + 20) / 1000;
-        HIP_TRY(ctx, launch_build_order(d_cost, d_cost + n_tiles, n_tiles, sky_cost, grid_lanes, tiles_x, dilate, dilate, d_order, d_meta, d_scratch, dc.stream));
-        HIP_TRY(ctx, hipMemcpyAsync(out_order, d_order, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, dc.stream));
-        HIP_TRY(ctx, hipMemcpyAsync(out_info2, d_meta, 8, hipMemcpyDeviceToHost, dc.stream));
+        HIP_TRY(ctx, launch_build_order(d_cost, d_cost + n_tiles, n_tiles, sky_cost, grid_lanes, tiles_x, dilate, dilate, split_tail, d_order, d_meta, d_scratch, dc.stream));
+        HIP_TRY(ctx, hipMemcpyAsync(out_info4, d_meta, 16, hipMemcpyDeviceToHost, dc.stream));
         HIP_TRY(ctx, hipStreamSynchronize(dc.stream));
+        HIP_TRY(ctx, hipMemcpy(out_order, d_order, ((size_t)n_tiles + out_info4[3]) * 4, hipMemcpyDeviceToHost));
         return BRT_OK;
     };
     const int32_t rc = body();

@@ -509,6 +509,13 @@ float tan_half_fov(float fov) { return (float)std::tan((double)(fov * 0.5f)); }
 // (sum of rays / lanes of the grid) bounds the frame time by itself -- RTIOW at 256 spp and 50 bounces has
 // pixels of > 10 000 sequential rays in a frame of ~5 000 rays per lane.  Tiles holding such a pixel (and at
 // least half the frame's longest pixel) are flagged; in the sorted order they are its front.
+// HALF-SAMPLE JOBS (split_tail): a launch ends in a tail -- when the queue runs dry most waves are in sky tiles (0.2 ms) and end
+// together, the others are in their last non-sky tile (a pixel chain of >= ~130 rays: 1-2 ms) and end that much later: 6 % of the
+// wave time on the headline frame.  The sky tiles at the end can only absorb a stagger of twice their own volume.
+// So the LAST split_tail non-sky tiles are handed out twice: once for the first half of the samples (the lane leaves its pixel's
+// state -- rng, sums, ray count -- in HBM), once, behind all the first halves, for the second half.  The jobs ahead of the sky tiles
+// are then half as long, their stagger is what the sky tiles can absorb.  order = [non-sky, longest first ... | first halves |
+// second halves | sky]; the order has n_tiles + n_split entries.
 // ---------------------------------------------------------------------------------------
 void build_tile_order(const uint32_t* ray_sum, const uint32_t* longest, uint32_t n_tiles, const TileOrderParams& p, TileOrder* out) {
     TileOrder& o = *out;
@@ -546,7 +553,11 @@ void build_tile_order(const uint32_t* ray_sum, const uint32_t* longest, uint32_t
     }
     if (p.sorted) std::sort(keys.begin(), keys.end());                         // longest first, then by index
     uint32_t k = 0;
+    o.n_nonsky = (uint32_t)keys.size();
+    o.n_split = p.sorted ? (uint32_t)std::min<size_t>(p.split_tail, keys.size()) : 0u;
+    o.order.resize((size_t)n_tiles + o.n_split);
     for (uint64_t key : keys) o.order[k++] = (uint32_t)(key & 0xffffffffu);
+    for (uint32_t i = 0; i < o.n_split; i++) o.order[k++] = (uint32_t)(keys[keys.size() - o.n_split + i] & 0xffffffffu);
     for (uint32_t tile = 0; tile < n_tiles; tile++)                            // sky tiles: raster order
         if (is_sky[tile]) o.order[k++] = tile;
     o.n_lane = (uint32_t)((uint64_t)keys.size() * p.lane_permille / 1000u);
@@ -667,16 +678,18 @@ int32_t brt_host_material(const float* base_color_srgb3, float metallic, float p
 
 int32_t brt_host_tile_order(const uint32_t* ray_sum, const uint32_t* longest_pixel, uint32_t n_tiles, uint32_t sample_count,
                             uint64_t grid_lanes, uint32_t sorted, uint32_t lane_permille, uint32_t tiles_x, uint32_t dilate,
-                            uint32_t* out_order, uint32_t* out_info3) {
-    if (!ray_sum || !longest_pixel || !out_order || !out_info3) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
+                            uint32_t split_tail, uint32_t* out_order, uint32_t* out_info5) {
+    if (!ray_sum || !longest_pixel || !out_order || !out_info5) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
     if (dilate != 0u && (tiles_x == 0u || n_tiles % tiles_x != 0u)) return fail(BRT_ERR_INVALID_ARGUMENT, "dilate needs a tiles_x that divides n_tiles");
     TileOrderParams tp{};
     tp.sample_count = sample_count; tp.grid_lanes = grid_lanes; tp.sorted = sorted; tp.sky_slack_permille = 20;
     tp.lane_permille = lane_permille; tp.critical = 1; tp.tiles_x = tiles_x; tp.dilate_x = tp.dilate_y = dilate;
+    tp.split_tail = split_tail;
     TileOrder to;
     build_tile_order(ray_sum, longest_pixel, n_tiles, tp, &to);
-    std::memcpy(out_order, to.order.data(), (size_t)n_tiles * 4);
-    out_info3[0] = to.n_lane; out_info3[1] = to.n_critical; out_info3[2] = to.longest_pixel;
+    std::memcpy(out_order, to.order.data(), to.order.size() * 4);
+    out_info5[0] = to.n_lane; out_info5[1] = to.n_critical; out_info5[2] = to.longest_pixel;
+    out_info5[3] = to.n_nonsky; out_info5[4] = to.n_split;
     return BRT_OK;
 }
 

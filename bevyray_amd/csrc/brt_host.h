@@ -46,12 +46,16 @@ struct TileOrderParams {
     // a tile is ranked by the longest pixel of its (2 dilate_x + 1) x (2 dilate_y + 1) neighbourhood in the tiles_x-wide tile grid and
     // is "sky" only if that whole neighbourhood was (0, 0: by itself); brt_order.hip has the why
     uint32_t tiles_x = 0, dilate_x = 0, dilate_y = 0;
+    // the last min(split_tail, non-sky tiles) non-sky tiles are in the order TWICE, as two half-sample jobs (see build_tile_order)
+    uint32_t split_tail = 0;
 };
 struct TileOrder {
     std::vector<uint32_t> order; // order[k] = k-th tile to hand out
     uint32_t n_lane = 0;         // order[0 .. n_lane) is the lane queue, the rest the tile queue
     uint32_t n_critical = 0;     // order[0 .. n_critical) are the critical tiles
     uint32_t longest_pixel = 0;
+    uint32_t n_nonsky = 0;       // order[0 .. n_nonsky) are the tiles that are not sky (before the second halves are inserted)
+    uint32_t n_split = 0;        // order[n_nonsky - n_split .. n_nonsky) = first halves, order[n_nonsky .. n_nonsky + n_split) = the same tiles, second halves
 };
 void build_tile_order(const uint32_t* ray_sum, const uint32_t* longest, uint32_t n_tiles, const TileOrderParams& p, TileOrder* out);
 

@@ -39,12 +39,14 @@ hipError_t launch_deinterleave(const float* tiles, float* frame, uint32_t width,
                                uint32_t tile_rows, hipStream_t stream);
 hipError_t launch_debug_eval(uint32_t op, const float* in, float* out, uint32_t n, hipStream_t stream);
 
-// Dispatch order on the GPU (brt_order.hip): d_meta[0] = critical tiles at the front of the order, d_meta[1] = longest pixel
+// Dispatch order on the GPU (brt_order.hip): d_meta[0] = critical tiles at the front of the order, d_meta[1] = longest pixel,
+// d_meta[2] = non-sky tiles, d_meta[3] = tiles handed out as two half-sample jobs (d_order then has n_tiles + d_meta[3] entries: room for
+// n_tiles + split_tail)
 size_t order_scratch_bytes(uint32_t n_tiles);
 // tiles_x / dilate_x / dilate_y: rank every tile by its neighbourhood of that radius (0, 0: by itself), brt_order.hip
 hipError_t launch_build_order(const uint32_t* d_ray_sum, const uint32_t* d_longest, uint32_t n_tiles, uint64_t sky_cost,
-                              uint64_t grid_lanes, uint32_t tiles_x, uint32_t dilate_x, uint32_t dilate_y, uint32_t* d_order,
-                              uint32_t* d_meta, char* d_scratch, hipStream_t stream);
+                              uint64_t grid_lanes, uint32_t tiles_x, uint32_t dilate_x, uint32_t dilate_y, uint32_t split_tail,
+                              uint32_t* d_order, uint32_t* d_meta, char* d_scratch, hipStream_t stream);
 
 // GPU PLOC builder (brt_bvh.hip): scratch size for n models, and the launch; *d_out / *d_info
 // point into the scratch (nodes in the reference's 48-byte format; info[0] = node count,

@@ -201,7 +201,15 @@ struct FrameParams {
     // of each finished pixel, tile_cost[n_tiles + tile] = max of them.  Either may be null.
     const uint32_t* tile_order;
     uint32_t* tile_cost;
-    const uint32_t* order_meta;      // order built on the GPU (brt_order.hip): [0] = critical tiles at its front (replaces crit_end)
+    const uint32_t* order_meta;      // order built on the GPU (brt_order.hip): [0] = critical tiles at its front (replaces crit_end),
+                                     // [2], [3] = split_nonsky, split_tiles below
+    // Half-sample jobs (brt_host.cpp build_tile_order): order positions [split_nonsky - split_tiles, split_nonsky) are FIRST halves (the
+    // lane ends after sample_count / 2 samples and leaves its pixel state in slice_state), the next split_tiles positions the SECOND
+    // halves of the same tiles; the tile queue then has split_tiles * 64 more slots than queue_size.  slice_state: 8 words per pixel
+    // of the tile buffer {rng, sum.x, sum.y, sum.z, depth sum, rays so far, -, stamp}; a record is valid when its stamp is slice_serial.
+    uint32_t split_nonsky, split_tiles;
+    uint32_t* slice_state;
+    uint32_t slice_serial;
     uint32_t tunable;                // 1: some knob above differs from its default -> the TUNABLE kernel instantiation
     uint32_t policy_flags;           // TUNABLE only; bit 0: `||` of raytrace.wgsl:269 short-circuits (alternative policy)
 };

@@ -6,6 +6,8 @@
 // frame (and half the frame's longest pixel) are CRITICAL.  Building it here keeps the measuring frames and the
 // first-frame pre-pass free of a device -> host -> device round trip (1.7 ms of host time per build at 1080p: copy the
 // counts back, std::sort, copy the order up, two stream synchronisations).
+// Half-sample jobs (split_tail; build_tile_order has the why): the last min(split_tail, non-sky tiles) non-sky tiles appear twice,
+// order = [non-sky ... | first halves | second halves | sky], n_tiles + n_split entries; meta[2] = non-sky tiles, meta[3] = n_split.
 // One block prepares the 64-bit keys and the frame totals (at most ~130 000 tiles at 4K), hipCUB sorts, a grid kernel
 // writes the order.  Default settings only (sorted, critical tiles on, no lane queue); anything else takes the host path.
 #include <hip/hip_runtime.h>
@@ -44,13 +46,13 @@ __device__ __forceinline__ void tile_cost_at(const uint32_t* __restrict__ ray_su
 
 __global__ __launch_bounds__(OB) void k_order_prepare(const uint32_t* __restrict__ ray_sum, const uint32_t* __restrict__ longest,
                                                       uint32_t n_tiles, unsigned long long sky_cost, unsigned long long grid_lanes,
-                                                      uint32_t tiles_x, uint32_t rx, uint32_t ry,
+                                                      uint32_t tiles_x, uint32_t rx, uint32_t ry, uint32_t split_tail,
                                                       unsigned long long* __restrict__ keys, uint32_t* __restrict__ meta) {
     __shared__ unsigned long long s_sum[OB];
-    __shared__ uint32_t s_max[OB], s_cnt[OB];
+    __shared__ uint32_t s_max[OB], s_cnt[OB], s_ns[OB];
     const uint32_t t = threadIdx.x;
     unsigned long long sum = 0;
-    uint32_t mx = 0;
+    uint32_t mx = 0, nonsky = 0;
     for (uint32_t i = t; i < n_tiles; i += OB) {
         const uint32_t rs = ray_sum[i];
         uint32_t lp;
@@ -59,11 +61,12 @@ __global__ __launch_bounds__(OB) void k_order_prepare(const uint32_t* __restrict
         sum += rs;
         mx = longest[i] > mx ? longest[i] : mx;
         keys[i] = ((unsigned long long)(sky ? 0xffffffffu : ~lp) << 32) | i;
+        nonsky += sky ? 0u : 1u;
     }
-    s_sum[t] = sum; s_max[t] = mx;
+    s_sum[t] = sum; s_max[t] = mx; s_ns[t] = nonsky;
     __syncthreads();
     for (int s = OB / 2; s > 0; s >>= 1) {
-        if ((int)t < s) { s_sum[t] += s_sum[t + s]; s_max[t] = s_max[t + s] > s_max[t] ? s_max[t + s] : s_max[t]; }
+        if ((int)t < s) { s_sum[t] += s_sum[t + s]; s_max[t] = s_max[t + s] > s_max[t] ? s_max[t + s] : s_max[t]; s_ns[t] += s_ns[t + s]; }
         __syncthreads();
     }
     const unsigned long long total = s_sum[0];
@@ -86,12 +89,26 @@ __global__ __launch_bounds__(OB) void k_order_prepare(const uint32_t* __restrict
         if ((int)t < s) s_cnt[t] += s_cnt[t + s];
         __syncthreads();
     }
-    if (t == 0) { meta[0] = s_cnt[0]; meta[1] = longest_pixel; }
+    if (t == 0) {
+        meta[0] = s_cnt[0];
+        meta[1] = longest_pixel;
+        meta[2] = s_ns[0];
+        meta[3] = split_tail < s_ns[0] ? split_tail : s_ns[0];
+    }
 }
 
-__global__ void k_order_emit(const unsigned long long* __restrict__ keys_sorted, uint32_t n_tiles, uint32_t* __restrict__ order) {
+__global__ void k_order_emit(const unsigned long long* __restrict__ keys_sorted, uint32_t n_tiles, const uint32_t* __restrict__ meta,
+                             uint32_t* __restrict__ order) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_tiles) order[i] = (uint32_t)(keys_sorted[i] & 0xffffffffull);
+    if (i >= n_tiles) return;
+    const uint32_t n_nonsky = meta[2], n_split = meta[3];
+    const uint32_t tile = (uint32_t)(keys_sorted[i] & 0xffffffffull);
+    if (i < n_nonsky) {
+        order[i] = tile;
+        if (i >= n_nonsky - n_split) order[i + n_split] = tile;      // its second half, behind all the first halves
+    } else {
+        order[i + n_split] = tile;                                   // sky tiles: behind both
+    }
 }
 
 size_t order_temp_bytes(uint32_t n_tiles) {
@@ -105,8 +122,8 @@ size_t order_temp_bytes(uint32_t n_tiles) {
 size_t order_scratch_bytes(uint32_t n_tiles) { return 2 * ((size_t)n_tiles * 8 + 256) + order_temp_bytes(n_tiles) + 256; }
 
 hipError_t launch_build_order(const uint32_t* d_ray_sum, const uint32_t* d_longest, uint32_t n_tiles, uint64_t sky_cost,
-                              uint64_t grid_lanes, uint32_t tiles_x, uint32_t dilate_x, uint32_t dilate_y, uint32_t* d_order,
-                              uint32_t* d_meta, char* d_scratch, hipStream_t stream) {
+                              uint64_t grid_lanes, uint32_t tiles_x, uint32_t dilate_x, uint32_t dilate_y, uint32_t split_tail,
+                              uint32_t* d_order, uint32_t* d_meta, char* d_scratch, hipStream_t stream) {
     if (n_tiles == 0) return hipSuccess;
     auto take = [&](size_t bytes) { char* r = d_scratch; d_scratch += (bytes + 255) & ~(size_t)255; return r; };
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(take((size_t)n_tiles * 8));
@@ -114,10 +131,10 @@ hipError_t launch_build_order(const uint32_t* d_ray_sum, const uint32_t* d_longe
     size_t temp_bytes = order_temp_bytes(n_tiles);
     void* temp = take(temp_bytes);
     hipLaunchKernelGGL(k_order_prepare, dim3(1), dim3(OB), 0, stream, d_ray_sum, d_longest, n_tiles, (unsigned long long)sky_cost,
-                       (unsigned long long)grid_lanes, tiles_x, dilate_x, dilate_y, keys, d_meta);
+                       (unsigned long long)grid_lanes, tiles_x, dilate_x, dilate_y, split_tail, keys, d_meta);
     hipError_t e = hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys, sorted, (int)n_tiles, 0, 64, stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_order_emit, dim3((n_tiles + 255u) / 256u), dim3(256), 0, stream, sorted, n_tiles, d_order);
+    hipLaunchKernelGGL(k_order_emit, dim3((n_tiles + 255u) / 256u), dim3(256), 0, stream, sorted, n_tiles, d_meta, d_order);
     return hipGetLastError();
 }
 

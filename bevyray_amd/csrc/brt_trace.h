@@ -65,9 +65,57 @@ struct PixelState {
     uint32_t sample;
     uint32_t out_index;     // pixel index in the tile buffer
     uint32_t frame_index;   // pixel index in the frame (raster inputs)
-    uint32_t tile;          // for the per-tile cost measurement
+    uint32_t tile;          // for the per-tile cost measurement; bits 30-31: kSliceFinal / kSliceFirst (what happens at sample_end) / kSliceDone
     uint32_t rays_begin;    // lane's ray counter when the pixel started
+    uint32_t sample_end;    // the lane leaves the pixel after this many samples (sample_count, or half of it: a first-half job)
 };
+
+// ---- half-sample jobs (FrameParams::split_*; why: brt_host.cpp build_tile_order) ---------------------------------------------------
+// A FIRST-half lane stops after sample_count / 2 samples; the SECOND-half lane of the same pixel (another wave, usually on another XCD,
+// a millisecond or two later) goes on from there with the state {rng, sums, rays so far} that waits in slice_state.  Nobody waits and
+// nothing is computed twice: whoever comes SECOND to the record's flag word carries the pixel on.
+//   first half, at its end    writes the state, then flag <- READY;  old flag == GAVE UP: the second half has been here and left,
+//                             this lane renders the second half itself (as if the tile had never been split)
+//   second half, at its start flag <- GAVE UP;  old flag == READY: the state is there, take it;  anything else: leave the pixel to
+//                             the first-half lane (this lane stays idle for the job)
+// Both are one atomic exchange on the same word, so exactly one of the two lanes goes on.  The record crosses XCDs, whose L2s are not
+// coherent with each other inside a kernel: every word is written and read by device-scope atomics (performed at the memory side, like
+// the tile queue's counter), the flag behind the RETURNS of the state words.  A flag belongs to this launch by its serial number.
+// A first-half lane does not go to memory at once: the exchanges are a round trip (microseconds) and the lanes of a tile end in ~30
+// different rounds -- one by one that cost the headline frame 4 %.  The lane just goes idle (kSliceDone: its registers keep the state)
+// and the WAVE settles all of them in one go the next time it runs its management code (slice_settle, top of the kernel's loop).
+constexpr uint32_t kSliceFinal = 0u, kSliceFirst = 1u, kSliceDone = 3u, kSliceShift = 30u, kTileMask = 0x3fffffffu;
+constexpr uint32_t kSliceReady = 1u, kSliceGaveUp = 2u;      // flag word = serial << 2 | one of these
+
+BRT_DEV uint32_t slice_xchg(uint32_t* p, uint32_t v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+BRT_DEV uint32_t slice_read(uint32_t* p) { return __hip_atomic_fetch_add(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// first half: true when the second-half lane has already given up on this pixel (the caller then carries on with it)
+BRT_DEV bool slice_store(const FrameParams& fp, const PixelState& ps, uint32_t rays) {
+    uint32_t* rec = fp.slice_state + 8u * (size_t)ps.out_index;
+    uint32_t seen = slice_xchg(rec + 0, ps.rng);
+    seen |= slice_xchg(rec + 1, __float_as_uint(ps.sum.x));
+    seen |= slice_xchg(rec + 2, __float_as_uint(ps.sum.y));
+    seen |= slice_xchg(rec + 3, __float_as_uint(ps.sum.z));
+    seen |= slice_xchg(rec + 4, __float_as_uint(ps.dsum));
+    seen |= slice_xchg(rec + 5, rays);
+    // the flag goes out when the six exchanges have RETURNED (performed): its value is made to depend on what they returned
+    uint32_t flag = (fp.slice_serial << 2) | kSliceReady;
+    asm volatile("v_and_b32 %1, 0, %1\n\tv_or_b32 %0, %0, %1" : "+v"(flag), "+v"(seen));
+    return slice_xchg(rec + 7, flag) == ((fp.slice_serial << 2) | kSliceGaveUp);
+}
+
+// second half: true when the state was there (ps continues at sample_count / 2; *rays_before = rays of the first half)
+BRT_DEV bool slice_load(const FrameParams& fp, PixelState& ps, uint32_t* rays_before) {
+    uint32_t* rec = fp.slice_state + 8u * (size_t)ps.out_index;
+    if (slice_xchg(rec + 7, (fp.slice_serial << 2) | kSliceGaveUp) != ((fp.slice_serial << 2) | kSliceReady)) return false;
+    ps.rng = slice_read(rec + 0);
+    ps.sum = mk3(__uint_as_float(slice_read(rec + 1)), __uint_as_float(slice_read(rec + 2)), __uint_as_float(slice_read(rec + 3)));
+    ps.dsum = __uint_as_float(slice_read(rec + 4));
+    *rays_before = slice_read(rec + 5);
+    ps.sample = fp.sample_count / 2u;
+    return true;
+}
 
 BRT_DEV void pixel_begin(const FrameParams& fp, const PixelCoord& c, PixelState& ps) {
     const float uvx = ((float)c.px + 0.5f) / (float)fp.width;
@@ -161,13 +209,19 @@ BRT_DEV void shade_landed(const ScenePtrs& sc, const FrameParams& fp, bool lande
         ps.sample++;
         bounce = 0;
         need_cam = true;
-        if (ps.sample == fp.sample_count) {
-            pixel_finish<LEAN != 0>(fp, ps, out_tile, raster_rgba, raster_depth);
-            // (in the LEAN instantiations too since round 4: a view whose camera moves measures every frame -- launch_part -- and
-            //  must not fall back to the general instantiation for it)
-            if (fp.tile_cost) {
-                atomicAdd(&fp.tile_cost[ps.tile], n_rays - ps.rays_begin);
-                atomicMax(&fp.tile_cost[fp.local_strips * fp.tiles_x + ps.tile], n_rays - ps.rays_begin);
+        if (ps.sample == ps.sample_end) {
+            const uint32_t at_end = ps.tile >> kSliceShift, tile = ps.tile & kTileMask;
+            if (at_end == kSliceFirst) {
+                ps.tile |= kSliceDone << kSliceShift;               // settled later, by the wave (slice_settle)
+            } else {
+                const uint32_t rays = n_rays - ps.rays_begin;       // (a second half: of the whole pixel)
+                pixel_finish<LEAN != 0>(fp, ps, out_tile, raster_rgba, raster_depth);
+                // (in the LEAN instantiations too since round 4: a view whose camera moves measures every frame -- launch_part -- and
+                //  must not fall back to the general instantiation for it)
+                if (fp.tile_cost) {
+                    atomicAdd(&fp.tile_cost[tile], rays);
+                    atomicMax(&fp.tile_cost[fp.local_strips * fp.tiles_x + tile], rays);
+                }
             }
             active = false;
         }
@@ -424,10 +478,18 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     const uint32_t pool_adopt = TUNABLE ? fp.pool_adopt : kPoolAdopt;
     // queue slots [crit_begin, crit_end) hold the CRITICAL tiles; when the order was built on the GPU its count lives there too
     const uint32_t crit_end = LEAN == 2 ? 0u : (fp.order_meta ? fp.order_meta[0] * 64u : fp.crit_end);
+    // half-sample jobs at the end of the order (FrameParams::split_*): slots [split_lo, split_mid) first halves, [split_mid, split_hi) second
+    // halves.  The instantiations that count or tune (and frames of very few samples) take a first half as the whole tile and skip the second.
+    constexpr bool kSlices = !COUNTERS && !TUNABLE;
+    const uint32_t split_tiles = fp.slice_state ? (fp.order_meta ? fp.order_meta[3] : fp.split_tiles) : 0u;
+    const uint32_t split_mid = (fp.order_meta ? fp.order_meta[2] : fp.split_nonsky) * 64u;
+    const uint32_t split_lo = split_mid - split_tiles * 64u, split_hi = split_mid + split_tiles * 64u;
+    const bool slices = kSlices && fp.sample_count >= 16u;
+    const uint32_t queue_size = fp.queue_size + split_tiles * 64u;
 
     PixelState ps;
     ps.sample = 0; ps.rng = 0; ps.out_index = 0; ps.frame_index = 0; ps.tile = 0; ps.rays_begin = 0;
-    ps.ndc0x = ps.ndc0y = 0.0f; ps.sum = mk3(0.0f, 0.0f, 0.0f); ps.dsum = 0.0f;
+    ps.ndc0x = ps.ndc0y = 0.0f; ps.sum = mk3(0.0f, 0.0f, 0.0f); ps.dsum = 0.0f; ps.sample_end = fp.sample_count;
     f3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f), tput = mk3(1.0f, 1.0f, 1.0f);
     uint32_t bounce = 0;
     float first_depth = kInf;
@@ -447,28 +509,62 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     // (100 MHz wall clock; read by brt_debug_profile as words 24..29)
     unsigned long long t_start = 0, t_empty = 0, drain_lane_rounds = 0;
     unsigned long long t_mark = 0, ticks_refill = 0, ticks_walk = 0, ticks_shade = 0, ticks_pre = 0;   // phase times of this wave
+#ifdef BRT_LIFE_HIST       // diagnostic build: wave lifetimes in the production instantiations too (finer bins: 2^13 ticks = 0.082 ms)
+    unsigned long long lh_start = wall_clock64();
+#endif
     if (COUNTERS) t_start = t_mark = wall_clock64();
 
     bool tiles_done = false;          // the tile queue (slots FrameParams::queue_lane .. queue_size) is empty
     bool again_mark = false;          // COUNTERS: the round that starts follows another one directly (phase times)
     // lane takes queue slot q of `tile`
+    // first-half lanes that have ended (kSliceDone) hand their pixel over -- or carry on with it, if its second-half lane has come and
+    // gone: slice_store.  Before anything reuses a lane: at the top of the management code.
+    auto slice_settle = [&]() {
+        const bool done = kSlices && !active && (ps.tile >> kSliceShift) == kSliceDone;
+        if (__ballot(done) == 0ull) return;
+        if (done) {
+            ps.tile &= kTileMask;
+            if (slice_store(fp, ps, n_rays - ps.rays_begin)) {
+                ps.sample_end = fp.sample_count;        // (sample, rng, sums: as the first half left them; need_cam is set, bounce is 0)
+                active = true;
+            }
+        }
+    };
     auto begin_pixel = [&](uint32_t q, uint32_t tile) {
         const PixelCoord c = slot_to_pixel<TUNABLE>(fp, q, tile);
-        if (c.inside) {
+        const bool first_half = q >= split_lo && q < split_mid, second_half = q >= split_mid && q < split_hi;
+        if (c.inside && !(second_half && !slices)) {
             pixel_begin(fp, c, ps);
             crit = q >= fp.crit_begin && q < crit_end;
             ps.rays_begin = n_rays;
+            ps.sample_end = fp.sample_count;
+            bool taken = true;                          // (a second-half lane whose first half is not there yet leaves the pixel alone)
+            if (slices && first_half) {
+                ps.sample_end = fp.sample_count / 2u;
+                ps.tile |= kSliceFirst << kSliceShift;
+            } else if (slices && second_half) {
+                uint32_t rays_before = 0u;
+                taken = slice_load(fp, ps, &rays_before);
+                ps.rays_begin = n_rays - rays_before;
+                // (diagnostic, brt_debug_profile [62], [63]: second halves that took the pixel over / that left it to the first-half lane)
+                const uint64_t tm = __ballot(taken), lm = __ballot(!taken);
+                if (mbcnt64(tm | lm) == 0u) {
+                    if (tm) atomicAdd(&counters[62], (unsigned long long)__popcll(tm));
+                    if (lm) atomicAdd(&counters[63], (unsigned long long)__popcll(lm));
+                }
+            }
             if (fp.sample_count == 0) {
                 // 0/0 per channel.  The sums are compile-time zeros here; keep them opaque: hipcc 7.2
                 // otherwise folds the four divisions into one and then drops two channels of the
                 // level-1/2 result (found by scripts/fuzz_parity.py; tests: sample_count 0).
                 asm volatile("" : "+v"(ps.sum.x), "+v"(ps.sum.y), "+v"(ps.sum.z), "+v"(ps.dsum));
                 pixel_finish<LEAN != 0>(fp, ps, out_tile, raster_rgba, raster_depth);
-            } else { active = true; bounce = 0; need_cam = true; }
+            } else if (taken) { active = true; bounce = 0; need_cam = true; }
         }
     };
 
     for (;;) {
+        if (split_tiles != 0u) slice_settle();
         // A wave that carries one of the frame's CRITICAL pixels (FrameParams::crit_*) issues ahead of its SIMD
         // mates and takes no new pixels: its rounds get shorter as its other pixels end, and the frame cannot
         // end before that chain has.
@@ -542,12 +638,12 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             }
         }
         // ---- nothing left to do (and the lane queue, if any, is empty): the next whole tile ----
-        if (queue_lane != fp.queue_size && !tiles_done && !wave_crit && __ballot(active) == 0ull &&
+        if (queue_lane != queue_size && !tiles_done && !wave_crit && __ballot(active) == 0ull &&
             __ballot(!exhausted) == 0ull) {
             uint32_t b = 0;
             if (lane == 0) b = atomicAdd(queue_counter + 1, 64u);
             b = queue_lane + (uint32_t)__shfl((int)b, 0, 64);
-            if (b < fp.queue_size) begin_pixel(b + lane, slot_tile(fp, b >> 6));
+            if (b < queue_size) begin_pixel(b + lane, slot_tile(fp, b >> 6));
             else {
                 tiles_done = true;
                 if (COUNTERS && t_empty == 0) t_empty = wall_clock64();
@@ -583,7 +679,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                         active = false;
                     }
                     // (while the tile queue has tiles the wave stays: it takes one next round)
-                    const bool stay = queue_lane != fp.queue_size && !tiles_done;
+                    const bool stay = queue_lane != queue_size && !tiles_done;
                     if (lane == 0) { pool_ctl[1] = count + live; if (!stay) pool_ctl[2] = alive - 1u; }
                     leave = !stay;
                 } else if (count != 0u && live < 64u) {
@@ -599,13 +695,14 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                         ps.rng = __float_as_uint(r1.z); ps.sample = __float_as_uint(r1.w);
                         ps.out_index = __float_as_uint(r2.x); ps.frame_index = __float_as_uint(r2.y);
                         ps.tile = __float_as_uint(r2.z); ps.rays_begin = n_rays - __float_as_uint(r2.w);
+                        ps.sample_end = (ps.tile >> kSliceShift) == kSliceFirst ? fp.sample_count / 2u : fp.sample_count;
                         o = mk3(r3.x, r3.y, r3.z); d = mk3(r3.w, r4.x, r4.y); tput = mk3(r4.z, r4.w, r5.x);
                         bounce = __float_as_uint(r5.y); first_depth = r5.z;
                         crit = (__float_as_uint(r5.w) & 1u) != 0u; need_cam = (__float_as_uint(r5.w) & 2u) != 0u;
                         active = true; in_flight = false; exhausted = true;
                     }
                     if (lane == 0) pool_ctl[1] = count - k;
-                } else if (live == 0u && count == 0u && (queue_lane == fp.queue_size || tiles_done)) {
+                } else if (live == 0u && count == 0u && (queue_lane == queue_size || tiles_done)) {
                     if (lane == 0) pool_ctl[2] = alive - 1u;
                     leave = true;
                 }
@@ -613,7 +710,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             }
             if (leave) break;
             finish_walks = wave_count(active) <= drain_donate && !tiles_done;
-        } else if (__ballot(active) == 0 && (queue_lane == fp.queue_size || tiles_done || __ballot(!exhausted) != 0ull)) {
+        } else if (__ballot(active) == 0 && (queue_lane == queue_size || tiles_done || __ballot(!exhausted) != 0ull)) {
             break;
         }
         if (__ballot(active) == 0) continue;      // (pool on) nothing live but paths may still arrive
@@ -688,6 +785,18 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             atomicAdd(&counters[3], (unsigned long long)c);
         }
     }
+#ifdef BRT_LIFE_HIST
+    if (!COUNTERS && lane == 0) {
+        const unsigned long long lh_end = wall_clock64();
+        atomicMax(&counters[24], ~lh_start);
+        atomicMax(&counters[27], lh_end);
+        atomicAdd(&counters[29], 1ull);
+        atomicAdd(&counters[45], lh_end - lh_start);
+        const unsigned long long bin = (lh_end - lh_start) >> 13;
+        // bins 88 .. 151 (7.2 .. 12.4 ms)
+        if (bin >= 88ull && bin < 152ull) atomicAdd(&counters[46 + ((bin - 88ull) >> 2)], 1ull << (16 * ((bin - 88ull) & 3ull)));
+    }
+#endif
     if (COUNTERS) {
         const unsigned long long t_end = wall_clock64();
         unsigned long long te = 0;   // earliest "queue empty" seen by a lane of this wave

@@ -394,7 +394,8 @@ class RaytracePlugin:
         names = ["interior", "leaf", "camera", "scatter", "sky", "ball", "camera_top", "round"]
         prof = {n: (int(raw[8 + 2 * k]), int(raw[9 + 2 * k])) for k, n in enumerate(names)}
         # wave time stamps (100 MHz wall clock): first start, first / last "pixel queue empty", last end
-        self.last_order_meta = {"critical_tiles": int(raw[40]), "longest_pixel_rays": int(raw[41])}
+        self.last_order_meta = {"critical_tiles": int(raw[40]), "longest_pixel_rays": int(raw[41]), "split_tiles": int(raw[42]),
+                                "second_halves_taken": int(raw[62]), "second_halves_left": int(raw[63])}
         t0 = (~int(raw[24])) & (2**64 - 1)
         if raw[29]:
             first_empty = ((~int(raw[25])) & (2**64 - 1)) if raw[25] else 0

@@ -267,30 +267,38 @@ int32_t brt_debug_eval(brt_ctx* ctx, uint32_t op, const float* in16, float* out8
  * 6 camera ray made at the top of a round (first sample of a pixel, late sample ends), 7 ray round); wave timeline in 100 MHz ticks: [24] ~first start, [25] ~first / [26] last "lane queue empty",
  * [27] last end, [28] sum of (end - empty) over waves, [29] waves, [30]/[31] live lanes and rounds after "empty";
  * wave time summed over waves: [5] pixel refill, [6] walk loop, [7] shading, [43] drain logic + camera ray +
- * walk begin, [44] rejection-sampler loop; [40] critical tiles and [41] longest pixel (rays) of the view's last measured frame.
+ * walk begin, [44] rejection-sampler loop; [40] critical tiles and [41] longest pixel (rays) of the view's last measured frame, [42] tiles its
+ * order hands out as two half-sample jobs, [62] / [63] pixels of the last launch whose second-half lane took the first half's state over /
+ * left the pixel to the first-half lane (whose state was not there yet).
  * out64 must hold 64 words. */
 int32_t brt_debug_profile(brt_ctx* ctx, uint64_t* out64);
 
 /* Diagnostic: the dispatch order as the GPU builds it (bevyray_amd/csrc/brt_order.hip, used behind every measuring
- * frame with default settings) for given per-tile ray counts: out_order as brt_host_tile_order's, out_info2 =
- * {critical tiles at the front, longest pixel}.  Tests compare it with brt_host_tile_order.  Host pointers, synchronous. */
+ * frame with default settings) for given per-tile ray counts: out_order as brt_host_tile_order's (n_tiles + split_tail words),
+ * out_info4 = {critical tiles at the front, longest pixel, non-sky tiles, tiles handed out as two half-sample jobs}.  Tests
+ * compare it with brt_host_tile_order.  Host pointers, synchronous. */
 int32_t brt_debug_tile_order(brt_ctx* ctx, const uint32_t* ray_sum, const uint32_t* longest_pixel, uint32_t n_tiles,
-                             uint32_t sample_count, uint64_t grid_lanes, uint32_t tiles_x, uint32_t dilate, uint32_t* out_order,
-                             uint32_t* out_info2);
+                             uint32_t sample_count, uint64_t grid_lanes, uint32_t tiles_x, uint32_t dilate, uint32_t split_tail,
+                             uint32_t* out_order, uint32_t* out_info4);
 
 /* ---- host-only helpers (no GPU needed) --------------------------------------------- */
 
 /* The dispatch order brt_render derives from one frame's per-tile ray counts (sum and longest pixel of each
  * 8x8 tile): out_order[k] = k-th tile to hand out -- the non-sky tiles (longest pixel
- * first when `sorted`), then the one-ray-per-sample "sky" tiles; out_info3 = {tiles at the front that go to the
+ * first when `sorted`), then the one-ray-per-sample "sky" tiles; out_info5[0..2] = {tiles at the front that go to the
  * lane queue (pixel by pixel to single lanes; the rest are handed out as whole tiles), critical tiles at the
  * front, longest pixel}.  grid_lanes = CUs x threads per workgroup.  dilate > 0: a tile is ranked by the longest pixel of the
  * (2 dilate + 1)^2 tiles around it in the tiles_x-wide tile grid, and is "sky" only if all of them were (what brt_render does by
- * default with radius 2, and with the radius the motion covers when the camera has moved since the costs were measured).  No
- * reference counterpart: the reference draws one fullscreen triangle (pipeline.rs:206-215). */
+ * default with radius 2, and with the radius the motion covers when the camera has moved since the costs were measured).
+ * split_tail > 0: the last min(split_tail, non-sky tiles) non-sky tiles are in the order TWICE -- [other non-sky tiles | those, first
+ * half of the samples | the same, second half | sky tiles] -- so that the jobs ahead of the cheap sky tiles are half as long and the
+ * end of a launch is balanced (brt_render does this for frames of at least 6 tiles per wave slot); out_order then holds
+ * n_tiles + that many words (room for n_tiles + split_tail), out_info5 = {lane-queue tiles, critical tiles, longest pixel,
+ * non-sky tiles, tiles that are split}.  No reference counterpart: the reference draws one fullscreen triangle
+ * (pipeline.rs:206-215). */
 int32_t brt_host_tile_order(const uint32_t* ray_sum, const uint32_t* longest_pixel, uint32_t n_tiles, uint32_t sample_count,
                             uint64_t grid_lanes, uint32_t sorted, uint32_t lane_permille, uint32_t tiles_x, uint32_t dilate,
-                            uint32_t* out_order, uint32_t* out_info3);
+                            uint32_t split_tail, uint32_t* out_order, uint32_t* out_info5);
 
 /* Replaces: obvhs::ploc::build_ploc::<24>(aabbs, identity, SortPrecision::U64, 0) and the
  * flatten into BVHNode (extract.rs:315-332), including Model::aabb's 0.1 pad

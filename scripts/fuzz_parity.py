@@ -153,9 +153,12 @@ def main():
     multi = brt.RaytracePlugin([0, 0, 0])      # three sub-contexts on one GPU: the in-process strip split of brt_render
     node = plugin.node
 
-    def render(c, b):
+    def render(c, b, counters=True):
         """-> (frame, stats or None): the four ways a frame can be produced through the C ABI"""
         args = (c["level"], c["camera"], c["window"], c["w"], c["h"])
+        if not counters:        # the production instantiation (the only one that runs half-sample jobs): frame + ray count
+            got = node.run(*args, buffers=b, raster_rgba=c["raster"], raster_depth=c["depth"])
+            return got, node.last_stats
         if c["mode"] == "multi":
             got = multi.node.run(*args, buffers=b, raster_rgba=c["raster"], raster_depth=c["depth"], flags=brt.FLAG_COUNTERS)
             return got, multi.node.last_stats
@@ -184,7 +187,7 @@ def main():
         return got, node.last_stats
     rng = np.random.default_rng(args.seed)
     t_start = time.time()
-    fails, done, pixels, rays, ploc_checked, rejected, tight_checked = 0, 0, 0, 0, 0, 0, 0
+    fails, done, pixels, rays, ploc_checked, rejected, tight_checked, split_checked = 0, 0, 0, 0, 0, 0, 0, 0
     lines = []
     t_progress = time.time()
     for case in range(args.cases):
@@ -196,10 +199,13 @@ def main():
         c = random_case(rng)
         b = c["buffers"]
         # kernel variant of this case: default plan, top-of-tree tile of a few records, everything from L2, knobs live
+        # ... the last tiles of the order as two half-sample jobs (production instantiations only: "parts" cases and the extra render below)
         variant = [{}, {}, {"BRT_FORCE_LDS_TOP": str(int(rng.integers(1, 200)))}, {"BRT_FORCE_GLOBAL_SCENE": "1"},
-                   {"BRT_TUNABLE": "1"}, {"BRT_FORCE_LDS_TOP": "100000", "BRT_TUNABLE": "1"}][int(rng.integers(0, 6))]
+                   {"BRT_TUNABLE": "1"}, {"BRT_FORCE_LDS_TOP": "100000", "BRT_TUNABLE": "1"},
+                   {"BRT_SPLIT_FORCE": str(int(rng.integers(1, 400)))},
+                   {"BRT_SPLIT_FORCE": str(int(rng.integers(1, 400))), "BRT_FORCE_GLOBAL_SCENE": "1"}][int(rng.integers(0, 8))]
         for pl in (plugin, multi):          # knobs live in the context (brt_set_tuning), not in the environment
-            for k in ("BRT_FORCE_LDS_TOP", "BRT_FORCE_GLOBAL_SCENE", "BRT_TUNABLE"):
+            for k in ("BRT_FORCE_LDS_TOP", "BRT_FORCE_GLOBAL_SCENE", "BRT_TUNABLE", "BRT_SPLIT_FORCE"):
                 pl.set_tuning(k, int(variant.get(k, 0)))
         try:
             if b.bvh is None:             # callee-built: binned SAH (default) or PLOC on the GPU, which must equal the CPU builder byte for byte
@@ -233,6 +239,13 @@ def main():
             bad = frames_differ(got, want)
             if bad:
                 raise AssertionError(f"{bad} of {got.size} frame values differ")
+            if "BRT_SPLIT_FORCE" in variant and c["mode"] not in ("multi", "simple", "parts"):
+                for rep in range(2):      # (the second frame runs in the order the first one measured)
+                    got2, st2 = render(c, b, counters=False)
+                    bad = frames_differ(got2, want)
+                    if bad or st2["rays"] != cnt["rays"]:
+                        raise AssertionError(f"half-sample jobs: {bad} of {got2.size} frame values differ, rays {st2['rays']} vs {cnt['rays']}")
+                split_checked += 1
             # the callee's SAH tree pads its leaf boxes by less than the reference's 0.1 (brt_sah.h sah_model_pad): on well-conditioned scenes
             # without coincident spheres (exact ties are decided by the visiting order) the frame must also be the one of the caller's
             # 0.1-padded PLOC tree -- i.e. the tighter boxes culled nothing a ray is accepted by.  Well-conditioned = no sphere of radius
@@ -265,7 +278,7 @@ def main():
                      window=np.asarray(c["window"]).view(np.uint8), size=np.array([c["w"], c["h"]]),
                      raster=np.zeros(0) if c["raster"] is None else c["raster"], depth=np.zeros(0) if c["depth"] is None else c["depth"])
     summary = (f"fuzz_parity seed {args.seed}: {done} cases bit-exact (frames + 5 counters), {fails} failed, {rejected} refused; "
-               f"{pixels} pixels, {rays} rays; {ploc_checked} callee-built trees byte-identical CPU vs GPU, {tight_checked} tight-box SAH frames equal to the PLOC-tree frame; "
+               f"{pixels} pixels, {rays} rays; {ploc_checked} callee-built trees byte-identical CPU vs GPU, {tight_checked} tight-box SAH frames equal to the PLOC-tree frame, {split_checked} cases also through half-sample jobs (frame + rays, twice); "
                f"{time.time() - t_start:.0f} s")
     print(summary, flush=True)
     if args.log:

@@ -1,0 +1,21 @@
+"""Half-sample jobs at the end of the dispatch order: kernel ms of 8 frames of config 2 per BRT_SPLIT_TAIL setting, the order's meta (tiles split,
+second halves that took the state over / left the pixel to the first-half lane), and -- with a library built with -DBRT_LIFE_HIST (BRT_LIB_PATH) -- the span of
+the last launch, the mean wave lifetime and the histogram of the lifetimes."""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import bevyray_amd as brt
+W,H,spp,b=1920,1080,64,8
+sc=brt.generate_scene(brt.SCENE_COVER,1)
+lvl,cam,win=brt.cover_camera(W,H,spp,b)
+for knobs in ({"BRT_SPLIT_TAIL": 0}, {"BRT_SPLIT_TAIL": 4}, {"BRT_SPLIT_TAIL": 8}, {"BRT_SPLIT_TAIL": 12}, {}, {"BRT_SPLIT_TAIL": 24}, {"BRT_SPLIT_TAIL": 32}):
+    with brt.RaytracePlugin([0]) as p:
+        for k, v in knobs.items(): p.set_tuning(k, v)
+        out=p.alloc_frame(W,H)
+        p.node.write_buffers(brt.Buffers(sc.models, sc.materials, None))
+        ks=[]
+        for i in range(8):
+            p.node.run(lvl,cam,win,W,H,out=out); ks.append(round(p.node.last_stats["kernel_ms"],3))
+        p.debug_profile()
+        print(knobs, ks, p.last_order_meta, p.node.last_stats["rays"], p.node.last_stats.get("kernel_variant"), flush=True)
+        tl = getattr(p, "last_timeline", None)
+        if tl: print("   end_ms", tl["end_ms"], "mean_life", tl["mean_wave_life_ms"], "hist(0.082ms from 7.2ms)", tl["wave_life_hist_0.33ms"], flush=True)

@@ -250,14 +250,15 @@ def test_new_exports_fail_with_codes_not_crashes_without_a_context():
         assert lib.brt_last_error(None)
 
 
-def _tile_order(ray_sum, longest, spp, grid_lanes, sorted_=1, lane_permille=0, tiles_x=0, dilate=0):
+def _tile_order(ray_sum, longest, spp, grid_lanes, sorted_=1, lane_permille=0, tiles_x=0, dilate=0, split_tail=0):
     ray_sum = np.ascontiguousarray(ray_sum, np.uint32)
     longest = np.ascontiguousarray(longest, np.uint32)
-    order = np.zeros(len(ray_sum), np.uint32)
-    info = np.zeros(3, np.uint32)
+    order = np.zeros(len(ray_sum) + split_tail, np.uint32)
+    info = np.zeros(5, np.uint32)
     _lib.check(_lib.load().brt_host_tile_order(ray_sum.ctypes.data, longest.ctypes.data, len(ray_sum), spp, grid_lanes, sorted_,
-                                               lane_permille, tiles_x, dilate, order.ctypes.data, info.ctypes.data))
-    return order, dict(zip(("n_lane", "n_critical", "longest_pixel"), (int(x) for x in info)))
+                                               lane_permille, tiles_x, dilate, split_tail, order.ctypes.data, info.ctypes.data))
+    info = dict(zip(("n_lane", "n_critical", "longest_pixel", "n_nonsky", "n_split"), (int(x) for x in info)))
+    return order[:len(ray_sum) + info["n_split"]], info
 
 
 def test_dispatch_order_from_tile_costs():
@@ -293,6 +294,15 @@ def test_dispatch_order_from_tile_costs():
     assert _tile_order(ray_sum, longest, spp, lanes, lane_permille=100)[1]["n_lane"] == (n - n_sky) // 10
     order3, info3 = _tile_order(ray_sum, longest, spp, lanes, sorted_=0)
     assert list(order3[:n - n_sky]) == sorted(order3[:n - n_sky]) and info3["n_critical"] == 0
+    # half-sample jobs: the last k non-sky tiles appear twice -- [other non-sky | first halves | second halves | sky] -- k capped by the
+    # non-sky tiles; the order without the repeats is the plain order
+    for k in (0, 1, 37, n - n_sky, n):
+        order4, info4 = _tile_order(ray_sum, longest, spp, lanes, split_tail=k)
+        ks = min(k, n - n_sky)
+        assert info4["n_nonsky"] == n - n_sky and info4["n_split"] == ks and len(order4) == n + ks
+        assert np.array_equal(order4[:n - n_sky], order[:n - n_sky])
+        assert np.array_equal(order4[n - n_sky:n - n_sky + ks], order[n - n_sky - ks:n - n_sky])
+        assert np.array_equal(order4[n - n_sky + ks:], order[n - n_sky:])
 
 
 def test_sah_builder_contract_depth_cap_and_determinism():

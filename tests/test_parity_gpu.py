@@ -1273,15 +1273,64 @@ def test_gpu_tile_order_equals_host_tile_order(plugin):
                 longest[0:5 * k:5] = longest[1::5]           # ties: raster order among equals
             # ranked by itself, and by the neighbourhood of radius 2 / 5 in a tile grid of some width that divides n (brt_render's default / a moved camera)
             widths = [t for t in (240, 120, 37, 16, 8, 5, 1) if n % t == 0]
-            for tiles_x, dilate in [(0, 0)] + [(widths[0], d) for d in (2, 5)]:
-                want = np.zeros(n, np.uint32); info3 = np.zeros(3, np.uint32)
-                _lib.check(lib.brt_host_tile_order(ray_sum.ctypes.data, longest.ctypes.data, n, spp, lanes, 1, 0, tiles_x, dilate, want.ctypes.data,
-                                                   info3.ctypes.data))
-                got = np.zeros(n, np.uint32); info2 = np.zeros(2, np.uint32)
-                _lib.check(lib.brt_debug_tile_order(plugin._ctx, ray_sum.ctypes.data, longest.ctypes.data, n, spp, lanes, tiles_x, dilate,
-                                                    got.ctypes.data, info2.ctypes.data), plugin._ctx)
-                assert np.array_equal(got, want), (n, spp, flavour, tiles_x, dilate)
-                assert int(info2[0]) == int(info3[1]) and int(info2[1]) == int(info3[2]), (n, spp, flavour, tiles_x, dilate, info2, info3)
+            # ... and with the last `split` non-sky tiles handed out as two half-sample jobs (none, fewer than there are, more than there are)
+            for tiles_x, dilate, split in [(0, 0, 0), (0, 0, max(1, n // 7)), (0, 0, n + 3)] + [(widths[0], d, s) for d in (2, 5) for s in (0, n // 3)]:
+                want = np.zeros(n + split, np.uint32); info5 = np.zeros(5, np.uint32)
+                _lib.check(lib.brt_host_tile_order(ray_sum.ctypes.data, longest.ctypes.data, n, spp, lanes, 1, 0, tiles_x, dilate, split,
+                                                   want.ctypes.data, info5.ctypes.data))
+                got = np.zeros(n + split, np.uint32); info4 = np.zeros(4, np.uint32)
+                _lib.check(lib.brt_debug_tile_order(plugin._ctx, ray_sum.ctypes.data, longest.ctypes.data, n, spp, lanes, tiles_x, dilate, split,
+                                                    got.ctypes.data, info4.ctypes.data), plugin._ctx)
+                assert info4.tolist() == info5[1:].tolist(), (n, spp, flavour, tiles_x, dilate, split, info4, info5)
+                n_split = int(info5[4])
+                assert n_split == min(split, int(info5[3]))
+                assert np.array_equal(got[:n + n_split], want[:n + n_split]), (n, spp, flavour, tiles_x, dilate, split)
+
+
+def test_half_sample_jobs_hand_the_pixel_state_over_without_changing_pixels_or_ray_counts(oracle):
+    """The last tiles of the dispatch order are handed out as two half-sample jobs (brt_host.cpp build_tile_order): the first leaves
+    {rng, sums, rays} per pixel in HBM, the second picks them up -- or, when the record is not there yet, leaves the pixel to the
+    first-half lane, which then renders the second half too (one atomic exchange per side decides; nobody waits, nothing is rendered
+    twice).  Forced on small frames (BRT_SPLIT_FORCE tiles; by default only frames of >= 6 tiles per wave slot split): few tiles -> the
+    second job runs beside the first and leaves, many -> it finds the records.
+    Pixels and the frame's ray count equal the oracle's either way, with the order built on the GPU and on the host."""
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    seen = {"taken": 0, "left": 0}
+    for (w, h, spp, bounces) in ((320, 180, 32, 8), (96, 40, 64, 4), (640, 360, 16, 8), (200, 120, 33, 3)):
+        lvl, cam, win = brt.cover_camera(w, h, spp, bounces)
+        want, cnt = oracle.render(b, lvl, cam, win, w, h)
+        n_tiles = ((w + 7) // 8) * ((h + 7) // 8)
+        for force, host in ((n_tiles, 0), (3, 0), (max(1, n_tiles // 2), 1), (n_tiles, 1)):
+            with brt.RaytracePlugin([0]) as p:
+                p.set_tuning("BRT_SPLIT_FORCE", force)
+                p.set_tuning("BRT_ORDER_ON_HOST", host)
+                for frame in range(3):          # pre-pass + frame in its order, then frames in the measured order
+                    got = p.node.run(lvl, cam, win, w, h, buffers=b if frame == 0 else None)
+                    assert_frames_equal(got, want)
+                    assert p.node.last_stats["rays"] == cnt["rays"], (w, h, spp, force, host, frame)
+                p.debug_profile()
+                meta = p.last_order_meta
+                assert 0 < meta["split_tiles"] <= force, (meta, force)
+                assert meta["second_halves_taken"] + meta["second_halves_left"] > 0, meta
+                seen["taken"] += meta["second_halves_taken"]
+                seen["left"] += meta["second_halves_left"]
+                # the counting instantiation takes a first half as the whole tile and skips the second: same frame, all five counters
+                got = p.node.run(lvl, cam, win, w, h, flags=brt.FLAG_COUNTERS)
+                assert_frames_equal(got, want)
+                assert {k: p.node.last_stats[k] for k in COUNTER_KEYS} == cnt
+    assert seen["left"] > 0, seen
+    # a frame of many tiles per wave slot, default settings: the second halves come up long after the first ones and take the states over
+    w, h, spp, bounces = 1920, 1080, 16, 2
+    lvl, cam, win = brt.cover_camera(w, h, spp, bounces)
+    want, cnt = oracle.render(b, lvl, cam, win, w, h)
+    with brt.RaytracePlugin([0]) as p:
+        for frame in range(3):
+            got = p.node.run(lvl, cam, win, w, h, buffers=b if frame == 0 else None)
+            assert_frames_equal(got, want)
+            assert p.node.last_stats["rays"] == cnt["rays"]
+        p.debug_profile()
+        meta = p.last_order_meta
+        assert meta["split_tiles"] > 0 and meta["second_halves_taken"] > 50 * meta["second_halves_left"], meta
 
 
 def test_order_built_on_host_and_on_gpu_render_the_same_frames(oracle, monkeypatch):
