@@ -479,8 +479,8 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     // queue slots [crit_begin, crit_end) hold the CRITICAL tiles; when the order was built on the GPU its count lives there too
     const uint32_t crit_end = LEAN == 2 ? 0u : (fp.order_meta ? fp.order_meta[0] * 64u : fp.crit_end);
     // half-sample jobs at the end of the order (FrameParams::split_*): slots [split_lo, split_mid) first halves, [split_mid, split_hi) second
-    // halves.  The instantiations that count or tune (and frames of very few samples) take a first half as the whole tile and skip the second.
-    constexpr bool kSlices = !COUNTERS && !TUNABLE;
+    // halves.  The counting instantiations (and frames of very few samples) take a first half as the whole tile and skip the second.
+    constexpr bool kSlices = !COUNTERS;
     const uint32_t split_tiles = fp.slice_state ? (fp.order_meta ? fp.order_meta[3] : fp.split_tiles) : 0u;
     const uint32_t split_mid = (fp.order_meta ? fp.order_meta[2] : fp.split_nonsky) * 64u;
     const uint32_t split_lo = split_mid - split_tiles * 64u, split_hi = split_mid + split_tiles * 64u;
