@@ -523,6 +523,8 @@ int32_t prepass_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const 
     pp.spp_f = (float)k;
     pp.tile_order = nullptr;
     pp.order_meta = nullptr;
+    pp.slice_state = nullptr;     // (raster order: nothing is split)
+    pp.split_nonsky = pp.split_tiles = 0u;
     pp.tunable = 1u;   // the knobs-live instantiation (all knobs at their defaults): the pre-pass then shows up under its own
                        // kernel name in rocprofv3 --stats instead of pulling down the average of the frame kernel
     pp.queue_lane = 0u;
