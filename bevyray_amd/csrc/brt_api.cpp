@@ -278,16 +278,19 @@ bool camera_jumped(const brt_ctx* ctx, const DeviceCtx& dc, const FrameParams& f
 }
 
 // Tiles at the end of the order that are handed out as two half-sample jobs (brt_host.cpp build_tile_order): BRT_SPLIT_TAIL quarters of
-// the wave slots.  Default 16, the last four tiles per wave slot: the second halves must come up late enough behind the first ones to
-// find their states (headline frame, 0 / 4 / 8 / 12 / 16 / 24: 9.49 / 9.53 / 9.40 / 9.33 / 9.21 / 9.28 ms; with 8, 1 % of the second
-// halves come too early, leave the pixel to its first-half lane, and those lanes are the new stragglers;
-// profiles/r04/split_tail.txt).  Only for launches of at least 6 tiles per wave slot, like the neighbourhood ranking: a rank's share
+// the wave slots (default 16: four tiles per wave slot), but at least half the launch's tiles.  The second halves must come up late
+// enough behind the first ones to find their states: on the headline frame 0 / 4 / 8 / 12 / 16 / 24 / every non-sky tile give 9.49 /
+// 9.53 / 9.40 / 9.33 / 9.21 / 9.28 / 9.25 ms -- with 8, 1 % of the second halves come too early, leave the pixel to its first-half
+// lane, and those lanes are the new stragglers; and where the jobs are longer the gap must be wider: the 4K / 1024 spp frame (129 600
+// tiles) 589 ms without, 596 with 16, 587 with 64 or all -- hence the half (profiles/r04/split_tail.txt).  The builders cap the number
+// at the non-sky tiles that are not critical.  Only for launches of at least 6 tiles per wave slot, like the neighbourhood ranking: a rank's share
 // of a frame split 2 or 4 ways has nothing to balance at its end.
 uint32_t split_tail_of(const brt_ctx* ctx, const DeviceCtx& dc, uint32_t n_tiles) {
     const uint64_t wave_slots = (uint64_t)dc.num_cus * (BRT_BLOCK / 64u);
     if (ctx->knobs[K_SPLIT_FORCE] != 0u) return ctx->knobs[K_SPLIT_FORCE] < n_tiles ? ctx->knobs[K_SPLIT_FORCE] : n_tiles;   // (tests: that many tiles, whatever the frame)
     if ((uint64_t)n_tiles < 6u * wave_slots) return 0u;
-    const uint64_t r = (uint64_t)ctx->knobs[K_SPLIT_TAIL] * wave_slots / 4u;
+    uint64_t r = (uint64_t)ctx->knobs[K_SPLIT_TAIL] * wave_slots / 4u;
+    if (r != 0u && r < n_tiles / 2u) r = n_tiles / 2u;
     return (uint32_t)(r < n_tiles ? r : n_tiles);
 }
 

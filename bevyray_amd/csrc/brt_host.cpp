@@ -554,12 +554,8 @@ void build_tile_order(const uint32_t* ray_sum, const uint32_t* longest, uint32_t
     if (p.sorted) std::sort(keys.begin(), keys.end());                         // longest first, then by index
     uint32_t k = 0;
     o.n_nonsky = (uint32_t)keys.size();
-    o.n_split = p.sorted ? (uint32_t)std::min<size_t>(p.split_tail, keys.size()) : 0u;
-    o.order.resize((size_t)n_tiles + o.n_split);
+    o.order.resize(n_tiles);
     for (uint64_t key : keys) o.order[k++] = (uint32_t)(key & 0xffffffffu);
-    for (uint32_t i = 0; i < o.n_split; i++) o.order[k++] = (uint32_t)(keys[keys.size() - o.n_split + i] & 0xffffffffu);
-    for (uint32_t tile = 0; tile < n_tiles; tile++)                            // sky tiles: raster order
-        if (is_sky[tile]) o.order[k++] = tile;
     o.n_lane = (uint32_t)((uint64_t)keys.size() * p.lane_permille / 1000u);
     if (o.n_lane > keys.size()) o.n_lane = (uint32_t)keys.size();
     if (p.sorted && p.critical && p.grid_lanes != 0) {
@@ -568,6 +564,12 @@ void build_tile_order(const uint32_t* ray_sum, const uint32_t* longest, uint32_t
         if (o.longest_pixel >= per_lane / 2)
             while (o.n_critical < keys.size() && rank[o.order[o.n_critical]] >= thr) o.n_critical++;
     }
+    // the second halves of the last n_split non-sky tiles (never of a critical tile: its wave's priority goes with the queue slot), then the sky tiles in raster order
+    o.n_split = p.sorted ? std::min(p.split_tail, o.n_nonsky - o.n_critical) : 0u;
+    o.order.resize((size_t)n_tiles + o.n_split);
+    for (uint32_t i = 0; i < o.n_split; i++) o.order[k++] = (uint32_t)(keys[keys.size() - o.n_split + i] & 0xffffffffu);
+    for (uint32_t tile = 0; tile < n_tiles; tile++)
+        if (is_sky[tile]) o.order[k++] = tile;
 }
 
 }  // namespace brt

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(OB) void k_order_prepare(const uint32_t* __restrict
         meta[0] = s_cnt[0];
         meta[1] = longest_pixel;
         meta[2] = s_ns[0];
-        meta[3] = split_tail < s_ns[0] ? split_tail : s_ns[0];
+        meta[3] = split_tail < s_ns[0] - s_cnt[0] ? split_tail : s_ns[0] - s_cnt[0];      // (never a critical tile: build_tile_order)
     }
 }
 

@@ -295,14 +295,18 @@ def test_dispatch_order_from_tile_costs():
     order3, info3 = _tile_order(ray_sum, longest, spp, lanes, sorted_=0)
     assert list(order3[:n - n_sky]) == sorted(order3[:n - n_sky]) and info3["n_critical"] == 0
     # half-sample jobs: the last k non-sky tiles appear twice -- [other non-sky | first halves | second halves | sky] -- k capped by the
-    # non-sky tiles; the order without the repeats is the plain order
+    # non-sky tiles that are not critical; the order without the repeats is the plain order
     for k in (0, 1, 37, n - n_sky, n):
         order4, info4 = _tile_order(ray_sum, longest, spp, lanes, split_tail=k)
-        ks = min(k, n - n_sky)
+        ks = min(k, n - n_sky - info4["n_critical"])     # (never a critical tile)
         assert info4["n_nonsky"] == n - n_sky and info4["n_split"] == ks and len(order4) == n + ks
         assert np.array_equal(order4[:n - n_sky], order[:n - n_sky])
         assert np.array_equal(order4[n - n_sky:n - n_sky + ks], order[n - n_sky - ks:n - n_sky])
         assert np.array_equal(order4[n - n_sky + ks:], order[n - n_sky:])
+    # a critical tile is never split
+    order6, info6 = _tile_order(ray_sum, longest, spp, int(ray_sum.sum()) // 200, split_tail=n)
+    assert info6["n_critical"] > 0 and info6["n_split"] == n - n_sky - info6["n_critical"]
+    assert np.array_equal(order6[n - n_sky:n - n_sky + info6["n_split"]], order[info6["n_critical"]:n - n_sky])
 
 
 def test_sah_builder_contract_depth_cap_and_determinism():
