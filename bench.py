@@ -542,7 +542,7 @@ def roofline_block(args, world, is_stub, kernel_ms, alg, workload, counted=None,
                     "the slowest rank's kernel time; peak = n_gpus x 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz (the guide's 2-cycle wave64 issue; "
                     "tests/tools/issue_bench.hip measures 2.2-2.4 cycles for the f32 add/mul/fma group in a pure stream and 4 for min/max, "
                     "compares, v_cndmask, conversions and integer multiplies, 8 for v_rcp/v_sqrt -- DESIGN.md section 5). The scene is LDS "
-                    "resident and ray state lives in registers, so HBM only sees the scene load per workgroup and one 16-B store per pixel: "
+                    "resident and ray state lives in registers, so HBM only sees the scene load per workgroup, one 16-B store per pixel and the 32-B pixel states that change hands between the two half-sample jobs of a tile (device-scope atomics, DESIGN.md section 6): "
                     "`traffic` (measured HBM bytes of the frame) / kernel time is `hbm_frac_measured` of the HBM peak; the SURVEY 8(d) "
                     "algorithmic bytes are informational (they are served from LDS/registers)",
             "counter_source": source, "counter_note": why}
