@@ -346,7 +346,7 @@ int32_t attach_tile_order(brt_ctx* ctx, DeviceCtx& dc, FrameParams& fp, hipStrea
             const bool fresh = bytes > dc.slice_state_cap;
             int32_t rc = ensure(ctx, &dc.d_slice_state, &dc.slice_state_cap, bytes);
             if (rc != BRT_OK) return rc;
-            if (fresh || dc.slice_serial == 0xffffffffu) {      // stamps of a new buffer (or after 2^32 launches) must not look valid
+            if (fresh || dc.slice_serial >= 0x3fffffffu) {      // flags of a new buffer (or after 2^30 launches: a flag holds serial << 2) must not look valid
                 HIP_TRY(ctx, hipMemsetAsync(dc.d_slice_state, 0, dc.slice_state_cap, stream));
                 dc.slice_serial = 0u;
             }
