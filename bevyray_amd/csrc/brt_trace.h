@@ -86,6 +86,12 @@ struct PixelState {
 // and the WAVE settles all of them in one go the next time it runs its management code (slice_settle, top of the kernel's loop).
 constexpr uint32_t kSliceFinal = 0u, kSliceFirst = 1u, kSliceDone = 3u, kSliceShift = 30u, kTileMask = 0x3fffffffu;
 constexpr uint32_t kSliceReady = 1u, kSliceGaveUp = 2u;      // flag word = serial << 2 | one of these
+#ifndef BRT_SLICE_EIGHTHS
+#define BRT_SLICE_EIGHTHS 4
+#endif
+// where a split tile's first job ends (samples).  Shorter last jobs -- 5/8, 6/8, 7/8 -- measured: config 2 9.14 / 9.14 / 9.20 against 9.14-9.19 at
+// the half, config 5 16.9-17.5 at 6/8 against 16.7-16.9 (profiles/r04/split_tail.txt)
+BRT_DEV uint32_t slice_point(const FrameParams& fp) { return (uint32_t)(((uint64_t)fp.sample_count * BRT_SLICE_EIGHTHS) >> 3); }
 
 BRT_DEV uint32_t slice_xchg(uint32_t* p, uint32_t v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 BRT_DEV uint32_t slice_read(uint32_t* p) { return __hip_atomic_fetch_add(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -113,7 +119,7 @@ BRT_DEV bool slice_load(const FrameParams& fp, PixelState& ps, uint32_t* rays_be
     ps.sum = mk3(__uint_as_float(slice_read(rec + 1)), __uint_as_float(slice_read(rec + 2)), __uint_as_float(slice_read(rec + 3)));
     ps.dsum = __uint_as_float(slice_read(rec + 4));
     *rays_before = slice_read(rec + 5);
-    ps.sample = fp.sample_count / 2u;
+    ps.sample = slice_point(fp);
     return true;
 }
 
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             ps.sample_end = fp.sample_count;
             bool taken = true;                          // (a second-half lane whose first half is not there yet leaves the pixel alone)
             if (slices && first_half) {
-                ps.sample_end = fp.sample_count / 2u;
+                ps.sample_end = slice_point(fp);
                 ps.tile |= kSliceFirst << kSliceShift;
             } else if (slices && second_half) {
                 uint32_t rays_before = 0u;
@@ -695,7 +701,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                         ps.rng = __float_as_uint(r1.z); ps.sample = __float_as_uint(r1.w);
                         ps.out_index = __float_as_uint(r2.x); ps.frame_index = __float_as_uint(r2.y);
                         ps.tile = __float_as_uint(r2.z); ps.rays_begin = n_rays - __float_as_uint(r2.w);
-                        ps.sample_end = (ps.tile >> kSliceShift) == kSliceFirst ? fp.sample_count / 2u : fp.sample_count;
+                        ps.sample_end = (ps.tile >> kSliceShift) == kSliceFirst ? slice_point(fp) : fp.sample_count;
                         o = mk3(r3.x, r3.y, r3.z); d = mk3(r3.w, r4.x, r4.y); tput = mk3(r4.z, r4.w, r5.x);
                         bounce = __float_as_uint(r5.y); first_depth = r5.z;
                         crit = (__float_as_uint(r5.w) & 1u) != 0u; need_cam = (__float_as_uint(r5.w) & 2u) != 0u;
