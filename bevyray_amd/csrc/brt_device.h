@@ -579,6 +579,9 @@ BRT_DEV void walk_loop_wave(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, ui
 #ifndef BRT_WALK_FAST
 #define BRT_WALK_FAST BRT_HAND_ASM
 #endif
+#ifndef BRT_WALK_FAST_TOP
+#define BRT_WALK_FAST_TOP 1   // the hand-written loop also for scenes walked from the LDS tile + global memory (walk_wave_top_asm)
+#endif
 // The whole wave-level walk loop (walk_loop_wave's nest: interior steps until `vote` lanes wait at a leaf, one leaf step,
 // until at most exit_at lanes still walk) as ONE block of hand-scheduled code.
 //   cur / spa     descriptor of the lane's current node (sign-extended 16-bit form: interior >= 0, leaf < -1, DONE = -1) and
@@ -752,6 +755,178 @@ BRT_DEV void walk_wave_lds_asm(uint32_t& cur, uint32_t& spa, float& closest, uin
 #endif
 }
 
+// The same loop for scenes that do not fit the LDS (SCENE_LDS_TOP: the top of the tree -- the records below byte offset near_bytes -- in the
+// LDS tile at address 0, the rest and the spheres in global memory; SCENE_GLOBAL: near_bytes = 0).  An interior step reads its record
+// from the tile or from the global array, lane by lane (two EXEC masks, one destination); the loads are waited for together, the
+// arithmetic is walk_wave_lds_asm's.  The compiler's loop for these modes (walk_loop_wave) spends ~8 branch instructions and six selects
+// per step: 1.03 G branches on the 10 004-sphere frame against 0.38 G on the cover frame.
+BRT_DEV void walk_wave_top_asm(uint32_t& cur, uint32_t& spa, float& closest, uint32_t& closest_idx, uint32_t gofs_x, uint32_t gofs_y,
+                               uint32_t gofs_z, f3 o, f3 inv, f3 d, float a, uint32_t near_bytes, uint64_t far, uint64_t sphg,
+                               uint32_t exit_at, uint32_t vote) {
+#if BRT_HAND_ASM
+    uint32_t t0, tx, ty, tz, pop, cnt, nw, thr;
+    float below;
+    uint64_t s_all, s_take, s_p2, s_any, s_both;
+    const uint32_t rec_bytes = PAIR_BYTES, c_tiny = 0x0f800000u /* 2^-96 */, c_eps = 0x3a83126fu /* 0.001f */, c_cls = 0x260u /* +-0, +inf */;
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n"                                // nothing of the compiler's in flight: the counted waits below are exact
+        "s_mov_b64 %[s_all], exec\n"
+        "v_add_u32_e32 %[below], -1, %[closest]\n"              // the largest float below closest (closest is FLT_MAX or an accepted t > 0)
+        // ---- outer loop: leave when at most exit_at lanes still walk -------------------------------------------------------
+        "3:\n"
+        "v_cmp_ne_u32_e32 vcc, -1, %[cur]\n"
+        "s_bcnt1_i32_b64 %[nw], vcc\n"
+        "s_cmp_le_u32 %[nw], %[exit_at]\n"
+        "s_cbranch_scc1 9f\n"
+        "s_max_u32 %[thr], %[nw], %[vote]\n"                    // interior steps while more than max(walking, vote) - vote lanes are at one
+        "s_sub_u32 %[thr], %[thr], %[vote]\n"
+        "v_cmp_lt_i32_e32 vcc, -1, %[cur]\n"                    // interior descriptors are >= 0
+        "s_bcnt1_i32_b64 %[cnt], vcc\n"
+        "s_cmp_le_u32 %[cnt], %[thr]\n"
+        "s_cbranch_scc1 5f\n"
+        // ---- interior steps ----------------------------------------------------------------------------------------------------
+        "1:\n"
+        "s_mov_b64 %[s_take], vcc\n"
+        "s_mov_b64 exec, vcc\n"
+        "ds_read_i16 %[pop], %[spa]\n"                          // the would-be pop: needs no address arithmetic, goes out first
+        "v_mul_lo_u32 %[t0], %[cur], %[rec_bytes]\n"
+        "v_add_u32_e32 %[tx], %[t0], %[gofs_x]\n"
+        "v_add_u32_e32 %[ty], %[t0], %[gofs_y]\n"
+        "v_add_u32_e32 %[tz], %[t0], %[gofs_z]\n"
+        "v_cmp_le_u32_e32 vcc, %[near_bytes], %[t0]\n"          // the record is only in the global array (L2): those loads go out first ...
+        "s_and_b64 exec, %[s_take], vcc\n"
+        "s_cbranch_execz 6f\n"
+        "global_load_dwordx4 v[100:103], %[tx], %[far]\n"       // { near L, near R, far L, far R } per axis
+        "global_load_dwordx4 v[104:107], %[ty], %[far]\n"
+        "global_load_dwordx4 v[108:111], %[tz], %[far]\n"
+        "global_load_dwordx2 v[112:113], %[t0], %[far] offset:96\n"   // descriptors of L and R
+        "6:\n"
+        "s_andn2_b64 exec, %[s_take], vcc\n"                    // ... or in the LDS tile (the top of the tree)
+        "s_cbranch_execz 7f\n"
+        "ds_read_b128 v[100:103], %[tx]\n"
+        "ds_read_b128 v[104:107], %[ty]\n"
+        "ds_read_b128 v[108:111], %[tz]\n"
+        "ds_read_b64 v[112:113], %[t0] offset:96\n"
+        "7:\n"
+        "s_mov_b64 exec, %[s_take]\n"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+        "v_sub_f32_e32 v100, v100, %[ox]\n v_sub_f32_e32 v101, v101, %[ox]\n v_sub_f32_e32 v102, v102, %[ox]\n v_sub_f32_e32 v103, v103, %[ox]\n"
+        "v_mul_f32_e32 v100, v100, %[ix]\n v_mul_f32_e32 v101, v101, %[ix]\n v_mul_f32_e32 v102, v102, %[ix]\n v_mul_f32_e32 v103, v103, %[ix]\n"
+        "v_sub_f32_e32 v104, v104, %[oy]\n v_sub_f32_e32 v105, v105, %[oy]\n v_sub_f32_e32 v106, v106, %[oy]\n v_sub_f32_e32 v107, v107, %[oy]\n"
+        "v_mul_f32_e32 v104, v104, %[iy]\n v_mul_f32_e32 v105, v105, %[iy]\n v_mul_f32_e32 v106, v106, %[iy]\n v_mul_f32_e32 v107, v107, %[iy]\n"
+        "v_sub_f32_e32 v108, v108, %[oz]\n v_sub_f32_e32 v109, v109, %[oz]\n v_sub_f32_e32 v110, v110, %[oz]\n v_sub_f32_e32 v111, v111, %[oz]\n"
+        "v_mul_f32_e32 v108, v108, %[iz]\n v_mul_f32_e32 v109, v109, %[iz]\n v_mul_f32_e32 v110, v110, %[iz]\n v_mul_f32_e32 v111, v111, %[iz]\n"
+        "v_max_f32_e32 v100, v100, v104\n"
+        "v_max_f32_e32 v101, v101, v105\n"
+        "v_min_f32_e32 v102, v102, v106\n"
+        "v_min_f32_e32 v103, v103, v107\n"
+        "v_max3_f32 v100, v100, v108, 1\n"                      // t_near = max(.., denorm_min)
+        "v_max3_f32 v101, v101, v109, 1\n"
+        "v_min3_f32 v102, v102, v110, %[below]\n"               // t_far = min(.., below(closest))
+        "v_min3_f32 v103, v103, v111, %[below]\n"
+        "ds_write_b16 %[spa], v112 offset:128\n"                // child L above the top: dead unless both are pushed
+        "v_cmp_le_f32_e32 vcc, v100, v102\n"                    // p1: child L is pushed (raytrace.wgsl:331)
+        "v_cmp_le_f32_e64 %[s_p2], v101, v103\n"                // p2: child R is pushed (raytrace.wgsl:338)
+        "s_or_b64 %[s_any], vcc, %[s_p2]\n"
+        "s_and_b64 %[s_both], vcc, %[s_p2]\n"
+        "s_andn2_b64 exec, %[s_take], %[s_any]\n"               // no child pushed: pop
+        "v_mov_b32_e32 %[cur], %[pop]\n"
+        "v_add_u32_e32 %[spa], 0xffffff80, %[spa]\n"
+        "s_andn2_b64 exec, vcc, %[s_p2]\n"                      // only L
+        "v_mov_b32_e32 %[cur], v112\n"
+        "s_mov_b64 exec, %[s_p2]\n"                             // R (pushed last, popped first)
+        "v_mov_b32_e32 %[cur], v113\n"
+        "s_mov_b64 exec, %[s_both]\n"                           // both: L stays on the stack
+        "v_add_u32_e32 %[spa], 0x80, %[spa]\n"
+        "s_mov_b64 exec, %[s_all]\n"
+        "v_cmp_lt_i32_e32 vcc, -1, %[cur]\n"
+        "s_bcnt1_i32_b64 %[cnt], vcc\n"
+        "s_cmp_gt_u32 %[cnt], %[thr]\n"
+        "s_cbranch_scc1 1b\n"
+        // ---- one leaf step for every lane that waits at a leaf --------------------------------------------------------------
+        "5:\n"
+        "v_cmp_gt_i32_e32 vcc, -1, %[cur]\n"                    // leaf descriptors are < -1
+        "s_and_b64 exec, %[s_all], vcc\n"
+        "v_and_b32_e32 v112, 0x3fff, %[cur]\n"                  // the leaf's sphere
+        "v_lshlrev_b32_e32 %[t0], 4, v112\n"
+        "global_load_dwordx4 v[100:103], %[t0], %[sphg]\n"      // { centre, r^2 }
+        "ds_read_i16 %[cur], %[spa]\n"                          // pop
+        "s_waitcnt vmcnt(0)\n"
+        "v_sub_f32_e32 v104, v100, %[ox]\n"                     // oc = centre - origin
+        "v_sub_f32_e32 v105, v101, %[oy]\n"
+        "v_sub_f32_e32 v106, v102, %[oz]\n"
+        "v_mul_f32_e32 v107, %[dx], v104\n"                     // h = dot(d, oc) = (dx ocx + dy ocy) + dz ocz
+        "v_mul_f32_e32 v108, %[dy], v105\n"
+        "v_mul_f32_e32 v104, v104, v104\n"                      // dot(oc, oc)
+        "v_mul_f32_e32 v105, v105, v105\n"
+        "v_add_f32_e32 v104, v104, v105\n"
+        "v_mul_f32_e32 v105, v106, v106\n"
+        "v_mul_f32_e32 v109, %[dz], v106\n"
+        "v_add_f32_e32 v107, v107, v108\n"
+        "v_add_f32_e32 v104, v105, v104\n"
+        "v_add_f32_e32 v107, v109, v107\n"                      // h
+        "v_sub_f32_e32 v104, v104, v103\n"                      // c = dot(oc, oc) - r^2
+        "v_mul_f32_e32 v105, v107, v107\n"                      // h h
+        "v_mul_f32_e32 v104, %[a], v104\n"                      // a c
+        "v_sub_f32_e32 v104, v105, v104\n"                      // discriminant
+        // sqrt(discriminant), correctly rounded: hipcc's expansion (a negative argument gives NaN, rejected below like the
+        // shader's -1).  Same operations on the same values as the compiler emits; the order is chosen so that every wait
+        // state its hazard recogniser fills with s_nop (VALU -> vcc / SGPR -> v_cndmask: 2, v_sqrt / v_rcp -> use: 1) holds
+        // an instruction that is needed anyway.
+        "v_cmp_gt_f32_e32 vcc, %[c_tiny], v104\n"               // below 2^-96: scale by 2^32 (vcc stays until the result is scaled back)
+        "v_mul_f32_e32 v105, 0x4f800000, v104\n"
+        "v_add_u32_e32 %[spa], 0xffffff80, %[spa]\n"            // (the pop's pointer move)
+        "v_cndmask_b32_e32 v104, v104, v105, vcc\n"
+        "v_sqrt_f32_e32 v105, v104\n"                           // s
+        "v_cmp_class_f32_e64 %[s_both], v104, %[c_cls]\n"       // +-0 and +inf are their own roots
+        "v_add_u32_e32 v106, -1, v105\n"                        // s - 1 ulp
+        "v_add_u32_e32 v109, 1, v105\n"                         // s + 1 ulp
+        "v_fma_f32 v108, -v106, v105, v104\n"                   // x - (s - 1 ulp) s
+        "v_fma_f32 v110, -v109, v105, v104\n"                   // x - (s + 1 ulp) s
+        "v_cmp_ge_f32_e64 %[s_p2], 0, v108\n"
+        "v_cmp_lt_f32_e64 %[s_any], 0, v110\n"
+        "s_nop 0\n"                                             // (the one wait state left over)
+        "v_cndmask_b32_e64 v106, v105, v106, %[s_p2]\n"
+        "v_cndmask_b32_e64 v105, v106, v109, %[s_any]\n"
+        "v_mul_f32_e32 v106, 0x37800000, v105\n"
+        "v_cndmask_b32_e32 v105, v105, v106, vcc\n"
+        "v_cndmask_b32_e64 v104, v105, v104, %[s_both]\n"
+        "v_sub_f32_e32 v104, v107, v104\n"                      // h - sqrt(discriminant)
+        // ... / a, correctly rounded: hipcc's expansion
+        "v_div_scale_f32 v105, %[s_p2], %[a], %[a], v104\n"
+        "v_rcp_f32_e32 v106, v105\n"
+        "v_div_scale_f32 v107, vcc, v104, %[a], v104\n"
+        "v_fma_f32 v109, -v105, v106, 1.0\n"
+        "v_fmac_f32_e32 v106, v109, v106\n"
+        "v_mul_f32_e32 v108, v107, v106\n"
+        "v_fma_f32 v109, -v105, v108, v107\n"
+        "v_fmac_f32_e32 v108, v109, v106\n"
+        "v_fma_f32 v105, -v105, v108, v107\n"
+        "v_div_fmas_f32 v105, v105, v106, v108\n"
+        "v_div_fixup_f32 v104, v105, %[a], v104\n"              // t
+        // accepted iff t > 0.001 && t < closest (raytrace.wgsl:353-354; strict: the first sphere reached wins ties)
+        "v_cmp_lt_f32_e32 vcc, %[c_eps], v104\n"
+        "v_cmp_lt_f32_e64 %[s_p2], v104, %[closest]\n"
+        "s_and_b64 exec, vcc, %[s_p2]\n"
+        "v_mov_b32_e32 %[closest], v104\n"
+        "v_mov_b32_e32 %[cidx], v112\n"
+        "v_add_u32_e32 %[below], -1, v104\n"
+        "s_mov_b64 exec, %[s_all]\n"
+        "s_waitcnt lgkmcnt(0)\n"                                // the pop has long arrived; the next test reads it
+        "s_branch 3b\n"
+        "9:\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        : [cur] "+v"(cur), [spa] "+v"(spa), [closest] "+v"(closest), [cidx] "+v"(closest_idx), [below] "=&v"(below), [t0] "=&v"(t0),
+          [tx] "=&v"(tx), [ty] "=&v"(ty), [tz] "=&v"(tz), [pop] "=&v"(pop), [cnt] "=&s"(cnt), [nw] "=&s"(nw), [thr] "=&s"(thr),
+          [s_all] "=&s"(s_all), [s_take] "=&s"(s_take), [s_p2] "=&s"(s_p2), [s_any] "=&s"(s_any), [s_both] "=&s"(s_both)
+        : [gofs_x] "v"(gofs_x), [gofs_y] "v"(gofs_y), [gofs_z] "v"(gofs_z), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [ix] "v"(inv.x),
+          [iy] "v"(inv.y), [iz] "v"(inv.z), [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z), [a] "v"(a), [near_bytes] "s"(near_bytes), [far] "s"(far), [sphg] "s"(sphg), [exit_at] "s"(exit_at),
+          [vote] "s"(vote), [rec_bytes] "s"(rec_bytes), [c_tiny] "s"(c_tiny), [c_eps] "s"(c_eps), [c_cls] "s"(c_cls)
+        : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112",
+          "v113");
+#endif
+}
+
 template <bool D16, bool SIMPLE_TREE, typename StackT>
 BRT_DEV void walk_loop_wave_lds(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, uint32_t ox, uint32_t oy, uint32_t oz,
                                 float& closest, uint32_t& closest_idx, uint32_t& cur, StackT*& sp, uint32_t& n,
@@ -764,6 +939,20 @@ BRT_DEV void walk_loop_wave_lds(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv
     //  counts the leaf lanes instead; the rules differ only when a lane ends its walk inside a run of interior steps, and only
     //  in when the leaf step runs)
     walk_wave_lds_asm(cur, spa, closest, closest_idx, ox, oy, oz, o, inv, d, a, sph, exit_at, vote);
+    sp = (StackT*)reinterpret_cast<lds_stack*>((uintptr_t)spa);
+}
+
+// ... and of a scene walked from the tile / from global memory (walk_wave_top_asm)
+template <bool D16, bool SIMPLE_TREE, int MODE, typename StackT>
+BRT_DEV void walk_loop_wave_top(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, uint32_t ox, uint32_t oy, uint32_t oz,
+                                float& closest, uint32_t& closest_idx, uint32_t& cur, StackT*& sp, uint32_t& n,
+                                uint32_t exit_at, uint32_t vote, HitCounters& hc) {
+    static_assert(D16 && SIMPLE_TREE && sizeof(StackT) == 2 && MODE != SCENE_LDS, "16-bit descriptors, no overflow rule, no leaf table");
+    typedef __attribute__((address_space(3))) StackT lds_stack;
+    uint32_t spa = (uint32_t)(uintptr_t)(lds_stack*)sp;
+    const uint32_t near_bytes = MODE == SCENE_LDS_TOP ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.near_bytes) : 0u;
+    const uint64_t far = (uint64_t)(uintptr_t)sc.pairs_far, sphg = (uint64_t)(uintptr_t)sc.spheres;
+    walk_wave_top_asm(cur, spa, closest, closest_idx, ox, oy, oz, o, inv, d, a, near_bytes, far, sphg, exit_at, vote);
     sp = (StackT*)reinterpret_cast<lds_stack*>((uintptr_t)spa);
 }
 
@@ -811,8 +1000,11 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, f3
             if (any_unsafe)
                 walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, true, MODE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp,
                                                                        n, exit_at, vote, hc);
+            constexpr bool kByHandTop = BRT_WALK_FAST && BRT_WALK_FAST_TOP && MODE != SCENE_LDS && !COUNTERS && SIMPLE_TREE && D16;
             if constexpr (kByHand)
                 walk_loop_wave_lds<D16, SIMPLE_TREE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp, n, exit_at, vote, hc);
+            else if constexpr (kByHandTop)
+                walk_loop_wave_top<D16, SIMPLE_TREE, MODE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp, n, exit_at, vote, hc);
             else if (!any_unsafe)
                 walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, false, MODE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp,
                                                                         n, exit_at, vote, hc);

@@ -850,8 +850,8 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
 template <int MODE, bool D, bool S, bool C, bool T, int LEAN = 0>
 static hipError_t launch_persistent_t(const TraceLaunch& tl) {
     auto kern = k_trace_persistent<MODE, D, S, C, T, LEAN>;
-    if (MODE == SCENE_LDS) {
-        // the hand-written walk loop (walk_wave_lds_asm) addresses the pair records from LDS address 0: the dynamic LDS must start there
+    if (MODE == SCENE_LDS || MODE == SCENE_LDS_TOP) {
+        // the hand-written walk loops (walk_wave_lds_asm, walk_wave_top_asm) address the pair records from LDS address 0: the dynamic LDS must start there
         static const size_t static_lds = [&] {
             hipFuncAttributes at{};
             return hipFuncGetAttributes(&at, reinterpret_cast<const void*>(kern)) == hipSuccess ? at.sharedSizeBytes : (size_t)1;

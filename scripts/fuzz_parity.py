@@ -187,7 +187,7 @@ def main():
         return got, node.last_stats
     rng = np.random.default_rng(args.seed)
     t_start = time.time()
-    fails, done, pixels, rays, ploc_checked, rejected, tight_checked, split_checked = 0, 0, 0, 0, 0, 0, 0, 0
+    fails, done, pixels, rays, ploc_checked, rejected, tight_checked, split_checked, prod_checked = 0, 0, 0, 0, 0, 0, 0, 0, 0
     lines = []
     t_progress = time.time()
     for case in range(args.cases):
@@ -239,13 +239,16 @@ def main():
             bad = frames_differ(got, want)
             if bad:
                 raise AssertionError(f"{bad} of {got.size} frame values differ")
-            if "BRT_SPLIT_FORCE" in variant and c["mode"] not in ("multi", "simple", "parts"):
-                for rep in range(2):      # (the second frame runs in the order the first one measured)
+            if c["mode"] not in ("multi", "simple", "parts"):
+                # the same frame from the production instantiation (the hand-written walk loops and the half-sample jobs only run there):
+                # frame + ray count; with forced half-sample jobs twice (the second frame runs in the order the first one measured)
+                for rep in range(2 if "BRT_SPLIT_FORCE" in variant else 1):
                     got2, st2 = render(c, b, counters=False)
                     bad = frames_differ(got2, want)
                     if bad or st2["rays"] != cnt["rays"]:
-                        raise AssertionError(f"half-sample jobs: {bad} of {got2.size} frame values differ, rays {st2['rays']} vs {cnt['rays']}")
-                split_checked += 1
+                        raise AssertionError(f"production instantiation: {bad} of {got2.size} frame values differ, rays {st2['rays']} vs {cnt['rays']}")
+                prod_checked += 1
+                split_checked += 1 if "BRT_SPLIT_FORCE" in variant else 0
             # the callee's SAH tree pads its leaf boxes by less than the reference's 0.1 (brt_sah.h sah_model_pad): on well-conditioned scenes
             # without coincident spheres (exact ties are decided by the visiting order) the frame must also be the one of the caller's
             # 0.1-padded PLOC tree -- i.e. the tighter boxes culled nothing a ray is accepted by.  Well-conditioned = no sphere of radius
@@ -278,7 +281,7 @@ def main():
                      window=np.asarray(c["window"]).view(np.uint8), size=np.array([c["w"], c["h"]]),
                      raster=np.zeros(0) if c["raster"] is None else c["raster"], depth=np.zeros(0) if c["depth"] is None else c["depth"])
     summary = (f"fuzz_parity seed {args.seed}: {done} cases bit-exact (frames + 5 counters), {fails} failed, {rejected} refused; "
-               f"{pixels} pixels, {rays} rays; {ploc_checked} callee-built trees byte-identical CPU vs GPU, {tight_checked} tight-box SAH frames equal to the PLOC-tree frame, {split_checked} cases also through half-sample jobs (frame + rays, twice); "
+               f"{pixels} pixels, {rays} rays; {ploc_checked} callee-built trees byte-identical CPU vs GPU, {tight_checked} tight-box SAH frames equal to the PLOC-tree frame, {prod_checked} cases also in the production instantiation (frame + rays), {split_checked} of them through half-sample jobs; "
                f"{time.time() - t_start:.0f} s")
     print(summary, flush=True)
     if args.log:
