@@ -809,11 +809,15 @@ BRT_DEV void walk_wave_top_asm(uint32_t& cur, uint32_t& spa, float& closest, uin
         "ds_read_b64 v[112:113], %[t0] offset:96\n"
         "7:\n"
         "s_mov_b64 exec, %[s_take]\n"
-        "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+        // (counted waits that hold for every mix: the LDS queue is {pop, x, y, z, descriptors} or just {pop}, the vector-memory queue {x, y, z,
+        //  descriptors} or empty -- a lane's x granule has arrived when at most 3 are outstanding in BOTH)
+        "s_waitcnt vmcnt(3) lgkmcnt(3)\n"
         "v_sub_f32_e32 v100, v100, %[ox]\n v_sub_f32_e32 v101, v101, %[ox]\n v_sub_f32_e32 v102, v102, %[ox]\n v_sub_f32_e32 v103, v103, %[ox]\n"
         "v_mul_f32_e32 v100, v100, %[ix]\n v_mul_f32_e32 v101, v101, %[ix]\n v_mul_f32_e32 v102, v102, %[ix]\n v_mul_f32_e32 v103, v103, %[ix]\n"
+        "s_waitcnt vmcnt(2) lgkmcnt(2)\n"
         "v_sub_f32_e32 v104, v104, %[oy]\n v_sub_f32_e32 v105, v105, %[oy]\n v_sub_f32_e32 v106, v106, %[oy]\n v_sub_f32_e32 v107, v107, %[oy]\n"
         "v_mul_f32_e32 v104, v104, %[iy]\n v_mul_f32_e32 v105, v105, %[iy]\n v_mul_f32_e32 v106, v106, %[iy]\n v_mul_f32_e32 v107, v107, %[iy]\n"
+        "s_waitcnt vmcnt(1) lgkmcnt(1)\n"
         "v_sub_f32_e32 v108, v108, %[oz]\n v_sub_f32_e32 v109, v109, %[oz]\n v_sub_f32_e32 v110, v110, %[oz]\n v_sub_f32_e32 v111, v111, %[oz]\n"
         "v_mul_f32_e32 v108, v108, %[iz]\n v_mul_f32_e32 v109, v109, %[iz]\n v_mul_f32_e32 v110, v110, %[iz]\n v_mul_f32_e32 v111, v111, %[iz]\n"
         "v_max_f32_e32 v100, v100, v104\n"
@@ -824,6 +828,7 @@ BRT_DEV void walk_wave_top_asm(uint32_t& cur, uint32_t& spa, float& closest, uin
         "v_max3_f32 v101, v101, v109, 1\n"
         "v_min3_f32 v102, v102, v110, %[below]\n"               // t_far = min(.., below(closest))
         "v_min3_f32 v103, v103, v111, %[below]\n"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n"                       // descriptors (and the pop, which went out first) are here
         "ds_write_b16 %[spa], v112 offset:128\n"                // child L above the top: dead unless both are pushed
         "v_cmp_le_f32_e32 vcc, v100, v102\n"                    // p1: child L is pushed (raytrace.wgsl:331)
         "v_cmp_le_f32_e64 %[s_p2], v101, v103\n"                // p2: child R is pushed (raytrace.wgsl:338)
