@@ -390,6 +390,9 @@ BRT_DEV uint32_t pool_peek(const uint32_t* ctl, int i) { return __atomic_load_n(
 // LEAN: what the steady-state frame of a Pure-level view needs and nothing else, so that the other checks, registers
 // and kernel arguments leave the round loop.  1: level 3 (no raster inputs, no depth average); 2: also no critical tiles (the host can rule them out: launch_part).  (A/B at the time it went in, round 2:
 // headline frame 12.87 (0) -> 12.73 (1) -> 12.59 ms (2); current timings: docs/experiments.md.)
+#ifndef BRT_PRIO_TOP
+#define BRT_PRIO_TOP 1   // the phase priorities also for scenes walked from the LDS tile + global memory (k_trace_persistent, kPhasePrio)
+#endif
 template <int MODE, bool D16, bool SIMPLE, bool COUNTERS, bool TUNABLE, int LEAN>
 __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView sv, FrameParams fp,
                                                                 uint32_t* __restrict__ queue_counter,
@@ -734,8 +737,9 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         // shading.  The walk is where the LDS round trips are (a step cannot start before the one before it has chosen its node), the
         // shading code is arithmetic that fills the slots those leave; without it the four waves of a SIMD take turns by age and a
         // walking wave waits behind a shading one with its next read not even issued.  (Critical waves stay at 3, FrameParams::crit_*.
-        // Scenes walked from L2 -- config 5 -- lose 2 % with it: there a walking wave mostly waits, whatever its priority.)
-        constexpr int kPhasePrio = MODE == SCENE_LDS ? BRT_PHASE_PRIO_AT : 0;
+        // Scenes walked from L2 -- config 5 -- lost 2 % with it under the compiler's walk loop; under the hand-written one they gain 2-3 %:
+        // 15.1 -> 14.8 ms, profiles/r04/ab_walk_top.txt.)
+        constexpr int kPhasePrio = (MODE == SCENE_LDS || BRT_PRIO_TOP) ? BRT_PHASE_PRIO_AT : 0;
         if (kPhasePrio == 2 && !wave_crit) __builtin_amdgcn_s_setprio(1);
         prof_section<COUNTERS>(hc, SEC_CAMERA_TOP, fresh && need_cam);
         if (fresh && bounce == 0) {
