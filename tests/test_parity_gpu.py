@@ -1319,6 +1319,22 @@ def test_half_sample_jobs_hand_the_pixel_state_over_without_changing_pixels_or_r
                 assert_frames_equal(got, want)
                 assert {k: p.node.last_stats[k] for k in COUNTER_KEYS} == cnt
     assert seen["left"] > 0, seen
+    # the depth blend levels (the general instantiation: the depth sum is part of the state that changes hands), with raster inputs
+    w, h, spp = 200, 120, 32
+    rng = np.random.default_rng(11)
+    raster = rng.random((h, w, 4), dtype=np.float32)
+    depth = rng.random((h, w), dtype=np.float32) * np.float32(0.02)
+    for level in (brt.Raytracing.FallbackRaster, brt.Raytracing.FallbackRaytraced):
+        lvl, cam, win = brt.cover_camera(w, h, spp, 4, level, 0.5)
+        want, cnt = oracle.render(b, lvl, cam, win, w, h, raster_rgba=raster, raster_depth=depth)
+        with brt.RaytracePlugin([0]) as p:
+            p.set_tuning("BRT_SPLIT_FORCE", 150)
+            for frame in range(3):
+                got = p.node.run(lvl, cam, win, w, h, buffers=b if frame == 0 else None, raster_rgba=raster, raster_depth=depth)
+                assert_frames_equal(got, want)
+                assert p.node.last_stats["rays"] == cnt["rays"]
+            p.debug_profile()
+            assert p.last_order_meta["split_tiles"] > 0
     # a frame of many tiles per wave slot, default settings: the second halves come up long after the first ones and take the states over
     w, h, spp, bounces = 1920, 1080, 16, 2
     lvl, cam, win = brt.cover_camera(w, h, spp, bounces)
