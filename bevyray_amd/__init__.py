@@ -11,7 +11,7 @@ from .raytracing import (  # noqa: F401
     BVH_NODE_DTYPE, CAMERA_DTYPE, EXTMEM_DMABUF_FD, EXTMEM_OPAQUE_FD, FLAG_CALLER_STREAM, FLAG_COUNTERS, FLAG_KERNEL_SIMPLE, POLICY_OR_SHORT_CIRCUIT, LEVEL_DTYPE, MATERIAL_DTYPE, MODEL_DTYPE,
     SCENE_COVER, SCENE_RTIOW_FINAL, SCENE_STRESS_GRID, STRIP_ROWS, WINDOW_DTYPE, Buffers, CameraExtract,
     OrthographicProjection, PerspectiveProjection, RaytracedCamera, RaytracedSphere, RaytraceMaterial, RaytracePlugin,
-    Raytracing, RayTracingNode, StandardMaterial, Transform, WindowExtract, build_bvh, build_bvh_sah, cover_camera, generate_scene,
+    Raytracing, RayTracingNode, StandardMaterial, Transform, WindowExtract, build_bvh, build_bvh_sah, cover_camera, generate_scene, tree_reach,
     prepare_buffers, rtiow_camera, tile_rows, validate_scene,
 )
 

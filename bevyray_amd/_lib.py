@@ -29,6 +29,7 @@ class BrtStats(C.Structure):
         ("lds_bytes", C.c_uint32), ("scene_in_lds", C.c_uint32), ("n_workgroups", C.c_uint32),
         ("threads_per_workgroup", C.c_uint32), ("prepass_ms", C.c_double),
         ("kernel_variant", C.c_uint32), ("measured_tile_costs", C.c_uint32),
+        ("tree_rebuilt", C.c_uint32), ("tree_reach", C.c_float), ("forwarded_bytes", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -87,9 +88,10 @@ _PROTOTYPES = {
     "brt_debug_profile": (_I32, [_VP, C.POINTER(C.c_uint64)]),
     "brt_debug_tile_order": (_I32, [_VP, _VP, _VP, _U32, _U32, C.c_uint64, _U32, _U32, _U32, _VP, _VP]),
     "brt_build_bvh": (_I32, [_VP, _U32, _VP, _U32, C.POINTER(_U32)]),
-    "brt_build_bvh_sah": (_I32, [_VP, _U32, _VP, _U32, C.POINTER(_U32)]),
+    "brt_build_bvh_sah": (_I32, [_VP, _U32, _F, _VP, _U32, C.POINTER(_U32)]),
+    "brt_host_tree_reach": (_I32, [_VP, _U32, _VP, C.POINTER(_F), C.POINTER(_U32), C.POINTER(_F)]),
     "brt_build_bvh_device": (_I32, [_VP, _VP, _U32, _VP, _U32, C.POINTER(_U32), C.POINTER(C.c_double)]),
-    "brt_build_bvh_sah_device": (_I32, [_VP, _VP, _U32, _VP, _U32, C.POINTER(_U32), C.POINTER(C.c_double)]),
+    "brt_build_bvh_sah_device": (_I32, [_VP, _VP, _U32, _F, _VP, _U32, C.POINTER(_U32), C.POINTER(C.c_double)]),
     "brt_validate_scene": (_I32, [_VP, _U32, _VP, _U32, _VP, _U32, C.POINTER(_U32)]),
     "brt_scene_generate": (_I32, [_U32, C.c_uint64, _VP, _VP, _U32, C.POINTER(_U32)]),
     "brt_host_camera_extract": (_I32, [C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _F, _F, _F, _F, _U32, _U32, _VP]),
@@ -127,7 +129,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.brt_abi_version() != 4:
+    if lib.brt_abi_version() != 5:
         raise RuntimeError("libbevyray_amd.so ABI version mismatch")
     _lib = lib
     return lib

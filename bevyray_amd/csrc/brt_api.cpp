@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "brt_ctx.h"
+#include "brt_sah.h"
 
 using namespace brt;
 
@@ -612,7 +613,7 @@ constexpr uint32_t kMaxGpuBuildModels = 1u << 24;   // scratch ~ 250 B per spher
 
 // A BVH built on the context's first device: models (host) -> nodes (host vector), kernel time in ms.  sah: the binned-SAH tree of
 // brt_sah.h (brt_sah.hip), else PLOC (brt_bvh.hip); each byte-identical to its CPU twin.
-int32_t build_bvh_on_device(brt_ctx* ctx, const Model* models, uint32_t n, bool sah, std::vector<BVHNode>* out, double* build_ms) {
+int32_t build_bvh_on_device(brt_ctx* ctx, const Model* models, uint32_t n, bool sah, float reach, std::vector<BVHNode>* out, double* build_ms) {
     out->clear();
     if (n == 0) return BRT_OK;
     if (n > (sah ? kMaxSahModels : kMaxGpuBuildModels))
@@ -628,7 +629,7 @@ int32_t build_bvh_on_device(brt_ctx* ctx, const Model* models, uint32_t n, bool 
     BVHNode* d_out = nullptr;
     uint32_t* d_info = nullptr;
     HIP_TRY(ctx, hipEventRecord(dc.ev0, dc.stream));
-    if (sah) HIP_TRY(ctx, launch_build_sah(reinterpret_cast<const Model*>(dc.d_bvh_models), n, dc.d_bvh_scratch, &d_out, &d_info, dc.stream));
+    if (sah) HIP_TRY(ctx, launch_build_sah(reinterpret_cast<const Model*>(dc.d_bvh_models), n, reach, dc.d_bvh_scratch, &d_out, &d_info, dc.stream));
     else HIP_TRY(ctx, launch_build_ploc(reinterpret_cast<const Model*>(dc.d_bvh_models), n, dc.d_bvh_scratch, &d_out, &d_info, ctx->knobs[K_PLOC_ONE_BLOCK_MAX], dc.stream));
     HIP_TRY(ctx, hipEventRecord(dc.ev1, dc.stream));
     out->resize(2 * (size_t)n - 1);
@@ -644,6 +645,38 @@ int32_t build_bvh_on_device(brt_ctx* ctx, const Model* models, uint32_t n, bool 
     HIP_TRY(ctx, hipEventElapsedTime(&ms, dc.ev0, dc.ev1));
     if (build_ms) *build_ms = ms;
     return BRT_OK;
+}
+
+// ---- the callee-built SAH tree and the camera (brt_sah.h "leaf boxes of the tree the CALLEE builds") -------------------------------
+// The leaf pads of that tree cover the rounding of the sphere test for rays of up to `reach`; at upload the camera is unknown and the
+// tree is built for the scene's own extent, reach = 2 S.  Every render call checks its camera: need = |camera|_1 + S + L (L: the longest
+// tangent from the camera to a big sphere -- how far from the camera a primary ray can land on the ground, from where it bounces back
+// into the scene).  Reaches come in steps of 2^(1/4) (level k: 2 S * 2^(k / 4), the pads grow by 2^(1/2) per step): a camera that needs
+// a higher level than the resident tree has -- or at least two levels less: it has come back -- gets the tree rebuilt on the GPU before
+// its frame is launched (brt_sah.hip: 0.2-0.5 ms + the re-encode); never a tree whose pads are below what the camera needs.  A
+// caller's tree (and the callee's PLOC tree: the reference's flat 0.1) is honoured as it comes.
+// (the rule itself -- tree_scene_of, tree_level_for, tree_reach_of, tree_pads_equal -- is host arithmetic: brt_host.cpp, exported as brt_host_tree_reach)
+int32_t upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, const void* materials, uint32_t n_materials,
+                     const void* bvh_nodes, uint32_t n_nodes, uint32_t level, bool rebuild);
+// before a frame is launched: *rebuilt = the tree was rebuilt for this camera
+int32_t ensure_tree_reach(brt_ctx* ctx, const void* camera80, uint32_t* rebuilt) {
+    *rebuilt = 0u;
+    if (!ctx->has_scene || !ctx->tree_callee_sah || !camera80) return BRT_OK;
+    Camera cam;
+    std::memcpy(&cam, camera80, sizeof cam);
+    uint32_t need = tree_level_for(ctx->tree_scene.scale, ctx->tree_scene.big, cam.position);
+    if (tree_pads_equal(ctx->tree_scene, 0.0f, tree_reach_of(ctx->tree_scene.scale, need))) need = 0u;   // the tree of the scene's own extent is that tree
+    if (need <= ctx->tree_level && need + 2u > ctx->tree_level) return BRT_OK;
+    // (the cover camera at its usual place already "needs" level 5 -- with every pad still at the 0.01 floor: same bytes, level 0)
+    if (tree_pads_equal(ctx->tree_scene, ctx->tree_reach, tree_reach_of(ctx->tree_scene.scale, need))) return BRT_OK;
+    *rebuilt = 1u;
+    return upload_scene(ctx, ctx->last_models.data(), (uint32_t)(ctx->last_models.size() / sizeof(Model)), ctx->last_materials.data(),
+                        (uint32_t)(ctx->last_materials.size() / sizeof(Material)), nullptr, 0u, need, true);
+}
+void tree_stats(const brt_ctx* ctx, uint32_t rebuilt, brt_stats* stats) {
+    if (!stats) return;
+    stats->tree_rebuilt = rebuilt;
+    stats->tree_reach = ctx->tree_callee_sah ? ctx->tree_reach : 0.0f;
 }
 
 }  // namespace
@@ -779,6 +812,17 @@ int32_t brt_destroy(brt_ctx* ctx) {
 int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, const void* materials, uint32_t n_materials,
                          const void* bvh_nodes, uint32_t n_nodes) {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
+    return upload_scene(ctx, models, n_models, materials, n_materials, bvh_nodes, n_nodes, 0u, false);
+}
+
+}  // extern "C"
+
+namespace {
+
+// brt_upload_scene; and, with rebuild_level != 0 / `rebuild`, the same scene bytes again (ctx->last_*) in a callee-built SAH tree whose
+// leaf pads cover a longer reach (ensure_tree_reach): the dispatch-order history and the dirty-tracking state stay as they are.
+int32_t upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, const void* materials, uint32_t n_materials,
+                     const void* bvh_nodes, uint32_t n_nodes, uint32_t level, bool rebuild) {
     // Dirty tracking (the reference re-uploads everything every frame, README.md:17 lists that as
     // future work): identical bytes as the last successful upload -> nothing to do, and the tile-cost
     // history stays valid.  BRT_NO_DIRTY_TRACKING=1 disables.
@@ -787,10 +831,26 @@ int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, co
     auto same = [](const std::vector<char>& v, const void* p, size_t n) {
         return v.size() == n && (n == 0 || (p && std::memcmp(v.data(), p, n) == 0));
     };
-    if (ctx->has_scene && ctx->knobs[K_NO_DIRTY_TRACKING] == 0 && same(ctx->last_models, models, mb) &&
+    if (!rebuild && ctx->has_scene && ctx->knobs[K_NO_DIRTY_TRACKING] == 0 && same(ctx->last_models, models, mb) &&
         same(ctx->last_materials, materials, tb) && same(ctx->last_bvh, bvh_nodes, bb))
         return BRT_OK;
+    // a frame of an asynchronous entry point (caller's stream) may still be reading the resident scene, or the build scratch: the
+    // scene buffers are rewritten only once every device of the context has drained
+    for (auto& dc : ctx->devs) {
+        HIP_TRY(ctx, hipSetDevice(dc.device));
+        for (hipEvent_t e : {dc.ev_last, dc.ev_copy, dc.ev_asm}) HIP_TRY(ctx, hipEventSynchronize(e));
+    }
     ctx->has_scene = false;
+    // the scale of the scene and its big spheres, for the reach a camera needs (brt_sah.h; ensure_tree_reach)
+    float reach = 0.0f;
+    if (!rebuild) {
+        ctx->tree_scene = tree_scene_of(static_cast<const Model*>(models), models ? n_models : 0u);
+        ctx->tree_callee_sah = false;
+        ctx->tree_level = 0;
+        ctx->tree_reach = 0.0f;
+    } else {
+        reach = tree_reach_of(ctx->tree_scene.scale, level);
+    }
     std::vector<BVHNode> built;
     const BVHNode* nodes = static_cast<const BVHNode*>(bvh_nodes);
     if (n_models > 0 && models && (!bvh_nodes || n_nodes == 0)) {
@@ -800,10 +860,13 @@ int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, co
         const bool sah = ctx->knobs[K_BVH_QUALITY] != 0u && n_models <= kMaxSahModels;
         const bool on_gpu = ctx->knobs[K_CPU_BVH] == 0u && n_models <= kMaxGpuBuildModels;
         int32_t rc;
-        if (on_gpu) rc = build_bvh_on_device(ctx, static_cast<const Model*>(models), n_models, sah, &built, nullptr);
-        else rc = sah ? build_bvh_sah(static_cast<const Model*>(models), n_models, &built)
+        if (on_gpu) rc = build_bvh_on_device(ctx, static_cast<const Model*>(models), n_models, sah, reach, &built, nullptr);
+        else rc = sah ? build_bvh_sah(static_cast<const Model*>(models), n_models, reach, &built)
                       : build_bvh_ploc(static_cast<const Model*>(models), n_models, &built);
         if (rc != BRT_OK) return rc;
+        ctx->tree_callee_sah = sah;
+        ctx->tree_level = level;
+        ctx->tree_reach = reach;
         nodes = built.data();
         n_nodes = (uint32_t)built.size();
     }
@@ -849,11 +912,12 @@ int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, co
         HIP_TRY(ctx, hipSetDevice(dc.device));
         HIP_TRY(ctx, hipStreamSynchronize(dc.stream));  // the caller's vectors are no longer referenced
     }
+    ctx->has_scene = true;
+    if (rebuild) { ctx->tree_rebuilds++; return BRT_OK; }     // (the bytes are ctx->last_* themselves; order history, centre: unchanged)
     ctx->last_models.assign(static_cast<const char*>(models), static_cast<const char*>(models) + mb);
     ctx->last_materials.assign(static_cast<const char*>(materials), static_cast<const char*>(materials) + tb);
     if (bb) ctx->last_bvh.assign(static_cast<const char*>(bvh_nodes), static_cast<const char*>(bvh_nodes) + bb);
     else ctx->last_bvh.clear();
-    ctx->has_scene = true;
     ctx->scene_epoch++;
     {
         double c[3] = {0, 0, 0};
@@ -879,6 +943,10 @@ int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, co
     }
     return BRT_OK;
 }
+
+}  // namespace
+
+extern "C" {
 
 uint32_t brt_tile_rows(uint32_t height, uint32_t n_parts) {
     if (n_parts == 0) return 0;
@@ -1224,8 +1292,11 @@ int32_t brt_render(brt_ctx* ctx, const void* camera80, const void* window16, uin
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (!out_rgba) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "out_rgba is null");
     if (!ctx->has_scene && level != 0u) return ctx_fail(ctx, BRT_ERR_NO_SCENE, "brt_upload_scene has not succeeded yet");
-    const int32_t rc = render_frame(ctx, camera80, window16, level, width, height, raster_rgba, raster_depth, out_rgba, flags, stats);
+    uint32_t rebuilt = 0u;
+    int32_t rc = level != 0u ? ensure_tree_reach(ctx, camera80, &rebuilt) : BRT_OK;
+    if (rc == BRT_OK) rc = render_frame(ctx, camera80, window16, level, width, height, raster_rgba, raster_depth, out_rgba, flags, stats);
     if (rc != BRT_OK) drain_all_streams(ctx);
+    else tree_stats(ctx, rebuilt, stats);
     return rc;
 }
 
@@ -1236,10 +1307,13 @@ int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* w
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (!d_out_tile) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "d_out_tile is null");
     if (!ctx->has_scene && level != 0u) return ctx_fail(ctx, BRT_ERR_NO_SCENE, "brt_upload_scene has not succeeded yet");
-    const int32_t rc = render_part_device(ctx, camera80, window16, level, width, height, part, n_parts, d_raster_rgba, d_raster_depth,
-                                          d_out_tile, hip_stream, flags, stats);
+    uint32_t rebuilt = 0u;
+    int32_t rc = level != 0u ? ensure_tree_reach(ctx, camera80, &rebuilt) : BRT_OK;
+    if (rc == BRT_OK) rc = render_part_device(ctx, camera80, window16, level, width, height, part, n_parts, d_raster_rgba, d_raster_depth,
+                                              d_out_tile, hip_stream, flags, stats);
     // a failed call leaves nothing in flight on the context's own streams (a caller's stream is the caller's to drain)
     if (rc != BRT_OK) drain_all_streams(ctx);
+    else tree_stats(ctx, rebuilt, stats);
     return rc;
 }
 
@@ -1250,9 +1324,12 @@ int32_t brt_render_device(brt_ctx* ctx, const void* camera80, const void* window
     if (!d_frame) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "d_frame is null");
     if (!ctx->has_scene && level != 0u) return ctx_fail(ctx, BRT_ERR_NO_SCENE, "brt_upload_scene has not succeeded yet");
     if (flags & BRT_FLAG_KERNEL_SIMPLE) return ctx_fail(ctx, BRT_ERR_UNSUPPORTED, "brt_render_device runs the persistent kernel only");
-    const int32_t rc = render_frame_device(ctx, camera80, window16, level, width, height, d_raster_rgba, d_raster_depth, d_frame, hip_stream,
-                                           flags, stats);
+    uint32_t rebuilt = 0u;
+    int32_t rc = level != 0u ? ensure_tree_reach(ctx, camera80, &rebuilt) : BRT_OK;
+    if (rc == BRT_OK) rc = render_frame_device(ctx, camera80, window16, level, width, height, d_raster_rgba, d_raster_depth, d_frame, hip_stream,
+                                               flags, stats);
     if (rc != BRT_OK) drain_all_streams(ctx);
+    else tree_stats(ctx, rebuilt, stats);
     return rc;
 }
 
@@ -1277,7 +1354,7 @@ int32_t brt_build_bvh_device(brt_ctx* ctx, const void* models, uint32_t n_models
     if (n_models == 0) return BRT_OK;
     if (!models) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "models is null");
     std::vector<BVHNode> nodes;
-    int32_t rc = build_bvh_on_device(ctx, static_cast<const Model*>(models), n_models, false, &nodes, out_build_ms);
+    int32_t rc = build_bvh_on_device(ctx, static_cast<const Model*>(models), n_models, false, 0.0f, &nodes, out_build_ms);
     if (rc != BRT_OK) return rc;
     *out_n_nodes = (uint32_t)nodes.size();
     if (nodes.size() > capacity || !out_nodes)
@@ -1286,7 +1363,7 @@ int32_t brt_build_bvh_device(brt_ctx* ctx, const void* models, uint32_t n_models
     return BRT_OK;
 }
 
-int32_t brt_build_bvh_sah_device(brt_ctx* ctx, const void* models, uint32_t n_models, void* out_nodes, uint32_t capacity,
+int32_t brt_build_bvh_sah_device(brt_ctx* ctx, const void* models, uint32_t n_models, float reach, void* out_nodes, uint32_t capacity,
                                  uint32_t* out_n_nodes, double* out_build_ms) {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (!out_n_nodes) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "out_n_nodes is null");
@@ -1294,7 +1371,7 @@ int32_t brt_build_bvh_sah_device(brt_ctx* ctx, const void* models, uint32_t n_mo
     if (n_models == 0) return BRT_OK;
     if (!models) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "models is null");
     std::vector<BVHNode> nodes;
-    int32_t rc = build_bvh_on_device(ctx, static_cast<const Model*>(models), n_models, true, &nodes, out_build_ms);
+    int32_t rc = build_bvh_on_device(ctx, static_cast<const Model*>(models), n_models, true, reach, &nodes, out_build_ms);
     if (rc != BRT_OK) return rc;
     *out_n_nodes = (uint32_t)nodes.size();
     if (nodes.size() > capacity || !out_nodes)

@@ -127,6 +127,13 @@ struct brt_ctx {
     // bytes of the last successful upload (dirty tracking: an unchanged scene is not re-sent)
     std::vector<char> last_models, last_materials, last_bvh;
     float scene_centre[3] = {0, 0, 0};   // mean centre of the scene's ordinary spheres (radius <= 100): what a camera translation is judged against
+    // the callee-built SAH tree and the camera (brt_sah.h "leaf boxes", brt_api.cpp ensure_tree_reach): the leaf pads of the resident
+    // tree cover rays of up to tree_reach; a camera that needs more has the tree rebuilt before its frame is launched
+    bool tree_callee_sah = false;        // the resident tree was built here with the binned-SAH builder (a caller's tree is honoured as it comes)
+    brt::TreeScene tree_scene;           // scale, radii and big spheres of the resident scene (brt_host.h)
+    uint32_t tree_level = 0;             // reach of the resident tree = 2 S * 2^(level / 4); level 0: the scene's own extent
+    float tree_reach = 0.0f;             // ... as passed to the builder (0 at level 0)
+    uint32_t tree_rebuilds = 0;          // rebuilds since brt_create (diagnostic)
     brt::Knobs knobs;           // tuning knobs (brt_set_tuning; environment once at brt_create under BRT_ENABLE_TUNING=1)
     uint32_t policy_flags = 0;  // brt_set_policy
     std::string last_error;

@@ -239,13 +239,13 @@ int32_t build_bvh_ploc(const Model* models, uint32_t n_models, std::vector<BVHNo
 // halves when a subtree's remaining depth budget only just covers a balanced split.
 // ---------------------------------------------------------------------------------------
 
-int32_t build_bvh_sah(const Model* models, uint32_t n_models, std::vector<BVHNode>* out) {
+int32_t build_bvh_sah(const Model* models, uint32_t n_models, float reach, std::vector<BVHNode>* out) {
     out->clear();
     if (n_models == 0) return BRT_OK;
     const uint32_t n = n_models;
     std::vector<SahKeyBox> box(n);
     std::vector<double> cen(3 * (size_t)n);
-    uint32_t scale_key = kSahKeyMaxIdentity;      // the scene's scale: max over its ordinary spheres (an order-independent integer max)
+    uint32_t scale_key = sah_reach_key(reach);    // the scene's scale: max over its ordinary spheres (an order-independent integer max), not below reach / 2
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t k = sah_key_max(sah_scale_term(models[i].position, models[i].radius));
         scale_key = k > scale_key ? k : scale_key;
@@ -572,6 +572,62 @@ void build_tile_order(const uint32_t* ray_sum, const uint32_t* longest, uint32_t
         if (is_sky[tile]) o.order[k++] = tile;
 }
 
+// ---- the reach a camera needs of the callee-built SAH tree (brt_sah.h "leaf boxes"; brt_api.cpp ensure_tree_reach) ---------------
+TreeScene tree_scene_of(const Model* models, uint32_t n_models) {
+    TreeScene t;
+    uint32_t scale_key = kSahKeyMaxIdentity;
+    for (uint32_t i = 0; i < n_models; i++) {
+        const Model& m = models[i];
+        const float term = sah_scale_term(m.position, m.radius);
+        const uint32_t k = sah_key_max(term);
+        scale_key = k > scale_key ? k : scale_key;
+        if (term == term) {                                   // an ordinary sphere (the ones sah_model_pad sizes by the scale)
+            t.rmin = m.radius < t.rmin ? m.radius : t.rmin;
+            t.rmax = m.radius > t.rmax ? m.radius : t.rmax;
+        }
+        if (m.radius > 100.0f && std::isfinite(m.radius) && std::isfinite(m.position[0]) && std::isfinite(m.position[1]) &&
+            std::isfinite(m.position[2]))
+            t.big.insert(t.big.end(), {m.position[0], m.position[1], m.position[2], m.radius});
+    }
+    t.scale = sah_unkey_max(scale_key);
+    return t;
+}
+// the scale the builders use for a `reach` (brt_sah.h sah_reach_key: max(S, reach / 2))
+float tree_scale_used(float scene_scale, float reach) {
+    const float half = 0.5f * reach;
+    return (half > scene_scale) ? half : scene_scale;
+}
+// every leaf pad is the same under both reaches (all at the floor under the larger, or all at the ceiling under the smaller): the
+// trees are the same bytes, a rebuild would change nothing
+bool tree_pads_equal(const TreeScene& t, float reach_a, float reach_b) {
+    const float sa = tree_scale_used(t.scale, reach_a), sb = tree_scale_used(t.scale, reach_b);
+    if (sa == sb || !(t.rmin <= t.rmax)) return true;
+    const float lo = sa < sb ? sa : sb, hi = sa < sb ? sb : sa;
+    return sah_model_pad(t.rmin, hi) <= 0.01f || sah_model_pad(t.rmax, lo) >= 0.1f;   // (the pad falls with the radius)
+}
+float tree_reach_of(float scene_scale, uint32_t level) {
+    if (level == 0u) return 0.0f;
+    const double r = 2.0 * (double)scene_scale * std::exp2(0.25 * (double)level);
+    return r < 3.0e38 ? (float)r : 3.0e38f;      // (finite: an infinite reach would read as "no floor", brt_sah.h sah_reach_key)
+}
+uint32_t tree_level_for(float scene_scale, const std::vector<float>& big_spheres, const float cam_pos[3]) {
+    const double S = scene_scale;
+    if (!(S > 0.0) || !std::isfinite(S)) return 0u;                 // no ordinary sphere: every pad is 0.1 as it is
+    const double l1 = (std::fabs((double)cam_pos[0]) + std::fabs((double)cam_pos[1])) + std::fabs((double)cam_pos[2]);
+    double L = 0.0;
+    for (size_t i = 0; i + 3 < big_spheres.size(); i += 4) {
+        const double dx = (double)cam_pos[0] - big_spheres[i], dy = (double)cam_pos[1] - big_spheres[i + 1], dz = (double)cam_pos[2] - big_spheres[i + 2];
+        const double r = big_spheres[i + 3], h = std::sqrt(dx * dx + dy * dy + dz * dz) - r;
+        const double t = h > 0.0 ? std::sqrt(h * (2.0 * r + h)) : 2.0 * r;      // (a camera inside the sphere: a chord)
+        if (t > L) L = t;
+    }
+    const double need = l1 + S + L;
+    if (!std::isfinite(need)) return kTreeLevelMax;
+    if (need <= 2.0 * S) return 0u;
+    const double k = std::ceil(4.0 * std::log2(need / (2.0 * S)));
+    return k < 1.0 ? 1u : (k > (double)kTreeLevelMax ? kTreeLevelMax : (uint32_t)k);
+}
+
 }  // namespace brt
 
 using namespace brt;
@@ -593,18 +649,32 @@ int32_t brt_build_bvh(const void* models, uint32_t n_models, void* out_nodes, ui
     return BRT_OK;
 }
 
-int32_t brt_build_bvh_sah(const void* models, uint32_t n_models, void* out_nodes, uint32_t capacity, uint32_t* out_n_nodes) {
+int32_t brt_build_bvh_sah(const void* models, uint32_t n_models, float reach, void* out_nodes, uint32_t capacity, uint32_t* out_n_nodes) {
     if (!out_n_nodes) return fail(BRT_ERR_INVALID_ARGUMENT, "out_n_nodes is null");
     *out_n_nodes = 0;
     if (n_models == 0) return BRT_OK;
     if (!models) return fail(BRT_ERR_INVALID_ARGUMENT, "models is null");
     std::vector<BVHNode> nodes;
-    int32_t rc = build_bvh_sah((const Model*)models, n_models, &nodes);
+    int32_t rc = build_bvh_sah((const Model*)models, n_models, reach, &nodes);
     if (rc != BRT_OK) return rc;
     *out_n_nodes = (uint32_t)nodes.size();
     if (nodes.size() > capacity || !out_nodes)
         return fail(BRT_ERR_CAPACITY, "BVH needs " + std::to_string(nodes.size()) + " nodes, capacity " + std::to_string(capacity));
     std::memcpy(out_nodes, nodes.data(), nodes.size() * sizeof(BVHNode));
+    return BRT_OK;
+}
+
+int32_t brt_host_tree_reach(const void* models, uint32_t n_models, const void* camera80, float* out_scene_scale, uint32_t* out_level,
+                            float* out_reach) {
+    if ((!models && n_models != 0u) || !camera80) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
+    const TreeScene t = tree_scene_of((const Model*)models, n_models);
+    Camera cam;
+    std::memcpy(&cam, camera80, sizeof cam);
+    uint32_t level = tree_level_for(t.scale, t.big, cam.position);
+    if (tree_pads_equal(t, 0.0f, tree_reach_of(t.scale, level))) level = 0u;      // the tree of the scene's own extent already is that tree
+    if (out_scene_scale) *out_scene_scale = t.scale;
+    if (out_level) *out_level = level;
+    if (out_reach) *out_reach = tree_reach_of(t.scale, level);
     return BRT_OK;
 }
 

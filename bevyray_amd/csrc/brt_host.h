@@ -31,7 +31,19 @@ struct EncodedScene {
 int32_t validate_and_encode(const Model* models, uint32_t n_models, const Material* materials, uint32_t n_materials,
                             const BVHNode* nodes, uint32_t n_nodes, EncodedScene* out, std::string* err);
 int32_t build_bvh_ploc(const Model* models, uint32_t n_models, std::vector<BVHNode>* out);
-int32_t build_bvh_sah(const Model* models, uint32_t n_models, std::vector<BVHNode>* out);   // binned SAH, same node contract
+int32_t build_bvh_sah(const Model* models, uint32_t n_models, float reach, std::vector<BVHNode>* out);   // binned SAH, same node contract; reach: brt_sah.h
+// the reach a camera needs of the callee-built SAH tree (rule: brt_sah.h "leaf boxes"; used by brt_api.cpp ensure_tree_reach)
+constexpr uint32_t kTreeLevelMax = 80;      // 2 S * 2^20: every pad has long been the reference's 0.1
+struct TreeScene {
+    float scale = 0.0f;                    // S of brt_sah.h (NaN: no ordinary sphere)
+    float rmin = 3.4e38f, rmax = 0.0f;     // radii of the ordinary spheres (rmin > rmax: none)
+    std::vector<float> big;                // {centre, radius} of the spheres of radius > 100 (the ground): tangent lengths from the camera
+};
+TreeScene tree_scene_of(const Model* models, uint32_t n_models);
+float tree_scale_used(float scene_scale, float reach);
+bool tree_pads_equal(const TreeScene& t, float reach_a, float reach_b);   // the trees of both reaches are the same bytes
+uint32_t tree_level_for(float scene_scale, const std::vector<float>& big_spheres, const float cam_pos[3]);
+float tree_reach_of(float scene_scale, uint32_t level);      // the builders' `reach` of a level (0 at level 0: the scene's own extent)
 int32_t scene_generate(uint32_t kind, uint64_t seed, std::vector<Model>* models, std::vector<Material>* materials);
 float tan_half_fov(float fov);
 

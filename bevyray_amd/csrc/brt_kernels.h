@@ -60,6 +60,6 @@ hipError_t launch_build_ploc(const Model* d_models, uint32_t n, char* d_scratch,
 // GPU binned-SAH builder (brt_sah.hip; the rule: brt_sah.h; CPU twin: brt_host.cpp build_bvh_sah): *d_out / *d_info point into
 // the scratch (info[0] = node count)
 size_t sah_scratch_bytes(uint32_t n);
-hipError_t launch_build_sah(const Model* d_models, uint32_t n, char* d_scratch, BVHNode** d_out, uint32_t** d_info, hipStream_t stream);
+hipError_t launch_build_sah(const Model* d_models, uint32_t n, float reach, char* d_scratch, BVHNode** d_out, uint32_t** d_info, hipStream_t stream);
 
 }  // namespace brt

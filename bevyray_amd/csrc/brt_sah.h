@@ -86,12 +86,22 @@ BRT_HD bool sah_finite(double x) { return x - x == 0.0; }   // false for +-inf a
 // surface) and the walk pays for it: interior visits per ray 12.7 -> 11.2 (cover), 19.5 -> 17.1 (10 k grid), sphere tests 2.3 -> 1.8.
 // What it needs: the sphere test's discriminant h*h - a*c carries a rounding error of ~2^-24 of its terms, dist^2 * a, i.e. it can
 // accept a ray whose true distance from the centre exceeds r by up to ~2^-24 * dist^2 / (2 r), dist = the distance the ray has
-// travelled to the sphere; the slab arithmetic's own error, ~2^-22 * dist, is small beside it.  With dist bounded by twice the
-// scene's scale S (the largest |c|_1 + r over its ordinary spheres, r <= 100: a ground sphere of radius 1000 is not a distance rays
-// travel): pad = clamp(2^-24 * (2 S)^2 / r, 0.01, 0.1) -- the reference's own 0.1 where the model asks for more (there the
-// reference's culling is as marginal as any), never less than 0.01.  Measured: on the 10 k grid (S = 100, pad 0.012) the first pixel
-// of a 640 x 360 x 16 spp frame differs from the brute-force frame at a pad of 1e-4, none at 1e-3 (docs/experiments.md); the -m gpu
-// suite compares the frames of configs 2 and 5 in this tree with the oracle's frames in the caller's 0.1-padded PLOC tree at full size.
+// travelled to the sphere; the slab arithmetic's own error, ~2^-22 * dist, is small beside it.  dist is bounded by the REACH of the
+// frame: rays start at the camera or on a sphere, so reach = max(2 S, |camera|_1 + S + L) with S the scene's scale (the largest
+// |c|_1 + r over its ordinary spheres, r <= 100: a ground sphere of radius 1000 is not a distance rays travel between its own
+// points -- it is convex) and L the longest tangent from the camera to such a big sphere (how far a primary ray can land on the ground
+// away from the camera).  pad = clamp(2^-24 * reach^2 / r, 0.01, 0.1): twice the model's bound, the reference's own 0.1 where the
+// model asks for more (there the reference's culling is as marginal as any), never less than 0.01.  The camera is not known at
+// upload: brt_upload_scene builds for reach = 2 S, and a render call whose camera needs more rebuilds the tree on the GPU first
+// (brt_api.cpp ensure_tree_reach; round 4 ignored the camera and lost pixels from a distance of ~260 on: VERDICT r4).
+// Measured: on the 10 k grid (S = 100, pad 0.012) the first pixel of a 640 x 360 x 16 spp frame differs from the brute-force frame at
+// a pad of 1e-4, none at 1e-3 (docs/experiments.md); the -m gpu suite compares the frames of configs 2 and 5 in this tree with the
+// oracle's frames in the caller's 0.1-padded PLOC tree at full size, and far-camera frames (x 20 ... x 60 the cover distance).
+// `reach` enters the builders as a FLOOR on the scale (scale = max(S, reach / 2)), as the max's initial key: still an integer max.
+BRT_HD uint32_t sah_reach_key(float reach) {      // initial value of the scale's key-max (kSahKeyMaxIdentity: no floor)
+    const float half = 0.5f * reach;
+    return (half > 0.0f && half - half == 0.0f) ? sah_key_max(half) : kSahKeyMaxIdentity;
+}
 BRT_HD float sah_scale_term(const float* position, float radius) {      // |c|_1 + r of an ordinary sphere, else NaN (ignored by the max)
     const float s = ((__builtin_fabsf(position[0]) + __builtin_fabsf(position[1])) + __builtin_fabsf(position[2])) + radius;
     return (radius > 0.0f && radius <= 100.0f && s - s == 0.0f) ? s : __builtin_nanf("");

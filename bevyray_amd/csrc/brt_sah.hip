@@ -575,7 +575,7 @@ size_t sah_scratch_bytes(uint32_t n) {
            al(2 * (size_t)n * sizeof(BVHNode)) + al(256);
 }
 
-hipError_t launch_build_sah(const Model* d_models, uint32_t n, char* d_scratch, BVHNode** d_out, uint32_t** d_info, hipStream_t stream) {
+hipError_t launch_build_sah(const Model* d_models, uint32_t n, float reach, char* d_scratch, BVHNode** d_out, uint32_t** d_info, hipStream_t stream) {
     auto take = [&](size_t bytes) { char* r = d_scratch; d_scratch += (bytes + 255) & ~(size_t)255; return r; };
     SahGlobals g;
     SahKeyBox* kbox = reinterpret_cast<SahKeyBox*>(take((size_t)n * sizeof(SahKeyBox)));
@@ -598,8 +598,8 @@ hipError_t launch_build_sah(const Model* d_models, uint32_t n, char* d_scratch, 
     // (a node the build failed to write would be a leaf of 2^32 - 1 spheres at sphere 2^32 - 1: brt_upload_scene's validation refuses it)
     hipError_t e = hipMemsetAsync(g.out, 0xff, (2 * (size_t)n - 1) * sizeof(BVHNode), stream);
     if (e != hipSuccess) return e;
-    uint32_t* scale_key = top_n + kTopCounters;                      // behind the level counters (zero = the max's identity)
-    e = hipMemsetAsync(scale_key, 0, 4, stream);
+    uint32_t* scale_key = top_n + kTopCounters;                      // behind the level counters; starts at the key of reach / 2 (zero = the max's identity)
+    e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scale_key), (int)sah_reach_key(reach), 1, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_sah_scale, dim3((n + 255u) / 256u), dim3(256), 0, stream, d_models, n, scale_key);
     hipLaunchKernelGGL(k_sah_prep, dim3((n + 255u) / 256u), dim3(256), 0, stream, d_models, n, scale_key, kbox, cen, g.st.idx[0], g.tasks,

@@ -173,16 +173,26 @@ def build_bvh(models: np.ndarray) -> np.ndarray:
     return _trim(nodes, out_n.value)
 
 
-def build_bvh_sah(models: np.ndarray) -> np.ndarray:
-    """The binned-SAH tree that brt_upload_scene builds when the caller passes no BVH (brt_build_bvh_sah)."""
+def build_bvh_sah(models: np.ndarray, reach: float = 0.0) -> np.ndarray:
+    """The binned-SAH tree that brt_upload_scene builds when the caller passes no BVH (brt_build_bvh_sah); reach: what the
+    leaf pads cover (0 = the scene's own extent; tree_reach(models, camera) for a camera further out)."""
     lib = _lib.load()
     models = np.ascontiguousarray(models, MODEL_DTYPE)
     n = len(models)
     cap = max(1, 2 * n)
     nodes = np.zeros(cap, BVH_NODE_DTYPE)
     out_n = C.c_uint32(0)
-    _lib.check(lib.brt_build_bvh_sah(models.ctypes.data, n, nodes.ctypes.data, cap, C.byref(out_n)))
+    _lib.check(lib.brt_build_bvh_sah(models.ctypes.data, n, float(reach), nodes.ctypes.data, cap, C.byref(out_n)))
     return _trim(nodes, out_n.value)
+
+
+def tree_reach(models: np.ndarray, camera: np.ndarray):
+    """brt_host_tree_reach: (scene scale S, level, reach) the callee-built SAH tree needs for this camera."""
+    lib = _lib.load()
+    models = np.ascontiguousarray(models, MODEL_DTYPE)
+    s, lvl, r = C.c_float(0), C.c_uint32(0), C.c_float(0)
+    _lib.check(lib.brt_host_tree_reach(models.ctypes.data, len(models), camera.ctypes.data, C.byref(s), C.byref(lvl), C.byref(r)))
+    return float(s.value), int(lvl.value), float(r.value)
 
 
 def validate_scene(models, materials, bvh) -> int:
@@ -336,7 +346,7 @@ class RaytracePlugin:
                                                   C.byref(ms)), self._ctx)
         return _trim(nodes, out_n.value), ms.value
 
-    def build_bvh_sah(self, models: np.ndarray):
+    def build_bvh_sah(self, models: np.ndarray, reach: float = 0.0):
         """GPU binned-SAH build (brt_build_bvh_sah_device): returns (nodes, kernel ms); same bytes as build_bvh_sah()."""
         models = np.ascontiguousarray(models, MODEL_DTYPE)
         n = len(models)
@@ -344,7 +354,7 @@ class RaytracePlugin:
         nodes = np.zeros(cap, BVH_NODE_DTYPE)
         out_n = C.c_uint32(0)
         ms = C.c_double(0.0)
-        _lib.check(self._lib.brt_build_bvh_sah_device(self._ctx, models.ctypes.data, n, nodes.ctypes.data, cap, C.byref(out_n),
+        _lib.check(self._lib.brt_build_bvh_sah_device(self._ctx, models.ctypes.data, n, float(reach), nodes.ctypes.data, cap, C.byref(out_n),
                                                       C.byref(ms)), self._ctx)
         return _trim(nodes, out_n.value), ms.value
 

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define BRT_ABI_VERSION 4u
+#define BRT_ABI_VERSION 5u
 
 /* Rows per strip of the interleaved row tiling. */
 #define BRT_STRIP_ROWS 8u
@@ -103,6 +103,10 @@ typedef struct brt_stats {
                                   pixel chain can be critical), + 16: knobs live (a tuning knob off its default) */
     uint32_t measured_tile_costs; /* 1: this frame measured the per-tile ray counts for the dispatch order of the next ones
                                   (first frames of a view, every frame while the camera moves, after scene uploads) */
+    uint32_t tree_rebuilt;     /* 1: the callee-built tree was rebuilt for this call's camera before the launch (see brt_upload_scene) */
+    float    tree_reach;       /* the `reach` the resident callee-built SAH tree was built with (what brt_build_bvh_sah takes: 0 = the
+                                  scene's own extent); 0 for a caller's tree */
+    uint64_t forwarded_bytes;  /* brt_render_device: bytes of the raster inputs forwarded to the other devices of the context */
 } brt_stats;
 
 uint32_t brt_abi_version(void);
@@ -138,7 +142,13 @@ int32_t brt_get_tuning(const brt_ctx* ctx, const char* name, uint32_t* out_value
  * them (indices in range, BVH reachable from node 0 without cycles) and copies them to
  * every device of the context.  If bvh_nodes == NULL / n_nodes == 0 the callee builds the
  * BVH itself (see brt_build_bvh_sah / brt_build_bvh_device): recommended, the ray loop runs faster in that tree than in
- * the caller's PLOC tree and the caller saves its own per-frame build (extract.rs:315-332). */
+ * the caller's PLOC tree and the caller saves its own per-frame build (extract.rs:315-332).
+ * The callee's tree pads a sphere's box by what the f32 arithmetic of the two intersection tests needs for the distances rays travel
+ * (0.01 ... 0.1) instead of the reference's flat 0.1 (Model::aabb, extract.rs:220-227).  Those distances depend on the camera, which
+ * an upload does not know: the tree is built for the scene's own extent, and every brt_render* call checks its camera first -- one
+ * that is further out than the resident tree covers has the tree rebuilt on the GPU (same scene bytes, larger pads, up to the
+ * reference's 0.1; 0.3-1 ms, brt_stats::tree_rebuilt) before its frame is launched.  The rule is brt_host_tree_reach.  A caller's
+ * tree is used as it comes. */
 int32_t brt_upload_scene(brt_ctx* ctx,
                          const void* models, uint32_t n_models,
                          const void* materials, uint32_t n_materials,
@@ -313,9 +323,20 @@ int32_t brt_build_bvh(const void* models, uint32_t n_models,
  * extract.rs:264-267); the shader only needs the node contract above, and an SAH tree costs the ray loop fewer node
  * visits (10 004-sphere grid: 23.6 -> 19.1 interior visits per ray).  This is the CPU statement of the tree
  * brt_upload_scene builds ON THE GPU (brt_build_bvh_sah_device, the same bytes) when the caller passes no BVH (up to 65 536
- * spheres; above that, or with the knob BRT_BVH_QUALITY=0: PLOC on the GPU). */
-int32_t brt_build_bvh_sah(const void* models, uint32_t n_models,
+ * spheres; above that, or with the knob BRT_BVH_QUALITY=0: PLOC on the GPU).
+ * reach: the longest distance a ray has travelled when it reaches a sphere, camera included (it sizes the leaf pads: brt_upload_scene
+ * above); 0 = the scene's own extent (what an upload builds); otherwise what brt_host_tree_reach returns for a camera. */
+int32_t brt_build_bvh_sah(const void* models, uint32_t n_models, float reach,
                           void* out_nodes, uint32_t capacity, uint32_t* out_n_nodes);
+
+/* The reach rule of the callee-built SAH tree (host arithmetic; brt_render* applies it before every launch): out_scene_scale = S, the
+ * largest |centre|_1 + radius over the scene's ordinary spheres (radius <= 100); the camera needs |position|_1 + S + L (L: the longest
+ * tangent from the camera to a sphere of radius > 100, i.e. how far away a primary ray can land on the ground); out_level = 0 when
+ * that is within 2 S, else the smallest k with 2 S * 2^(k/4) >= it (at most 80); out_reach = the `reach` of that level for
+ * brt_build_bvh_sah (0 at level 0).  The resident tree is rebuilt when a camera needs a higher level than it has, or at least two
+ * levels less.  camera80: a CameraExtract.  No reference counterpart (the reference pads by 0.1 whatever the camera). */
+int32_t brt_host_tree_reach(const void* models, uint32_t n_models, const void* camera80, float* out_scene_scale, uint32_t* out_level,
+                            float* out_reach);
 
 /* The same build on the GPU (PLOC in one workgroup, bevyray_amd/csrc/brt_bvh.hip): takes the
  * host model vector, returns byte-identical nodes to brt_build_bvh plus the kernel time.
@@ -328,7 +349,7 @@ int32_t brt_build_bvh_device(brt_ctx* ctx, const void* models, uint32_t n_models
  * than 1024 spheres, then a workgroup per subtree, a wave per node): byte-identical nodes plus the kernel time.  This is what
  * brt_upload_scene runs when the caller passes no BVH (up to 65 536 spheres), so that a scene that changes every frame --
  * the reference rebuilds and re-uploads per frame, extract.rs:299-336 -- costs no host-side build.  Needs a context (a GPU). */
-int32_t brt_build_bvh_sah_device(brt_ctx* ctx, const void* models, uint32_t n_models,
+int32_t brt_build_bvh_sah_device(brt_ctx* ctx, const void* models, uint32_t n_models, float reach,
                                  void* out_nodes, uint32_t capacity, uint32_t* out_n_nodes, double* out_build_ms);
 
 /* Checks what brt_upload_scene checks, without a context. */

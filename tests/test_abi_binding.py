@@ -26,7 +26,7 @@ def test_rust_binding_declares_exactly_the_headers_exports():
 
 
 def test_rust_binding_constants_stats_layout_and_abi_version():
-    assert RUST["abi"] == HEADER["abi"] == 4
+    assert RUST["abi"] == HEADER["abi"] == 5
     for name, value in HEADER["constants"].items():
         assert RUST["constants"].get(name) == value, name
     assert not set(RUST["constants"]) - set(HEADER["constants"])
@@ -51,7 +51,7 @@ def test_ctypes_binding_and_the_built_library_match_the_header():
                 assert ct in (ctypes.c_void_p, ctypes.c_char_p) or issubclass(ct, ctypes._Pointer), (name, an)
         if ret in width:
             assert res is width[ret], name
-    assert [(n, {ctypes.c_uint64: "u64", ctypes.c_uint32: "u32", ctypes.c_double: "f64"}[t]) for n, t in _lib.BrtStats._fields_] == HEADER["stats"]
+    assert [(n, {ctypes.c_uint64: "u64", ctypes.c_uint32: "u32", ctypes.c_double: "f64", ctypes.c_float: "f32"}[t]) for n, t in _lib.BrtStats._fields_] == HEADER["stats"]
     # every export is a defined symbol of the built library, and nothing else is exported under the brt_ prefix
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.build()], capture_output=True, text=True, check=True).stdout
     exported = sorted(ln.split()[-1] for ln in out.splitlines() if ln.split()[-1].startswith("brt_") and " T " in ln)

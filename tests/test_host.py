@@ -8,7 +8,7 @@ import pytest
 
 import bevyray_amd as brt
 from bevyray_amd import _lib
-from helpers import chain_bvh, make_buffers, median_split_bvh, single_leaf_bvh
+from helpers import chain_bvh, make_buffers, median_split_bvh, single_leaf_bvh, uniforms
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -22,9 +22,9 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/bevyray_amd.h but not exported"
     assert declared == set(_lib.EXPORTS), "ctypes prototypes out of sync with the header"
-    assert _lib.load().brt_abi_version() == 4
+    assert _lib.load().brt_abi_version() == 5
     import ctypes
-    assert ctypes.sizeof(_lib.BrtStats) == 104         # 9 x 8 + 4 x 4 + prepass_ms + kernel_variant, measured_tile_costs (include/bevyray_amd.h, ABI 4)
+    assert ctypes.sizeof(_lib.BrtStats) == 120         # 9 x 8 + 4 x 4 + prepass_ms + kernel_variant, measured_tile_costs + tree_rebuilt, tree_reach, forwarded_bytes (include/bevyray_amd.h, ABI 5)
 
 
 def test_wire_layouts_match_the_wgsl_structs():
@@ -241,7 +241,8 @@ def test_new_exports_fail_with_codes_not_crashes_without_a_context():
     assert lib.brt_release_frame(None, None) == -1
     assert lib.brt_debug_export_frame_fd(None, 64, C.byref(fd), C.byref(ptr)) == -1
     assert lib.brt_debug_copy_to_host(None, None, None, 0) == -1
-    assert lib.brt_build_bvh_sah_device(None, None, 0, None, 0, None, None) == -1
+    assert lib.brt_build_bvh_sah_device(None, None, 0, 0.0, None, 0, None, None) == -1
+    assert lib.brt_host_tree_reach(None, 3, None, None, None, None) == -1
     assert lib.brt_rccl_unique_id(None) == -1
     buf = (C.c_char * 128)()
     rc = lib.brt_rccl_unique_id(buf)
@@ -366,3 +367,82 @@ def test_sah_builder_contract_depth_cap_and_determinism():
             for ch in (nodes[nd["index"]], nodes[nd["index"] + 1]):
                 assert np.all(ch["bounds_min"] >= nd["bounds_min"]) and np.all(ch["bounds_max"] <= nd["bounds_max"])
     assert min(pads) == float(f32(0.01)) and max(pads) == float(f32(0.1))      # the small spheres and the ground sphere of the cover scene
+
+
+def _leaf_pads(models, nodes):
+    """leaf box half-width minus radius, per sphere (x axis of bounds_max: exact in f32 only up to the rounding of c + (r + pad))"""
+    pads = np.zeros(len(models), np.float64)
+    for nd in nodes[nodes["model_count"] > 0]:
+        m = models[nd["index"]]
+        pads[nd["index"]] = (float(nd["bounds_max"][1]) - float(nd["bounds_min"][1])) / 2 - float(m["radius"])
+    return pads
+
+
+def test_tree_reach_rule_and_pads_follow_the_camera():
+    """The callee-built SAH tree pads its leaf boxes for the distances rays travel -- camera included (brt_sah.h):
+    brt_host_tree_reach is the rule brt_render* applies, brt_build_bvh_sah(reach) the tree it then builds.  Replaces what
+    Model::aabb's flat 0.1 (extract.rs:220-227) does for the reference whatever the camera."""
+    f32 = np.float32
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    m = b.models
+    ordinary = m["radius"] <= 100
+    ap = np.abs(m["position"][ordinary]).astype(f32)
+    S_want = float((((ap[:, 0] + ap[:, 1]) + ap[:, 2]) + m["radius"][ordinary]).max())
+    _, cam, _ = brt.cover_camera(160, 90, 1, 1)
+    S, level, reach = brt.tree_reach(m, cam)
+    assert S == S_want
+    # the cover camera: |(13, 2, 3)|_1 + S + the tangent to the ground sphere ~ 105 > 2 S, yet every pad of that reach is still the
+    # 0.01 floor -> the tree of the scene's own extent already is that tree: level 0
+    assert (level, reach) == (0, 0.0)
+    base = brt.build_bvh_sah(m)
+    assert np.array_equal(base.view(np.uint8), brt.build_bvh_sah(m, 105.0).view(np.uint8))
+    # moving out along the view axis: the level never falls, the reach covers |cam|_1 + S + tangent, the pads grow up to the reference's 0.1
+    last_level, last_pads = 0, _leaf_pads(m, base)
+    for k in (2, 5, 10, 20, 30, 60, 1000, 1e6):
+        _, cam, _ = uniforms(160, 90, 1, 1, (13.0 * k, 2.0 * k, 3.0 * k), (0, 0, 0), 0.4 / k, 0.5)
+        S2, level, reach = brt.tree_reach(m, cam)
+        assert S2 == S and level >= last_level and level <= 80
+        if level:
+            c = np.array([13.0 * k, 2.0 * k, 3.0 * k])
+            hgt = np.linalg.norm(c - np.array([0.0, -1000.0, 0.0])) - 1000.0
+            need = np.abs(c).sum() + S + np.sqrt(hgt * (2000.0 + hgt))
+            assert reach >= need * (1 - 1e-6) and reach <= need * 2 ** 0.25 * (1 + 1e-6)
+            assert abs(reach - 2 * S * 2 ** (level / 4)) <= 1e-5 * reach
+        nodes = brt.build_bvh_sah(m, reach)
+        assert brt.validate_scene(m, b.materials, nodes) <= 28
+        pads = _leaf_pads(m, nodes)
+        assert np.all(pads >= last_pads - 1e-4) and pads.max() <= 0.1 + 1e-4 and pads.min() >= 0.01 - 1e-4
+        # the rule of brt_sah.h at this reach, in f32, for the r = 0.2 spheres
+        small = np.isclose(m["radius"], 0.2)
+        d = f32(2.0) * max(f32(S), f32(0.5) * f32(reach))
+        want = min(max((f32(5.9604645e-8) * (d * d)) / f32(0.2), f32(0.01)), f32(0.1))
+        assert np.allclose(pads[small], float(want), atol=2e-6)
+        last_level, last_pads = level, pads
+    assert last_level >= 70 and np.allclose(last_pads, 0.1, atol=1e-4)           # far enough out: the reference's own boxes
+    # a camera that is not a number needs the most: level 80, not "no floor"
+    _, cam, _ = brt.cover_camera(160, 90, 1, 1)
+    cam = cam.copy(); cam["position"][0, 1] = np.nan
+    assert brt.tree_reach(m, cam)[1] == 80
+    # a scene without ordinary spheres has nothing the camera could change
+    g = m[m["radius"] > 100]
+    assert brt.tree_reach(g, cam)[1] == 0
+
+
+def test_far_camera_frames_in_the_callee_tree_equal_the_reference_tree(oracle):
+    """CPU statement of the -m gpu far-camera test: the oracle's frame in the callee's tree built for the camera's reach equals its
+    frame in the reference's 0.1-padded PLOC tree (and in one leaf of all spheres) at x 1 ... x 30 the cover distance -- where the
+    tree of the scene's own extent (round 4's only tree) loses 7 / 53 / 377 pixels from x 20 on."""
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    w, h = 160, 90
+    brute = single_leaf_bvh(b.models)
+    lost = 0
+    for k in (1, 20, 25, 30):
+        lvl, cam, win = uniforms(w, h, 4, 4, (13.0 * k, 2.0 * k, 3.0 * k), (0, 0, 0), 0.4 / k, 0.5, far=1e5)
+        _, level, reach = brt.tree_reach(b.models, cam)
+        assert (level > 0) == (k > 1)
+        frames = [oracle.render(brt.Buffers(b.models, b.materials, t), lvl, cam, win, w, h)[0]
+                  for t in (brt.build_bvh_sah(b.models, reach), b.bvh, brute, brt.build_bvh_sah(b.models))]
+        assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
+        assert np.array_equal(frames[0].view(np.uint32), frames[2].view(np.uint32))
+        lost += int((frames[3].view(np.uint32) != frames[2].view(np.uint32)).any(axis=2).sum())
+    assert lost > 100            # the camera-blind tree does lose pixels out there: the case is real

@@ -52,7 +52,7 @@ def parse_header(path):
             consts[m.group(1)] = nxt
             nxt += 1
     st = re.search(r"typedef struct brt_stats \{(.*?)\} brt_stats;", h, flags=re.S).group(1)
-    stats = [(n, C_TO_RUST[t]) for t, n in re.findall(r"(uint64_t|uint32_t|double)\s+([a-z_]+)\s*;", st)]
+    stats = [(n, C_TO_RUST[t]) for t, n in re.findall(r"(uint64_t|uint32_t|double|float)\s+([a-z_]+)\s*;", st)]
     return {"functions": fns, "constants": consts, "stats": stats, "abi": consts["BRT_ABI_VERSION"]}
 
 
@@ -69,5 +69,5 @@ def parse_rust(path):
         fns[name] = (" ".join((ret or "()").split()), al)
     consts = {n: int(v) for n, v in re.findall(r"pub const (BRT_[A-Z0-9_]+)\s*:\s*[iu]32\s*=\s*(-?\d+)\s*;", src)}
     st = re.search(r"pub struct brt_stats \{(.*?)\n\}", src, flags=re.S).group(1)
-    stats = [(n, t) for n, t in re.findall(r"pub ([a-z_]+)\s*:\s*(u64|u32|f64)", st)]
+    stats = [(n, t) for n, t in re.findall(r"pub ([a-z_]+)\s*:\s*(u64|u32|f64|f32)", st)]
     return {"functions": fns, "constants": consts, "stats": stats, "abi": consts.get("BRT_ABI_VERSION")}
