@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("BRT_LIB_PATH") or os.path.join(_HERE, "libbevyray_amd.so")   # BRT_LIB_PATH: A/B of builds
 _SOURCES = ["brt_api.cpp", "brt_interop.cpp", "brt_ctx.h", "brt_host.cpp", "brt_kernels.hip", "brt_trace_prod.hip", "brt_trace_tune.hip", "brt_trace.h",
-            "brt_host.h", "brt_kernels.h", "brt_layout.h", "brt_device.h", "brt_ploc.h", "brt_sah.h", "brt_bvh.hip", "brt_sah.hip", "brt_order.hip", "Makefile"]
+            "brt_host.h", "brt_kernels.h", "brt_layout.h", "brt_device.h", "brt_ploc.h", "brt_sah.h", "brt_srgb_table.h", "brt_bvh.hip", "brt_sah.hip", "brt_order.hip", "Makefile"]
 
 _lock = threading.Lock()
 _lib = None
@@ -89,6 +89,7 @@ _PROTOTYPES = {
     "brt_debug_tile_order": (_I32, [_VP, _VP, _VP, _U32, _U32, C.c_uint64, _U32, _U32, _U32, _VP, _VP]),
     "brt_build_bvh": (_I32, [_VP, _U32, _VP, _U32, C.POINTER(_U32)]),
     "brt_build_bvh_sah": (_I32, [_VP, _U32, _F, _VP, _U32, C.POINTER(_U32)]),
+    "brt_host_srgb_thresholds": (_I32, [C.POINTER(_F)]),
     "brt_host_tree_reach": (_I32, [_VP, _U32, _VP, C.POINTER(_F), C.POINTER(_U32), C.POINTER(_F)]),
     "brt_build_bvh_device": (_I32, [_VP, _VP, _U32, _VP, _U32, C.POINTER(_U32), C.POINTER(C.c_double)]),
     "brt_build_bvh_sah_device": (_I32, [_VP, _VP, _U32, _F, _VP, _U32, C.POINTER(_U32), C.POINTER(C.c_double)]),

@@ -313,10 +313,12 @@ int32_t build_order_on_device(brt_ctx* ctx, DeviceCtx& dc, uint32_t n_tiles, uin
 
 // before the launch: attach the order table if the history matches this view, and -- when the
 // history is missing, the camera has moved or a scene upload asks for it -- the (zeroed) cost buffer to measure again
-int32_t attach_tile_order(brt_ctx* ctx, DeviceCtx& dc, FrameParams& fp, hipStream_t stream, bool may_measure) {
+int32_t attach_tile_order(brt_ctx* ctx, DeviceCtx& dc, FrameParams& fp, hipStream_t stream, bool may_measure, uint32_t flags) {
     fp.tile_order = nullptr;
     fp.tile_cost = nullptr;
-    if (!lpt_enabled(ctx) || fp.level == 0u) return BRT_OK;
+    // (the bring-up kernel takes slot q = tile q / 64 of a plain order: an order with half-sample jobs -- n_tiles + n_split entries,
+    //  [non-sky | second halves | sky] -- would have it render the split tiles twice and the last sky tiles never: raster order there)
+    if (!lpt_enabled(ctx) || fp.level == 0u || (flags & BRT_FLAG_KERNEL_SIMPLE)) return BRT_OK;
     const uint32_t n_tiles = fp.local_strips * fp.tiles_x;
     uint32_t key[6];
     order_key_of(ctx, fp, key);
@@ -587,7 +589,8 @@ void free_device(DeviceCtx& dc) {
     if (dc.d_ctrl) (void)hipFree(dc.d_ctrl);
     if (dc.d_tile) (void)hipFree(dc.d_tile);
     if (dc.d_gather) (void)hipFree(dc.d_gather);
-    for (hipEvent_t e : {dc.ev_copy, dc.ev_asm, dc.ev_in, dc.ev_g0, dc.ev_g1})
+    if (dc.d_pack) (void)hipFree(dc.d_pack);
+    for (hipEvent_t e : {dc.ev_copy, dc.ev_asm, dc.ev_in, dc.ev_g0, dc.ev_g1, dc.ev_pack})
         if (e) (void)hipEventDestroy(e);
     if (dc.d_raster_rgba) (void)hipFree(dc.d_raster_rgba);
     if (dc.d_raster_depth) (void)hipFree(dc.d_raster_depth);
@@ -723,6 +726,7 @@ int32_t brt_create(const int32_t* device_ids, int32_t n_devices, brt_ctx** out_c
             HIP_TRY(ctx, hipEventCreateWithFlags(&dc.ev_copy, hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&dc.ev_asm, hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&dc.ev_in, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&dc.ev_pack, hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreate(&dc.ev_g0));
             HIP_TRY(ctx, hipEventCreate(&dc.ev_g1));
             HIP_TRY(ctx, hipEventRecord(dc.ev_asm, dc.stream));
@@ -990,7 +994,7 @@ int32_t render_part_device(brt_ctx* ctx, const void* camera80, const void* windo
         rc = prepass_order(ctx, dc, fp, d_raster_rgba, d_raster_depth, d_out_tile, stream, flags, &prepass_ran);
         if (rc != BRT_OK) return rc;
     }
-    rc = attach_tile_order(ctx, dc, fp, stream, own_stream);
+    rc = attach_tile_order(ctx, dc, fp, stream, own_stream, flags);
     if (rc != BRT_OK) return rc;
     LaunchPlan lp{};
     rc = launch_part(ctx, dc, fp, d_raster_rgba, d_raster_depth, d_out_tile, stream, flags, own_stream, &lp);
@@ -1055,18 +1059,41 @@ int32_t render_frame(brt_ctx* ctx, const void* camera80, const void* window16, u
         if (rc != BRT_OK) return rc;
         const float* d_rgba = nullptr;
         const float* d_depth = nullptr;
+        // raster inputs: the whole frame for a one-device context; else this device's strips only, densely in the tile's own layout
+        // (FrameParams::raster_dense) -- a strided 2-D copy, 1 / n_parts of the bytes over PCIe per device
+        auto send = [&](const float* src, float** d_buf, size_t* cap, uint32_t fpp) -> int32_t {
+            const size_t px_bytes = (size_t)fpp * 4u;
+            if (n_parts == 1) {
+                int32_t r = ensure(ctx, d_buf, cap, frame_px * px_bytes);
+                if (r != BRT_OK) return r;
+                HIP_TRY(ctx, hipMemcpyAsync(*d_buf, src, frame_px * px_bytes, hipMemcpyHostToDevice, dc.stream));
+                return BRT_OK;
+            }
+            int32_t r = ensure(ctx, d_buf, cap, (size_t)tile_rows * width * px_bytes);
+            if (r != BRT_OK) return r;
+            const uint32_t strips = (height + BRT_STRIP_ROWS - 1u) / BRT_STRIP_ROWS, full = height / BRT_STRIP_ROWS;
+            const size_t strip_bytes = (size_t)BRT_STRIP_ROWS * width * px_bytes;
+            const uint32_t n_full = full > p ? (full - p + n_parts - 1u) / n_parts : 0u;      // whole strips p, p + n, ... < full
+            if (n_full)
+                HIP_TRY(ctx, hipMemcpy2DAsync(*d_buf, strip_bytes, reinterpret_cast<const char*>(src) + (size_t)p * strip_bytes,
+                                              strip_bytes * n_parts, strip_bytes, n_full, hipMemcpyHostToDevice, dc.stream));
+            if (strips > full && full % n_parts == p)                                       // the frame's last, partial strip is this part's
+                HIP_TRY(ctx, hipMemcpyAsync(reinterpret_cast<char*>(*d_buf) + (size_t)n_full * strip_bytes,
+                                            reinterpret_cast<const char*>(src) + (size_t)full * strip_bytes,
+                                            (size_t)(height - full * BRT_STRIP_ROWS) * width * px_bytes, hipMemcpyHostToDevice, dc.stream));
+            return BRT_OK;
+        };
         if (raster_rgba) {
-            rc = ensure(ctx, &dc.d_raster_rgba, &dc.raster_rgba_cap, frame_px * 16);
+            rc = send(raster_rgba, &dc.d_raster_rgba, &dc.raster_rgba_cap, 4u);
             if (rc != BRT_OK) return rc;
-            HIP_TRY(ctx, hipMemcpyAsync(dc.d_raster_rgba, raster_rgba, frame_px * 16, hipMemcpyHostToDevice, dc.stream));
             d_rgba = dc.d_raster_rgba;
         }
         if (raster_depth) {
-            rc = ensure(ctx, &dc.d_raster_depth, &dc.raster_depth_cap, frame_px * 4);
+            rc = send(raster_depth, &dc.d_raster_depth, &dc.raster_depth_cap, 1u);
             if (rc != BRT_OK) return rc;
-            HIP_TRY(ctx, hipMemcpyAsync(dc.d_raster_depth, raster_depth, frame_px * 4, hipMemcpyHostToDevice, dc.stream));
             d_depth = dc.d_raster_depth;
         }
+        fps[p].raster_dense = n_parts > 1 ? 1u : 0u;
         if (!direct && dc.stage_cap < tile_bytes) {
             if (dc.h_stage) HIP_TRY(ctx, hipHostFree(dc.h_stage));
             dc.h_stage = nullptr;
@@ -1078,7 +1105,7 @@ int32_t render_frame(brt_ctx* ctx, const void* camera80, const void* window16, u
         rc = prepass_order(ctx, dc, fps[p], d_rgba, d_depth, dc.d_tile, dc.stream, flags, &ran);
         if (rc != BRT_OK) return rc;
         prepass_ran[p] = ran;
-        rc = attach_tile_order(ctx, dc, fps[p], dc.stream, true);
+        rc = attach_tile_order(ctx, dc, fps[p], dc.stream, true, flags);
         if (rc != BRT_OK) return rc;
         rc = launch_part(ctx, dc, fps[p], d_rgba, d_depth, dc.d_tile, dc.stream, flags, true, &lp);
         if (rc != BRT_OK) return rc;
@@ -1150,7 +1177,7 @@ int32_t render_frame(brt_ctx* ctx, const void* camera80, const void* window16, u
 // when an ordinal repeats), and k_deinterleave writes the frame -- what bevyray_amd/parallel.py does with one process per
 // GPU and an RCCL gather, for a single-process host (the Rust node).
 int32_t render_frame_device(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level, uint32_t width, uint32_t height,
-                            const float* d_raster_rgba, const float* d_raster_depth, float* d_frame, void* hip_stream, uint32_t flags,
+                            const float* d_raster_rgba, const float* d_raster_depth, void* d_frame, void* hip_stream, uint32_t flags,
                             brt_stats* stats) {
     const auto t0 = std::chrono::steady_clock::now();
     const uint32_t n_parts = (uint32_t)ctx->devs.size();
@@ -1161,7 +1188,6 @@ int32_t render_frame_device(brt_ctx* ctx, const void* camera80, const void* wind
     }
     const uint32_t tile_rows = brt_tile_rows(height, n_parts);
     const size_t tile_floats = (size_t)tile_rows * width * 4, tile_bytes = tile_floats * 4;
-    const size_t frame_px = (size_t)width * height;
     DeviceCtx& d0 = ctx->devs[0];
     HIP_TRY(ctx, hipSetDevice(d0.device));
     const bool own_stream = (hip_stream == nullptr) && !(flags & BRT_FLAG_CALLER_STREAM);
@@ -1172,9 +1198,10 @@ int32_t render_frame_device(brt_ctx* ctx, const void* camera80, const void* wind
         bool grow = d0.gather_cap < tile_bytes * n_parts;
         for (uint32_t p = 1; p < n_parts; p++) {
             const DeviceCtx& dc = ctx->devs[p];
-            grow = grow || dc.tile_cap < tile_bytes || (d_raster_rgba && dc.raster_rgba_cap < frame_px * 16) ||
-                   (d_raster_depth && level != 0u && dc.raster_depth_cap < frame_px * 4);
+            grow = grow || dc.tile_cap < tile_bytes || (d_raster_rgba && dc.raster_rgba_cap < tile_bytes) ||
+                   (d_raster_depth && level != 0u && dc.raster_depth_cap < tile_bytes / 4);
         }
+        grow = grow || ((d_raster_rgba || d_raster_depth) && d0.pack_cap < (tile_bytes + tile_bytes / 4) * (n_parts - 1u));
         if (grow)
             for (auto& dc : ctx->devs) {
                 HIP_TRY(ctx, hipSetDevice(dc.device));
@@ -1186,6 +1213,24 @@ int32_t render_frame_device(brt_ctx* ctx, const void* camera80, const void* wind
     if (rc != BRT_OK) return rc;
     // the other devices start behind whatever the caller enqueued before this call (its raster inputs)
     HIP_TRY(ctx, hipEventRecord(d0.ev_in, stream0));
+    // Raster inputs of the other devices: a device reads only its own strips, so only those travel -- packed per part on the first
+    // device (k_pack_strips, the tile's own layout: FrameParams::raster_dense), one peer copy per device and input: 1 / n_parts of
+    // the frame each instead of the whole frame (round 4: 41 MB at 1080p, 166 MB at 4K, x 7 devices, every frame at levels 1 / 2)
+    const bool fwd_rgba = n_parts > 1 && d_raster_rgba != nullptr, fwd_depth = n_parts > 1 && d_raster_depth != nullptr && level != 0u;
+    uint64_t forwarded = 0;
+    float* pack_rgba = nullptr;
+    float* pack_depth = nullptr;
+    if (fwd_rgba || fwd_depth) {
+        rc = ensure(ctx, &d0.d_pack, &d0.pack_cap, (tile_bytes + tile_bytes / 4) * (n_parts - 1u));
+        if (rc != BRT_OK) return rc;
+        pack_rgba = d0.d_pack;
+        pack_depth = d0.d_pack + tile_floats * (n_parts - 1u);
+        HIP_TRY(ctx, hipStreamWaitEvent(stream0, d0.ev_asm, 0));    // (the previous frame's devices have read the pack buffer: ev_copy sits behind their reads)
+        for (uint32_t q = 1; q < n_parts; q++) HIP_TRY(ctx, hipStreamWaitEvent(stream0, ctx->devs[q].ev_last, 0));
+        if (fwd_rgba) HIP_TRY(ctx, launch_pack_strips(d_raster_rgba, pack_rgba, width, height, n_parts, tile_rows, 4u, stream0));
+        if (fwd_depth) HIP_TRY(ctx, launch_pack_strips(d_raster_depth, pack_depth, width, height, n_parts, tile_rows, 1u, stream0));
+        HIP_TRY(ctx, hipEventRecord(d0.ev_pack, stream0));
+    }
     LaunchPlan lp{};
     std::vector<char> prepass_ran(n_parts, 0);
     for (uint32_t p = 0; p < n_parts; p++) {
@@ -1203,18 +1248,24 @@ int32_t render_frame_device(brt_ctx* ctx, const void* camera80, const void* wind
             HIP_TRY(ctx, hipStreamWaitEvent(sp, d0.ev_asm, 0));     // the gather buffer is free again (previous frame assembled)
             // (level 0 reads the raster colour too -- k_passthrough, raytrace.wgsl:97-99 -- so it is forwarded at every level: a
             //  device must never be handed a pointer into another device's memory, peer access is not enabled)
-            if (d_raster_rgba) {
-                rc = ensure(ctx, &dc.d_raster_rgba, &dc.raster_rgba_cap, frame_px * 16);
+            if (fwd_rgba || fwd_depth) HIP_TRY(ctx, hipStreamWaitEvent(sp, d0.ev_pack, 0));
+            if (fwd_rgba) {
+                rc = ensure(ctx, &dc.d_raster_rgba, &dc.raster_rgba_cap, tile_bytes);
                 if (rc != BRT_OK) return rc;
-                HIP_TRY(ctx, hipMemcpyPeerAsync(dc.d_raster_rgba, dc.device, d_raster_rgba, d0.device, frame_px * 16, sp));
+                HIP_TRY(ctx, hipMemcpyPeerAsync(dc.d_raster_rgba, dc.device, pack_rgba + (size_t)(p - 1u) * tile_floats, d0.device, tile_bytes, sp));
                 d_rgba = dc.d_raster_rgba;
+                forwarded += tile_bytes;
             }
-            if (d_raster_depth && level != 0u) {
-                rc = ensure(ctx, &dc.d_raster_depth, &dc.raster_depth_cap, frame_px * 4);
+            if (fwd_depth) {
+                rc = ensure(ctx, &dc.d_raster_depth, &dc.raster_depth_cap, tile_bytes / 4);
                 if (rc != BRT_OK) return rc;
-                HIP_TRY(ctx, hipMemcpyPeerAsync(dc.d_raster_depth, dc.device, d_raster_depth, d0.device, frame_px * 4, sp));
+                HIP_TRY(ctx, hipMemcpyPeerAsync(dc.d_raster_depth, dc.device, pack_depth + (size_t)(p - 1u) * (tile_floats / 4), d0.device, tile_bytes / 4, sp));
                 d_depth = dc.d_raster_depth;
+                forwarded += tile_bytes / 4;
+            } else if (level == 0u) {
+                d_depth = nullptr;
             }
+            fps[p].raster_dense = 1u;
         } else {
             HIP_TRY(ctx, hipStreamWaitEvent(sp, d0.ev_asm, 0));
         }
@@ -1224,7 +1275,7 @@ int32_t render_frame_device(brt_ctx* ctx, const void* camera80, const void* wind
             if (rc != BRT_OK) return rc;
             prepass_ran[p] = ran;
         }
-        rc = attach_tile_order(ctx, dc, fps[p], sp, own_stream);
+        rc = attach_tile_order(ctx, dc, fps[p], sp, own_stream, flags);
         if (rc != BRT_OK) return rc;
         rc = launch_part(ctx, dc, fps[p], d_rgba, d_depth, out, sp, flags, true, &lp);
         if (rc != BRT_OK) return rc;
@@ -1237,11 +1288,12 @@ int32_t render_frame_device(brt_ctx* ctx, const void* camera80, const void* wind
     HIP_TRY(ctx, hipSetDevice(d0.device));
     HIP_TRY(ctx, hipEventRecord(d0.ev_g0, stream0));
     for (uint32_t p = 1; p < n_parts; p++) HIP_TRY(ctx, hipStreamWaitEvent(stream0, ctx->devs[p].ev_copy, 0));
-    HIP_TRY(ctx, launch_deinterleave(d0.d_gather, d_frame, width, height, n_parts, tile_rows, stream0));
+    HIP_TRY(ctx, launch_deinterleave(d0.d_gather, d_frame, width, height, n_parts, tile_rows, flags & BRT_FLAG_OUT_MASK, stream0));
     HIP_TRY(ctx, hipEventRecord(d0.ev_g1, stream0));
     HIP_TRY(ctx, hipEventRecord(d0.ev_asm, stream0));
     HIP_TRY(ctx, hipEventRecord(d0.ev_last, stream0));
     brt_stats st{};
+    st.forwarded_bytes = forwarded;
     for (uint32_t p = 0; p < n_parts; p++) st.paths += part_pixels(fps[p]) * (uint64_t)fps[p].sample_count;
     if (own_stream) {
         double kernel_ms = 0.0, prepass_ms = 0.0;
@@ -1292,6 +1344,7 @@ int32_t brt_render(brt_ctx* ctx, const void* camera80, const void* window16, uin
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (!out_rgba) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "out_rgba is null");
     if (!ctx->has_scene && level != 0u) return ctx_fail(ctx, BRT_ERR_NO_SCENE, "brt_upload_scene has not succeeded yet");
+    if (flags & BRT_FLAG_OUT_MASK) return ctx_fail(ctx, BRT_ERR_UNSUPPORTED, "brt_render writes RGBA f32 (BRT_FLAG_OUT_* apply to the device frame of brt_render_device / brt_gather_rccl / brt_deinterleave_device)");
     uint32_t rebuilt = 0u;
     int32_t rc = level != 0u ? ensure_tree_reach(ctx, camera80, &rebuilt) : BRT_OK;
     if (rc == BRT_OK) rc = render_frame(ctx, camera80, window16, level, width, height, raster_rgba, raster_depth, out_rgba, flags, stats);
@@ -1307,6 +1360,7 @@ int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* w
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (!d_out_tile) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "d_out_tile is null");
     if (!ctx->has_scene && level != 0u) return ctx_fail(ctx, BRT_ERR_NO_SCENE, "brt_upload_scene has not succeeded yet");
+    if (flags & BRT_FLAG_OUT_MASK) return ctx_fail(ctx, BRT_ERR_UNSUPPORTED, "a rank's tile is RGBA f32 (the format is applied where the frame is assembled: brt_gather_rccl / brt_deinterleave_device)");
     uint32_t rebuilt = 0u;
     int32_t rc = level != 0u ? ensure_tree_reach(ctx, camera80, &rebuilt) : BRT_OK;
     if (rc == BRT_OK) rc = render_part_device(ctx, camera80, window16, level, width, height, part, n_parts, d_raster_rgba, d_raster_depth,
@@ -1318,7 +1372,7 @@ int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* w
 }
 
 int32_t brt_render_device(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level, uint32_t width, uint32_t height,
-                          const float* d_raster_rgba, const float* d_raster_depth, float* d_frame, void* hip_stream, uint32_t flags,
+                          const float* d_raster_rgba, const float* d_raster_depth, void* d_frame, void* hip_stream, uint32_t flags,
                           brt_stats* stats) {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (!d_frame) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "d_frame is null");
@@ -1334,14 +1388,14 @@ int32_t brt_render_device(brt_ctx* ctx, const void* camera80, const void* window
 }
 
 int32_t brt_deinterleave_device(brt_ctx* ctx, const float* d_tiles, uint32_t n_parts, uint32_t width, uint32_t height,
-                                float* d_frame, void* hip_stream, uint32_t flags) {
+                                void* d_frame, void* hip_stream, uint32_t flags) {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (!d_tiles || !d_frame || n_parts == 0) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "null buffer / n_parts == 0");
     DeviceCtx& dc = ctx->devs[0];
     HIP_TRY(ctx, hipSetDevice(dc.device));
     const bool own_stream = (hip_stream == nullptr) && !(flags & BRT_FLAG_CALLER_STREAM);
     hipStream_t stream = own_stream ? dc.stream : static_cast<hipStream_t>(hip_stream);
-    HIP_TRY(ctx, launch_deinterleave(d_tiles, d_frame, width, height, n_parts, brt_tile_rows(height, n_parts), stream));
+    HIP_TRY(ctx, launch_deinterleave(d_tiles, d_frame, width, height, n_parts, brt_tile_rows(height, n_parts), flags & BRT_FLAG_OUT_MASK, stream));
     if (own_stream) HIP_TRY(ctx, hipStreamSynchronize(stream));
     return BRT_OK;
 }

@@ -36,6 +36,9 @@ struct DeviceCtx {
     size_t raster_depth_cap = 0;
     float* d_gather = nullptr;   // first device only: the tiles of all devices back to back (brt_render_device)
     size_t gather_cap = 0;
+    float* d_pack = nullptr;     // first device only: the raster inputs' strips of parts 1 .. N-1, packed per part (brt_render_device)
+    size_t pack_cap = 0;
+    hipEvent_t ev_pack = nullptr;   // first device: the strips are packed (the other devices' peer copies start behind it)
     hipEvent_t ev_copy = nullptr;   // this device's tile has arrived in the first device's gather buffer
     hipEvent_t ev_asm = nullptr;    // first device: the frame of the last brt_render_device call is assembled (the gather buffer is free)
     hipEvent_t ev_in = nullptr;     // first device: the caller's stream at the start of a brt_render_device call

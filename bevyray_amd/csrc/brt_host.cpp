@@ -8,6 +8,7 @@
 #include "brt_host.h"
 #include "brt_ploc.h"
 #include "brt_sah.h"
+#include "brt_srgb_table.h"
 
 #include <algorithm>
 #include <cmath>
@@ -661,6 +662,12 @@ int32_t brt_build_bvh_sah(const void* models, uint32_t n_models, float reach, vo
     if (nodes.size() > capacity || !out_nodes)
         return fail(BRT_ERR_CAPACITY, "BVH needs " + std::to_string(nodes.size()) + " nodes, capacity " + std::to_string(capacity));
     std::memcpy(out_nodes, nodes.data(), nodes.size() * sizeof(BVHNode));
+    return BRT_OK;
+}
+
+int32_t brt_host_srgb_thresholds(float* out255) {
+    if (!out255) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
+    std::memcpy(out255, kSrgbThreshold, sizeof kSrgbThreshold);
     return BRT_OK;
 }
 

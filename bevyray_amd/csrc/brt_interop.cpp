@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <unistd.h>
 
+#include <cstdlib>
 #include <mutex>
 
 #include "brt_ctx.h"
@@ -42,14 +43,22 @@ Rccl& rccl() {
     std::call_once(once, [] {
         // a copy that is already in the process (PyTorch's, or the host's own) first: two RCCLs in one process work, but each
         // would bring up its own transports
-        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // BRT_RCCL_LIB=<path>: that library and no other (a host that ships its own RCCL; tests force the not-found path with it).
+        // Read once, here: nothing reads the environment per frame.
+        const char* forced = std::getenv("BRT_RCCL_LIB");
+        const char* defaults[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        std::vector<const char*> names;
+        if (forced && *forced) names.push_back(forced);
+        else names.assign(defaults, defaults + 3);
         for (const char* n : names)
             if ((r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+        std::string err;
         for (const char* n : names) {
             if (r.lib) break;
             r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (!r.lib) { const char* e = dlerror(); err = e ? e : "?"; }      // (dlerror() clears what it returns: one call per failure)
         }
-        if (!r.lib) { r.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return; }
+        if (!r.lib) { r.why = "librccl not found: " + err; return; }
         auto sym = [&](const char* name) {
             void* p = dlsym(r.lib, name);
             if (!p && r.why.empty()) r.why = std::string("librccl has no ") + name;
@@ -102,14 +111,15 @@ void release_one(ExternalFrame& f) {
     f = ExternalFrame();
 }
 
-size_t vmm_granularity(int device) {
+size_t vmm_granularity(int device, bool minimum = false) {
     hipMemAllocationProp prop{};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
     prop.location.id = device;
     prop.requestedHandleType = hipMemHandleTypePosixFileDescriptor;
     size_t g = 0;
-    if (hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || g == 0) g = 2u << 20;
+    if (hipMemGetAllocationGranularity(&g, &prop, minimum ? hipMemAllocationGranularityMinimum : hipMemAllocationGranularityRecommended) != hipSuccess || g == 0)
+        g = minimum ? 4096u : (2u << 20);
     return g;
 }
 
@@ -163,7 +173,7 @@ int32_t brt_rccl_comm_destroy(brt_ctx* ctx, void* comm) {
 }
 
 int32_t brt_gather_rccl(brt_ctx* ctx, void* nccl_comm, int32_t rank, int32_t world, const float* d_tile, float* d_tiles_on_root,
-                        uint32_t width, uint32_t height, float* d_frame_on_root, void* hip_stream, uint32_t flags) {
+                        uint32_t width, uint32_t height, void* d_frame_on_root, void* hip_stream, uint32_t flags) {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (!nccl_comm || !d_tile) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "null communicator / tile");
     if (world < 1 || rank < 0 || rank >= world) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "rank / world out of range");
@@ -180,12 +190,12 @@ int32_t brt_gather_rccl(brt_ctx* ctx, void* nccl_comm, int32_t rank, int32_t wor
     const int rc = r.gather(d_tile, d_tiles_on_root, count, kNcclFloat, 0, nccl_comm, stream);      // THE collective of the path
     if (rc != 0) return nccl_fail(ctx, "ncclGather", rc);
     if (rank == 0 && d_frame_on_root)
-        HIP_TRY(ctx, launch_deinterleave(d_tiles_on_root, d_frame_on_root, width, height, (uint32_t)world, tile_rows, stream));
+        HIP_TRY(ctx, launch_deinterleave(d_tiles_on_root, d_frame_on_root, width, height, (uint32_t)world, tile_rows, flags & BRT_FLAG_OUT_MASK, stream));
     if (own_stream) HIP_TRY(ctx, hipStreamSynchronize(stream));
     return BRT_OK;
 }
 
-int32_t brt_import_frame_fd(brt_ctx* ctx, int32_t fd, uint64_t bytes, uint32_t handle_type, float** out_d_frame) {
+int32_t brt_import_frame_fd(brt_ctx* ctx, int32_t fd, uint64_t bytes, uint32_t handle_type, void** out_d_frame) {
     if (!ctx || !out_d_frame) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
     *out_d_frame = nullptr;
     if (fd < 0 || bytes == 0) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "bad file descriptor / zero size");
@@ -216,19 +226,35 @@ int32_t brt_import_frame_fd(brt_ctx* ctx, int32_t fd, uint64_t bytes, uint32_t h
         //  to a pointer: passing the value itself faults inside the runtime)
         int os_fd = fd;
         HIP_TRY(ctx, hipMemImportFromShareableHandle(&f.vmm, &os_fd, hipMemHandleTypePosixFileDescriptor));
-        const size_t g = vmm_granularity(dc.device);
-        f.mapped = (f.bytes + g - 1) / g * g;
-        const int32_t rc = map_vmm(ctx, dc.device, f.vmm, f.mapped, &f.ptr);
-        if (rc != BRT_OK) { (void)hipMemRelease(f.vmm); return rc; }
+        // The size of the imported allocation cannot be queried, and a mapping must not ask for more than the handle owns: `bytes`
+        // rounded up to the RECOMMENDED granularity (what brt_debug_export_frame_fd and most exporters allocate), then to the
+        // MINIMUM one, then `bytes` itself (an exporter that allocated exactly that).  The first that maps is the allocation.
+        size_t cand[3] = {0, 0, f.bytes};
+        {
+            const size_t g = vmm_granularity(dc.device), gm = vmm_granularity(dc.device, true);
+            cand[0] = (f.bytes + g - 1) / g * g;
+            cand[1] = (f.bytes + gm - 1) / gm * gm;
+        }
+        int32_t rc = BRT_ERR_HIP;
+        for (int i = 0; i < 3 && rc != BRT_OK; i++) {
+            if (i > 0 && (cand[i] == cand[i - 1] || cand[i] == cand[0])) continue;
+            f.mapped = cand[i];
+            rc = map_vmm(ctx, dc.device, f.vmm, f.mapped, &f.ptr);
+        }
+        if (rc != BRT_OK) {
+            (void)hipMemRelease(f.vmm);
+            return ctx_fail(ctx, BRT_ERR_HIP, "the dma-buf could not be mapped at " + std::to_string(cand[0]) + ", " + std::to_string(cand[1]) + " or " +
+                                                  std::to_string(cand[2]) + " bytes: `bytes` must be the size the exporter allocated (" + ctx->last_error + ")");
+        }
     } else {
         return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "unknown external-memory handle type");
     }
     ctx->external.push_back(f);
-    *out_d_frame = static_cast<float*>(f.ptr);
+    *out_d_frame = f.ptr;
     return BRT_OK;
 }
 
-int32_t brt_release_frame(brt_ctx* ctx, float* d_frame) {
+int32_t brt_release_frame(brt_ctx* ctx, void* d_frame) {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     for (size_t i = 0; i < ctx->external.size(); i++)
         if (ctx->external[i].ptr == d_frame) {
@@ -244,7 +270,7 @@ int32_t brt_release_frame(brt_ctx* ctx, float* d_frame) {
     return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "pointer was not returned by brt_import_frame_fd / brt_debug_export_frame_fd");
 }
 
-int32_t brt_debug_export_frame_fd(brt_ctx* ctx, uint64_t bytes, int32_t* out_fd, float** out_d_ptr) {
+int32_t brt_debug_export_frame_fd(brt_ctx* ctx, uint64_t bytes, int32_t* out_fd, void** out_d_ptr) {
     if (!ctx || !out_fd || !out_d_ptr || bytes == 0) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer / zero size");
     *out_fd = -1;
     *out_d_ptr = nullptr;
@@ -271,7 +297,7 @@ int32_t brt_debug_export_frame_fd(brt_ctx* ctx, uint64_t bytes, int32_t* out_fd,
     if (rc != BRT_OK) { (void)close(fd); (void)hipMemRelease(f.vmm); return rc; }
     ctx->external.push_back(f);
     *out_fd = fd;
-    *out_d_ptr = static_cast<float*>(f.ptr);
+    *out_d_ptr = f.ptr;
     return BRT_OK;
 }
 

@@ -35,8 +35,13 @@ constexpr uint32_t WGQ_BYTES = 64;           // a workgroup's share of the pixel
 hipError_t launch_trace_persistent(const TraceLaunch& tl);
 hipError_t launch_trace_simple(const TraceLaunch& tl);
 hipError_t launch_passthrough(const FrameParams& fp, float* out_tile, const float* raster_rgba, hipStream_t stream);
-hipError_t launch_deinterleave(const float* tiles, float* frame, uint32_t width, uint32_t height, uint32_t n_parts,
-                               uint32_t tile_rows, hipStream_t stream);
+// out_format: BRT_FLAG_OUT_* (include/bevyray_amd.h): the frame is written in the colour target's own format
+hipError_t launch_deinterleave(const float* tiles, void* frame, uint32_t width, uint32_t height, uint32_t n_parts,
+                               uint32_t tile_rows, uint32_t out_format, hipStream_t stream);
+// the strips of parts 1 .. n_parts-1 of a full-frame input (floats_per_pixel 4: colour, 1: depth), each part densely in its tile layout:
+// packed[(part - 1) * tile_rows * width ...]
+hipError_t launch_pack_strips(const float* frame, float* packed, uint32_t width, uint32_t height, uint32_t n_parts, uint32_t tile_rows,
+                              uint32_t floats_per_pixel, hipStream_t stream);
 hipError_t launch_debug_eval(uint32_t op, const float* in, float* out, uint32_t n, hipStream_t stream);
 
 // Dispatch order on the GPU (brt_order.hip): d_meta[0] = critical tiles at the front of the order, d_meta[1] = longest pixel,

@@ -30,6 +30,9 @@
 // k_debug_eval        evaluates single device functions for per-function parity tests.
 #include <hip/hip_runtime.h>
 
+#include <hip/hip_fp16.h>
+
+#include "brt_srgb_table.h"
 #include "brt_trace.h"
 
 namespace brt {
@@ -104,19 +107,72 @@ __global__ void k_passthrough(FrameParams fp, float4* __restrict__ out_tile, con
     const PixelCoord c = slot_to_pixel(fp, q, slot_tile(fp, q >> 6));
     if (!c.inside) return;
     out_tile[c.local_row * fp.width + c.px] =
-        raster_rgba ? raster_rgba[c.py * fp.width + c.px] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        raster_rgba ? raster_rgba[fp.raster_dense ? c.local_row * fp.width + c.px : c.py * fp.width + c.px] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 // ---- gather root: tiles of all parts -> frame -----------------------------------------------------
 
-__global__ void k_deinterleave(const float4* __restrict__ tiles, float4* __restrict__ frame, uint32_t width,
+// The frame is written in the colour target's own format (reference: the pass renders into post_process.destination, whose format is
+// TextureFormat::bevy_default() -- 8-bit sRGB, or Rgba16Float under HDR, pipeline.rs:311-315).  The conversions, exactly:
+//   RGBA8 sRGB   colour: v = round(255 * OETF(clamp(c, 0, 1))) as the number of thresholds <= c (brt_srgb_table.h: exact for every f32, a
+//                NaN encodes as 0 like the hardware's clamp); alpha: the linear rule below
+//   RGBA8        v = round-half-even(255 * clamp(c, 0, 1)), the product exact in f64
+//   RGBA16F      f32 -> f16, round to nearest even (v_cvt_f16_f32; overflow to infinity, denormals kept)
+BRT_DEV uint32_t encode_srgb8(float c) {
+    uint32_t n = 0;                                       // thresholds <= c so far: binary search over the 255 of them
+#pragma unroll
+    for (uint32_t step = 128u; step != 0u; step >>= 1)
+        if (n + step <= 255u && c >= kSrgbThreshold[n + step - 1u]) n += step;
+    return n;
+}
+BRT_DEV uint32_t encode_unorm8(float c) {
+    const double x = c > 0.0f ? (c < 1.0f ? (double)c : 1.0) : 0.0;      // (a NaN fails the first test: 0)
+    return (uint32_t)__double2int_rn(x * 255.0);
+}
+template <uint32_t FMT> struct OutPixel;
+template <> struct OutPixel<BRT_FLAG_OUT_RGBA32F> {
+    typedef float4 type;
+    static BRT_DEV float4 make(float4 v) { return v; }
+};
+template <> struct OutPixel<BRT_FLAG_OUT_RGBA8_UNORM_SRGB> {
+    typedef uint32_t type;
+    static BRT_DEV uint32_t make(float4 v) { return encode_srgb8(v.x) | (encode_srgb8(v.y) << 8) | (encode_srgb8(v.z) << 16) | (encode_unorm8(v.w) << 24); }
+};
+template <> struct OutPixel<BRT_FLAG_OUT_RGBA8_UNORM> {
+    typedef uint32_t type;
+    static BRT_DEV uint32_t make(float4 v) { return encode_unorm8(v.x) | (encode_unorm8(v.y) << 8) | (encode_unorm8(v.z) << 16) | (encode_unorm8(v.w) << 24); }
+};
+template <> struct OutPixel<BRT_FLAG_OUT_RGBA16F> {
+    typedef uint2 type;
+    static BRT_DEV uint2 make(float4 v) {
+        const uint32_t x = __half_as_ushort(__float2half_rn(v.x)), y = __half_as_ushort(__float2half_rn(v.y));
+        const uint32_t z = __half_as_ushort(__float2half_rn(v.z)), w = __half_as_ushort(__float2half_rn(v.w));
+        return make_uint2(x | (y << 16), z | (w << 16));
+    }
+};
+
+template <uint32_t FMT>
+__global__ void k_deinterleave(const float4* __restrict__ tiles, typename OutPixel<FMT>::type* __restrict__ frame, uint32_t width,
                                uint32_t height, uint32_t n_parts, uint32_t tile_rows) {
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t y = blockIdx.y;
     if (x >= width || y >= height) return;
     const uint32_t strip = y / 8u, r = y - strip * 8u;
     const uint32_t part = strip % n_parts, k = strip / n_parts;
-    frame[(size_t)y * width + x] = tiles[((size_t)part * tile_rows + (k * 8u + r)) * width + x];
+    frame[(size_t)y * width + x] = OutPixel<FMT>::make(tiles[((size_t)part * tile_rows + (k * 8u + r)) * width + x]);
+}
+
+// ---- first device of an N-device context: the strips of parts 1 .. N-1 of a full-frame raster input, each part's densely (the layout
+// of its tile buffer) -- what is then sent to that part's device instead of the whole frame --------------------------------------------
+
+template <typename T>
+__global__ void k_pack_strips(const T* __restrict__ frame, T* __restrict__ packed, uint32_t width, uint32_t height, uint32_t n_parts,
+                              uint32_t tile_rows) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lr = blockIdx.y, part = blockIdx.z + 1u;
+    const uint32_t y = ((lr / 8u) * n_parts + part) * 8u + (lr & 7u);
+    if (x >= width || y >= height) return;
+    packed[((size_t)(part - 1u) * tile_rows + lr) * width + x] = frame[(size_t)y * width + x];
 }
 
 // ---- per-function probes ----------------------------------------------------------------------------
@@ -207,6 +263,11 @@ __global__ void k_debug_eval(uint32_t op, const float* __restrict__ in, float* _
             r[0] = (float)bad; r[1] = __uint_as_float(bad_x);
             break;
         }
+        case BRT_DBG_ENCODE: {   // the store conversions of BRT_FLAG_OUT_* on one value
+            const uint2 h = OutPixel<BRT_FLAG_OUT_RGBA16F>::make(make_float4(a[0], 0.0f, 0.0f, 0.0f));
+            r[0] = (float)encode_srgb8(a[0]); r[1] = (float)encode_unorm8(a[0]); r[2] = (float)(h.x & 0xffffu);
+            break;
+        }
         default: break;
     }
 }
@@ -257,12 +318,34 @@ hipError_t launch_passthrough(const FrameParams& fp, float* out_tile, const floa
     return hipGetLastError();
 }
 
-hipError_t launch_deinterleave(const float* tiles, float* frame, uint32_t width, uint32_t height, uint32_t n_parts,
-                               uint32_t tile_rows, hipStream_t stream) {
+template <uint32_t FMT>
+static void launch_deinterleave_t(const float* tiles, void* frame, uint32_t width, uint32_t height, uint32_t n_parts, uint32_t tile_rows,
+                                  hipStream_t stream) {
+    hipLaunchKernelGGL(k_deinterleave<FMT>, dim3((width + 255u) / 256u, height), dim3(256), 0, stream, reinterpret_cast<const float4*>(tiles),
+                       reinterpret_cast<typename OutPixel<FMT>::type*>(frame), width, height, n_parts, tile_rows);
+}
+hipError_t launch_deinterleave(const float* tiles, void* frame, uint32_t width, uint32_t height, uint32_t n_parts,
+                               uint32_t tile_rows, uint32_t out_format, hipStream_t stream) {
     if (width == 0 || height == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_deinterleave, dim3((width + 255u) / 256u, height), dim3(256), 0, stream,
-                       reinterpret_cast<const float4*>(tiles), reinterpret_cast<float4*>(frame), width, height, n_parts,
-                       tile_rows);
+    switch (out_format) {
+        case BRT_FLAG_OUT_RGBA32F: launch_deinterleave_t<BRT_FLAG_OUT_RGBA32F>(tiles, frame, width, height, n_parts, tile_rows, stream); break;
+        case BRT_FLAG_OUT_RGBA8_UNORM_SRGB: launch_deinterleave_t<BRT_FLAG_OUT_RGBA8_UNORM_SRGB>(tiles, frame, width, height, n_parts, tile_rows, stream); break;
+        case BRT_FLAG_OUT_RGBA16F: launch_deinterleave_t<BRT_FLAG_OUT_RGBA16F>(tiles, frame, width, height, n_parts, tile_rows, stream); break;
+        case BRT_FLAG_OUT_RGBA8_UNORM: launch_deinterleave_t<BRT_FLAG_OUT_RGBA8_UNORM>(tiles, frame, width, height, n_parts, tile_rows, stream); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_strips(const float* frame, float* packed, uint32_t width, uint32_t height, uint32_t n_parts, uint32_t tile_rows,
+                              uint32_t floats_per_pixel, hipStream_t stream) {
+    if (width == 0 || height == 0 || n_parts < 2 || tile_rows == 0) return hipSuccess;
+    const dim3 grid((width + 255u) / 256u, tile_rows, n_parts - 1u);
+    if (floats_per_pixel == 4u)
+        hipLaunchKernelGGL(k_pack_strips<float4>, grid, dim3(256), 0, stream, reinterpret_cast<const float4*>(frame),
+                           reinterpret_cast<float4*>(packed), width, height, n_parts, tile_rows);
+    else
+        hipLaunchKernelGGL(k_pack_strips<float>, grid, dim3(256), 0, stream, frame, packed, width, height, n_parts, tile_rows);
     return hipGetLastError();
 }
 

@@ -79,8 +79,8 @@ struct PixelState {
 //   second half, at its start flag <- GAVE UP;  old flag == READY: the state is there, take it;  anything else: leave the pixel to
 //                             the first-half lane (this lane stays idle for the job)
 // Both are one atomic exchange on the same word, so exactly one of the two lanes goes on.  The record crosses XCDs, whose L2s are not
-// coherent with each other inside a kernel: every word is written and read by device-scope atomics (performed at the memory side, like
-// the tile queue's counter), the flag behind the RETURNS of the state words.  A flag belongs to this launch by its serial number.
+// coherent with each other inside a kernel: the flag is an agent-scope atomic (performed at the memory side, like the tile queue's
+// counter) with release / acquire semantics around the state words (BRT_SLICE_SYNC below).  A flag belongs to this launch by its serial number.
 // A first-half lane does not go to memory at once: the exchanges are a round trip (microseconds) and the lanes of a tile end in ~30
 // different rounds -- one by one that cost the headline frame 4 %.  The lane just goes idle (kSliceDone: its registers keep the state)
 // and the WAVE settles all of them in one go the next time it runs its management code (slice_settle, top of the kernel's loop).
@@ -93,12 +93,48 @@ constexpr uint32_t kSliceReady = 1u, kSliceGaveUp = 2u;      // flag word = seri
 // the half, config 5 16.9-17.5 at 6/8 against 16.7-16.9 (profiles/r04/split_tail.txt)
 BRT_DEV uint32_t slice_point(const FrameParams& fp) { return (uint32_t)(((uint64_t)fp.sample_count * BRT_SLICE_EIGHTHS) >> 3); }
 
+// How the 32-byte record crosses from one wave to another (usually another XCD, whose L2 is not coherent with this one's inside a
+// kernel).  BRT_SLICE_SYNC:
+//   1 (default)  every access to the record is an agent-scope access of its own: the state as two wide stores with sc1 (written
+//                through to the memory side: what the memory model lowers an agent-scope atomic store to, 128 and 64 bits wide --
+//                tearing does not matter, nobody reads before the flag), `s_waitcnt vmcnt(0)` (their acknowledgements), THEN the
+//                flag by an agent-scope exchange; the taker's exchange first, and behind its return two wide sc1 loads (read at the
+//                memory side, never from a stale line of this L2).  This is the release / acquire pair of (2) with the cache-wide
+//                operations left out that this record does not need: `buffer_wbl2 sc1` writes back lines that were NOT written
+//                through (ours were), `buffer_inv sc1` drops lines that plain loads might hit (ours bypass).  2 stores + 1 atomic |
+//                1 atomic + 2 loads per pixel; HBM traffic of the headline launch 342 -> ~100 MB.
+//   2            the memory model's recipe verbatim: plain wide stores, the flag exchange with RELEASE semantics (hipcc emits
+//                buffer_wbl2 sc1 + s_waitcnt before it), the taker's with ACQUIRE (buffer_inv sc1 behind it), plain wide loads.
+//                Correct by the book and measurably slower, because the invalidate drops this XCD's whole L2 every time a wave
+//                starts a second-half tile: headline frame 9.22 -> 9.29 ms, the 10 004-sphere frame (whose tree lives in L2)
+//                14.89 -> 15.72 ms (+5.6 %); profiles/r05/slice_sync_ab.txt.
+//   0            round 4: every word by its own agent-scope atomic (7 + 1 exchanges, 6 fetch_add(0)), the flag behind the returns
+//                of the others by a data dependency.  Same speed as (1), 3.4 x the HBM traffic.
+// All three render the same frames (forced-split suite, fuzz; scripts/split_stress.py: every tile of a 1080p frame split, 200
+// frames, each against the unsplit render).
+#ifndef BRT_SLICE_SYNC
+#define BRT_SLICE_SYNC 1
+#endif
+typedef uint32_t slice_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t slice_u2 __attribute__((ext_vector_type(2)));
 BRT_DEV uint32_t slice_xchg(uint32_t* p, uint32_t v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 BRT_DEV uint32_t slice_read(uint32_t* p) { return __hip_atomic_fetch_add(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // first half: true when the second-half lane has already given up on this pixel (the caller then carries on with it)
 BRT_DEV bool slice_store(const FrameParams& fp, const PixelState& ps, uint32_t rays) {
     uint32_t* rec = fp.slice_state + 8u * (size_t)ps.out_index;
+    const uint32_t ready = (fp.slice_serial << 2) | kSliceReady, gave_up = (fp.slice_serial << 2) | kSliceGaveUp;
+#if BRT_SLICE_SYNC == 2
+    *reinterpret_cast<slice_u4*>(rec) = slice_u4{ps.rng, __float_as_uint(ps.sum.x), __float_as_uint(ps.sum.y), __float_as_uint(ps.sum.z)};
+    *reinterpret_cast<slice_u2*>(rec + 4) = slice_u2{__float_as_uint(ps.dsum), rays};
+    return __hip_atomic_exchange(rec + 7, ready, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == gave_up;
+#elif BRT_SLICE_SYNC == 1
+    const slice_u4 a = {ps.rng, __float_as_uint(ps.sum.x), __float_as_uint(ps.sum.y), __float_as_uint(ps.sum.z)};
+    const slice_u2 b = {__float_as_uint(ps.dsum), rays};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx2 %0, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 :: "v"(rec), "v"(a), "v"(b) : "memory");
+    return slice_xchg(rec + 7, ready) == gave_up;
+#else
     uint32_t seen = slice_xchg(rec + 0, ps.rng);
     seen |= slice_xchg(rec + 1, __float_as_uint(ps.sum.x));
     seen |= slice_xchg(rec + 2, __float_as_uint(ps.sum.y));
@@ -106,19 +142,37 @@ BRT_DEV bool slice_store(const FrameParams& fp, const PixelState& ps, uint32_t r
     seen |= slice_xchg(rec + 4, __float_as_uint(ps.dsum));
     seen |= slice_xchg(rec + 5, rays);
     // the flag goes out when the six exchanges have RETURNED (performed): its value is made to depend on what they returned
-    uint32_t flag = (fp.slice_serial << 2) | kSliceReady;
+    uint32_t flag = ready;
     asm volatile("v_and_b32 %1, 0, %1\n\tv_or_b32 %0, %0, %1" : "+v"(flag), "+v"(seen));
-    return slice_xchg(rec + 7, flag) == ((fp.slice_serial << 2) | kSliceGaveUp);
+    return slice_xchg(rec + 7, flag) == gave_up;
+#endif
 }
 
 // second half: true when the state was there (ps continues at sample_count / 2; *rays_before = rays of the first half)
 BRT_DEV bool slice_load(const FrameParams& fp, PixelState& ps, uint32_t* rays_before) {
     uint32_t* rec = fp.slice_state + 8u * (size_t)ps.out_index;
-    if (slice_xchg(rec + 7, (fp.slice_serial << 2) | kSliceGaveUp) != ((fp.slice_serial << 2) | kSliceReady)) return false;
-    ps.rng = slice_read(rec + 0);
-    ps.sum = mk3(__uint_as_float(slice_read(rec + 1)), __uint_as_float(slice_read(rec + 2)), __uint_as_float(slice_read(rec + 3)));
-    ps.dsum = __uint_as_float(slice_read(rec + 4));
-    *rays_before = slice_read(rec + 5);
+    const uint32_t ready = (fp.slice_serial << 2) | kSliceReady, gave_up = (fp.slice_serial << 2) | kSliceGaveUp;
+#if BRT_SLICE_SYNC == 2
+    if (__hip_atomic_exchange(rec + 7, gave_up, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ready) return false;
+    const slice_u4 a = *reinterpret_cast<const slice_u4*>(rec);
+    const slice_u2 b = *reinterpret_cast<const slice_u2*>(rec + 4);
+#elif BRT_SLICE_SYNC == 1
+    if (slice_xchg(rec + 7, gave_up) != ready) return false;
+    slice_u4 a;
+    slice_u2 b;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b) : "v"(rec) : "memory");
+#else
+    if (slice_xchg(rec + 7, gave_up) != ready) return false;
+    slice_u4 a;
+    slice_u2 b;
+    a.x = slice_read(rec + 0); a.y = slice_read(rec + 1); a.z = slice_read(rec + 2); a.w = slice_read(rec + 3);
+    b.x = slice_read(rec + 4); b.y = slice_read(rec + 5);
+#endif
+    ps.rng = a.x;
+    ps.sum = mk3(__uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+    ps.dsum = __uint_as_float(b.x);
+    *rays_before = b.y;
     ps.sample = slice_point(fp);
     return true;
 }
@@ -133,7 +187,7 @@ BRT_DEV void pixel_begin(const FrameParams& fp, const PixelCoord& c, PixelState&
     ps.dsum = 0.0f;
     ps.sample = 0;
     ps.out_index = c.local_row * fp.width + c.px;
-    ps.frame_index = c.py * fp.width + c.px;
+    ps.frame_index = fp.raster_dense ? ps.out_index : c.py * fp.width + c.px;
     ps.tile = c.tile;
 }
 

@@ -173,7 +173,7 @@ public:
     // copy over xGMI, one de-interleave kernel): `d_destination` is a device pointer, e.g. the mapped colour target
     // (pipeline.rs:191-203).  d_raster_* are optional device buffers on the first device.
     bool run_device(const std::optional<std::pair<RaytraceLevelExtract, CameraExtract>>& view, const WindowExtract& window,
-                    uint32_t width, uint32_t height, const float* d_raster_rgba, const float* d_raster_depth, float* d_destination,
+                    uint32_t width, uint32_t height, const float* d_raster_rgba, const float* d_raster_depth, void* d_destination,
                     void* hip_stream = nullptr, brt_stats* stats = nullptr, uint32_t flags = 0) {
         if (!view) return false;
         check(brt_render_device(ctx_, &view->second, &window, view->first.level, width, height, d_raster_rgba, d_raster_depth,
@@ -190,7 +190,7 @@ public:
         return true;
     }
     void gather(void* comm, int32_t rank, int32_t world, const float* d_tile, float* d_tiles_on_root, uint32_t width, uint32_t height,
-                float* d_frame_on_root, void* hip_stream = nullptr, uint32_t flags = 0) {
+                void* d_frame_on_root, void* hip_stream = nullptr, uint32_t flags = 0) {
         check(brt_gather_rccl(ctx_, comm, rank, world, d_tile, d_tiles_on_root, width, height, d_frame_on_root, hip_stream, flags), ctx_);
     }
 private:
@@ -218,12 +218,12 @@ public:
     void set_tuning(const char* name, uint32_t value) { check(brt_set_tuning(ctx_, name, value), ctx_); }
     // the colour target's memory, exported by the host's graphics API as a file descriptor (pipeline.rs:191-203 renders straight
     // into post_process.destination): a device pointer that run_device / gather accept as the frame (brt_import_frame_fd)
-    float* import_frame(int32_t fd, uint64_t bytes, uint32_t handle_type = BRT_EXTMEM_OPAQUE_FD) {
-        float* d = nullptr;
+    void* import_frame(int32_t fd, uint64_t bytes, uint32_t handle_type = BRT_EXTMEM_OPAQUE_FD) {
+        void* d = nullptr;
         check(brt_import_frame_fd(ctx_, fd, bytes, handle_type, &d), ctx_);
         return d;
     }
-    void release_frame(float* d_frame) { check(brt_release_frame(ctx_, d_frame), ctx_); }
+    void release_frame(void* d_frame) { check(brt_release_frame(ctx_, d_frame), ctx_); }
     // the communicator of the one-process-per-GPU form: `id` from rccl_unique_id() on rank 0, handed to the others by the host's means
     static std::array<char, 128> rccl_unique_id() {
         std::array<char, 128> id{};

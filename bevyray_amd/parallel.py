@@ -44,23 +44,40 @@ class RcclGather:
     def create(plugin, rank: int, world: int, group=None):
         import torch
         import torch.distributed as dist
-        ok, uid = 1, b""
-        if rank == 0:
-            try:
-                uid = plugin.rccl_unique_id()          # also proves that librccl resolves (dlopen) in this process
-            except Exception:                          # noqa: BLE001
-                ok = 0
-        if world > 1:
-            box = [uid if ok else None]
-            dist.broadcast_object_list(box, src=0, group=group)
-            if box[0] is None:
-                return None
-            uid = box[0]
-        elif not ok:
+
+        def all_ok(ok: bool) -> bool:
+            """every rank takes the same path: min over the ranks' flags (a CPU tensor under gloo, a device tensor under nccl)"""
+            if world == 1:
+                return ok
+            dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            return bool(int(t.item()))
+
+        # EVERY rank proves that librccl resolves (dlopen) in its process -- a rank without it would otherwise fall back alone and
+        # leave the others waiting in ncclCommInitRank
+        uid, ok = b"", True
+        try:
+            uid = plugin.rccl_unique_id()
+        except Exception:                              # noqa: BLE001
+            ok = False
+        if not all_ok(ok):
             return None
+        if world > 1:
+            box = [uid]
+            dist.broadcast_object_list(box, src=0, group=group)      # rank 0's id is the communicator's
+            uid = box[0]
+        comm = 0
         try:
             comm = plugin.rccl_comm_create(uid, rank, world)
-        except Exception:                              # noqa: BLE001  (every rank fails alike: same library, same node)
+        except Exception:                              # noqa: BLE001
+            ok = False
+        if not all_ok(ok):                             # (a device error on one rank: the ranks that did get a communicator give it back)
+            if comm:
+                try:
+                    plugin.rccl_comm_destroy(comm)
+                except Exception:                      # noqa: BLE001
+                    pass
             return None
         return RcclGather(plugin, comm, rank, world)
 

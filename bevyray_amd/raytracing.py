@@ -50,6 +50,9 @@ FLAG_KERNEL_SIMPLE = 2
 POLICY_OR_SHORT_CIRCUIT = 1   # brt_set_policy: the WGSL-spec reading of `||` in raytrace.wgsl:269 (default: both operands evaluated)
 EXTMEM_OPAQUE_FD, EXTMEM_DMABUF_FD = 1, 2   # brt_import_frame_fd handle types
 FLAG_CALLER_STREAM = 4   # device entry points: `stream` is the caller's stream even when its handle is 0
+# format of an assembled DEVICE frame (render_device, gather_rccl, deinterleave_device): the colour target's own (pipeline.rs:311-315)
+FLAG_OUT_RGBA32F, FLAG_OUT_RGBA8_UNORM_SRGB, FLAG_OUT_RGBA16F, FLAG_OUT_RGBA8_UNORM = 0, 8, 16, 24
+OUT_PIXEL_BYTES = {FLAG_OUT_RGBA32F: 16, FLAG_OUT_RGBA8_UNORM_SRGB: 4, FLAG_OUT_RGBA16F: 8, FLAG_OUT_RGBA8_UNORM: 4}
 
 SCENE_COVER, SCENE_RTIOW_FINAL, SCENE_STRESS_GRID = 0, 1, 2
 
@@ -193,6 +196,13 @@ def tree_reach(models: np.ndarray, camera: np.ndarray):
     s, lvl, r = C.c_float(0), C.c_uint32(0), C.c_float(0)
     _lib.check(lib.brt_host_tree_reach(models.ctypes.data, len(models), camera.ctypes.data, C.byref(s), C.byref(lvl), C.byref(r)))
     return float(s.value), int(lvl.value), float(r.value)
+
+
+def srgb_thresholds() -> np.ndarray:
+    """brt_host_srgb_thresholds: the 255 f32 decision thresholds of the exact 8-bit sRGB encode (code = thresholds <= c)."""
+    out = np.zeros(255, np.float32)
+    _lib.check(_lib.load().brt_host_srgb_thresholds(out.ctypes.data_as(C.POINTER(C.c_float))))
+    return out
 
 
 def validate_scene(models, materials, bvh) -> int:
@@ -515,17 +525,18 @@ class RayTracingNode:
         return self.last_stats
 
     def deinterleave_device(self, d_tiles: int, n_parts: int, width: int, height: int, d_frame: int,
-                            stream: Optional[int] = None):
+                            stream: Optional[int] = None, out_format: int = FLAG_OUT_RGBA32F):
         """stream=None: own stream, synchronous.  stream=<handle> (0 = default stream): asynchronous there --
-        pass the stream the gather was enqueued on so that the copy kernel runs behind it."""
+        pass the stream the gather was enqueued on so that the copy kernel runs behind it.  out_format: FLAG_OUT_*."""
         p = self._p
         _lib.check(p._lib.brt_deinterleave_device(p._ctx, d_tiles, n_parts, width, height, d_frame, stream or None,
-                                                  0 if stream is None else FLAG_CALLER_STREAM), p._ctx)
+                                                  (0 if stream is None else FLAG_CALLER_STREAM) | out_format), p._ctx)
 
     def gather_rccl(self, comm: int, rank: int, world: int, d_tile: int, d_tiles_on_root: int, width: int, height: int,
-                    d_frame_on_root: int = 0, stream: Optional[int] = None):
+                    d_frame_on_root: int = 0, stream: Optional[int] = None, out_format: int = FLAG_OUT_RGBA32F):
         """brt_gather_rccl: ONE ncclGather of every rank's tile to rank 0 and, there, the de-interleave kernel behind it on the
         same stream.  Stream rule as for render_part_device."""
         p = self._p
         _lib.check(p._lib.brt_gather_rccl(p._ctx, comm, rank, world, d_tile, d_tiles_on_root or None, width, height,
-                                          d_frame_on_root or None, stream or None, 0 if stream is None else FLAG_CALLER_STREAM), p._ctx)
+                                          d_frame_on_root or None, stream or None,
+                                          (0 if stream is None else FLAG_CALLER_STREAM) | out_format), p._ctx)

@@ -31,7 +31,8 @@
  *                              near f32 @12, far @16, fov @20, aspect @24,
  *                              position vec3 @32, direction vec3 @48, up vec3 @64
  *       WindowExtract    16 B  random_seed f32 @0, height u32 @4
- *   - Frames are RGBA f32, row-major, top row first, width*height*16 bytes.
+ *   - Frames are RGBA f32, row-major, top row first, width*height*16 bytes (device frames optionally in the colour
+ *     target's own format: BRT_FLAG_OUT_*).
  */
 #ifndef BEVYRAY_AMD_H
 #define BEVYRAY_AMD_H
@@ -73,10 +74,25 @@ enum {
 enum {
     BRT_FLAG_COUNTERS = 1u,        /* also count node pops / interior visits / sphere tests / hits */
     BRT_FLAG_KERNEL_SIMPLE = 2u,   /* one-thread-per-pixel bring-up kernel instead of the persistent one */
-    BRT_FLAG_CALLER_STREAM = 4u    /* device entry points: `hip_stream` is the caller's stream even when it is NULL
+    BRT_FLAG_CALLER_STREAM = 4u,   /* device entry points: `hip_stream` is the caller's stream even when it is NULL
                                       (NULL is then the legacy default stream, not "the context's own stream"):
                                       the work is enqueued there, ordered with whatever the caller enqueued before
                                       (e.g. an RCCL gather), and the call does not synchronise */
+    /* Format of the assembled DEVICE frame (brt_render_device, brt_gather_rccl, brt_deinterleave_device): the reference's pass writes
+     * into post_process.destination, whose format is TextureFormat::bevy_default() (pipeline.rs:311-315) -- an 8-bit sRGB target, or
+     * Rgba16Float under HDR -- so with brt_import_frame_fd the frame can be stored where the next pass reads it, in that format.
+     * The pass's result IS the RGBA f32 frame (parity is stated on it); the other formats are its store conversion, exactly:
+     *   RGBA8_UNORM_SRGB  r, g, b: round(255 * OETF(clamp(c, 0, 1))), OETF the sRGB encode (12.92 c below 0.0031308, else
+     *                     1.055 c^(1/2.4) - 0.055), evaluated exactly (as the number of decision thresholds <= c, see
+     *                     bevyray_amd/csrc/brt_srgb_table.h); alpha: the RGBA8_UNORM rule.  NaN stores 0.  4 bytes per pixel, r first.
+     *   RGBA8_UNORM       round-half-even(255 * clamp(c, 0, 1)), exact.  4 bytes per pixel.
+     *   RGBA16F           f32 -> f16, round to nearest even.  8 bytes per pixel.
+     * brt_render / brt_render_part_device always write RGBA f32 (host frame / a rank's tile: the tiles travel as f32). */
+    BRT_FLAG_OUT_RGBA32F = 0u,
+    BRT_FLAG_OUT_RGBA8_UNORM_SRGB = 8u,
+    BRT_FLAG_OUT_RGBA16F = 16u,
+    BRT_FLAG_OUT_RGBA8_UNORM = 24u,
+    BRT_FLAG_OUT_MASK = 24u
 };
 
 typedef struct brt_ctx brt_ctx;
@@ -201,7 +217,7 @@ int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* w
 int32_t brt_render_device(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level,
                           uint32_t width, uint32_t height,
                           const float* d_raster_rgba, const float* d_raster_depth,
-                          float* d_frame, void* hip_stream, uint32_t flags, brt_stats* stats_or_null);
+                          void* d_frame, void* hip_stream, uint32_t flags, brt_stats* stats_or_null);
 
 /* Rows in the dense tile of `part` (same for every part: padded to whole strips). */
 uint32_t brt_tile_rows(uint32_t height, uint32_t n_parts);
@@ -213,7 +229,7 @@ uint32_t brt_tile_rows(uint32_t height, uint32_t n_parts);
  * pass the stream the gather was enqueued on (with BRT_FLAG_CALLER_STREAM if that is the default stream), or
  * the copy kernel is not ordered behind the gather. */
 int32_t brt_deinterleave_device(brt_ctx* ctx, const float* d_tiles, uint32_t n_parts,
-                                uint32_t width, uint32_t height, float* d_frame, void* hip_stream, uint32_t flags);
+                                uint32_t width, uint32_t height, void* d_frame, void* hip_stream, uint32_t flags);
 
 /* ---- the one collective of the path: one process per GPU, one RCCL gather per frame -----------------
  * For a host that runs one process per GPU (instead of one N-device context, brt_render_device): every rank renders its part
@@ -231,7 +247,7 @@ int32_t brt_rccl_unique_id(void* out_id128);
 int32_t brt_rccl_comm_create(brt_ctx* ctx, const void* id128, int32_t rank, int32_t world, void** out_comm);
 int32_t brt_rccl_comm_destroy(brt_ctx* ctx, void* comm);
 int32_t brt_gather_rccl(brt_ctx* ctx, void* nccl_comm, int32_t rank, int32_t world, const float* d_tile, float* d_tiles_on_root,
-                        uint32_t width, uint32_t height, float* d_frame_on_root, void* hip_stream, uint32_t flags);
+                        uint32_t width, uint32_t height, void* d_frame_on_root, void* hip_stream, uint32_t flags);
 
 /* ---- a frame target in another API's memory -----------------------------------------------------------
  * Replaces: the pass writing straight into post_process.destination (pipeline.rs:191-203).  The host exports the memory behind
@@ -242,12 +258,12 @@ int32_t brt_gather_rccl(brt_ctx* ctx, void* nccl_comm, int32_t rank, int32_t wor
  * BRT_EXTMEM_DMABUF_FD = a dma-buf of a HIP virtual-memory allocation (hipMemImportFromShareableHandle; the caller keeps and
  * closes its descriptor).  brt_release_frame unmaps (after the context's pending work); brt_destroy releases what is left. */
 enum { BRT_EXTMEM_OPAQUE_FD = 1, BRT_EXTMEM_DMABUF_FD = 2 };
-int32_t brt_import_frame_fd(brt_ctx* ctx, int32_t fd, uint64_t bytes, uint32_t handle_type, float** out_d_frame);
-int32_t brt_release_frame(brt_ctx* ctx, float* d_frame);
+int32_t brt_import_frame_fd(brt_ctx* ctx, int32_t fd, uint64_t bytes, uint32_t handle_type, void** out_d_frame);
+int32_t brt_release_frame(brt_ctx* ctx, void* d_frame);
 /* Diagnostic (tests): allocates `bytes` of exportable device memory on the first device (hipMemCreate), maps it and exports it
  * as a dma-buf descriptor -- the other side of brt_import_frame_fd when no Vulkan is at hand.  Release with brt_release_frame;
  * the caller closes the descriptor. */
-int32_t brt_debug_export_frame_fd(brt_ctx* ctx, uint64_t bytes, int32_t* out_fd, float** out_d_ptr);
+int32_t brt_debug_export_frame_fd(brt_ctx* ctx, uint64_t bytes, int32_t* out_fd, void** out_d_ptr);
 /* Diagnostic: hipMemcpy device -> host on the context's first device (for pointers that are no tensor of the caller's). */
 int32_t brt_debug_copy_to_host(brt_ctx* ctx, const void* d_src, void* h_dst, uint64_t bytes);
 
@@ -265,8 +281,10 @@ enum {
     BRT_DBG_DIV = 6,       /* in: n, d            out: n / d, shared-reciprocal short form, 1 / d, its short form (brt_device.h) */
     BRT_DBG_DIV_SWEEP = 7, /* in: seed (bits), count          out: mismatches of the short forms over `count` random plain-range pairs,
                               bits of the first mismatching n and d */
-    BRT_DBG_SQRT_SWEEP = 8 /* in: first (bits), count         out: mismatches of the short sqrt over `count` consecutive floats per element
+    BRT_DBG_SQRT_SWEEP = 8,/* in: first (bits), count         out: mismatches of the short sqrt over `count` consecutive floats per element
                               (element i starts at first + i * count; element 0 also checks +0 and -0), bits of the first mismatching argument */
+    BRT_DBG_ENCODE = 9     /* in: c               out (as floats holding integers): the 8-bit sRGB code, the 8-bit unorm code, the f16 bits of c
+                              (the store conversions of BRT_FLAG_OUT_*) */
 };
 int32_t brt_debug_eval(brt_ctx* ctx, uint32_t op, const float* in16, float* out8, uint32_t n);
 
@@ -351,6 +369,11 @@ int32_t brt_build_bvh_device(brt_ctx* ctx, const void* models, uint32_t n_models
  * the reference rebuilds and re-uploads per frame, extract.rs:299-336 -- costs no host-side build.  Needs a context (a GPU). */
 int32_t brt_build_bvh_sah_device(brt_ctx* ctx, const void* models, uint32_t n_models, float reach,
                                  void* out_nodes, uint32_t capacity, uint32_t* out_n_nodes, double* out_build_ms);
+
+/* The 255 decision thresholds of the exact 8-bit sRGB encode (BRT_FLAG_OUT_RGBA8_UNORM_SRGB): out255[k - 1] = the smallest f32 >=
+ * EOTF((k - 0.5) / 255); the code of a linear value c is the number of thresholds <= c.  For hosts / tests that want to state the
+ * same encode on the CPU. */
+int32_t brt_host_srgb_thresholds(float* out255);
 
 /* Checks what brt_upload_scene checks, without a context. */
 int32_t brt_validate_scene(const void* models, uint32_t n_models,

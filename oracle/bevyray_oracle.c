@@ -598,3 +598,53 @@ int oracle_raycast(const void* models, uint32_t n_models, const void* bvh_nodes,
     *out_material = h.material; *out_front = h.front_face;
     return 0;
 }
+
+/* ---- the colour target's store (checker-side restatement) ---------------------------------------------------------
+ * The reference's pass writes its vec4<f32> result into post_process.destination, a texture of format
+ * TextureFormat::bevy_default() (/root/reference/src/raytracing/pipeline.rs:311-315, :193-199): an 8-bit sRGB target, or
+ * Rgba16Float under HDR.  The conversion belongs to the store, not to the shader; the product offers it for its device
+ * frames (include/bevyray_amd.h BRT_FLAG_OUT_*), and this is what the tests hold those frames to -- the formulas in
+ * double precision, where the product counts precomputed f32 thresholds:
+ *   format 1  RGBA8 sRGB   r, g, b: nearbyint(255 * OETF(clamp(c, 0, 1))), OETF(c) = 12.92 c (c <= 0.0031308) else
+ *                          1.055 c^(1/2.4) - 0.055; alpha: format 3's rule.  NaN stores 0.
+ *   format 2  RGBA16F      f32 -> f16, round to nearest even, overflow to infinity, denormals kept
+ *   format 3  RGBA8        nearbyint(255 * clamp(c, 0, 1)) (ties to even; the product 255 c is exact in double)          */
+static uint8_t unorm8(float c) {
+    double x = c > 0.0f ? (c < 1.0f ? (double)c : 1.0) : 0.0;
+    return (uint8_t)nearbyint(255.0 * x);
+}
+static uint8_t srgb8(float c) {
+    double x = c > 0.0f ? (c < 1.0f ? (double)c : 1.0) : 0.0;
+    double e = x <= 0.0031308 ? 12.92 * x : 1.055 * pow(x, 1.0 / 2.4) - 0.055;
+    return (uint8_t)nearbyint(255.0 * e);
+}
+static uint16_t f32_to_f16_rne(float f) {
+    uint32_t u = f2u(f), sign = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u | ((a >> 13) & 0x1ffu));     /* NaN (quiet) */
+    if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                            /* rounds to >= 65520: infinity */
+    if (a < 0x33000001u) return (uint16_t)sign;                                         /* <= 2^-25: rounds to zero (2^-25 itself ties to even = 0) */
+    int32_t e = (int32_t)(a >> 23) - 127;
+    uint32_t m = (a & 0x7fffffu) | 0x800000u;                                           /* 24-bit significand */
+    uint32_t shift = e < -14 ? (uint32_t)(13 + (-14 - e)) : 13u;                        /* bits dropped (denormal results drop more) */
+    uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1u);
+    if (rem > half || (rem == half && (q & 1u))) q++;
+    if (e < -14) return (uint16_t)(sign | q);                                           /* denormal (q may carry into the smallest normal) */
+    return (uint16_t)(sign | (((uint32_t)(e + 15) << 10) + (q - 0x400u)));              /* (a carry out of q bumps the exponent) */
+}
+int oracle_encode_frame(const float* rgba, uint64_t n_pixels, int format, void* out) {
+    if (!rgba || !out) return -1;
+    for (uint64_t i = 0; i < n_pixels; i++) {
+        const float* p = rgba + 4 * i;
+        if (format == 1 || format == 3) {
+            uint8_t* o = (uint8_t*)out + 4 * i;
+            for (int k = 0; k < 3; k++) o[k] = format == 1 ? srgb8(p[k]) : unorm8(p[k]);
+            o[3] = unorm8(p[3]);
+        } else if (format == 2) {
+            uint16_t* o = (uint16_t*)out + 4 * i;
+            for (int k = 0; k < 4; k++) o[k] = f32_to_f16_rne(p[k]);
+        } else {
+            return -2;
+        }
+    }
+    return 0;
+}

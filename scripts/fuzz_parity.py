@@ -247,11 +247,12 @@ def main():
                 # the callee's SAH tree follows the camera (larger leaf pads for a camera further out): the oracle walks the CPU twin of
                 # the tree the context says it built, and that tree must cover what this camera needs
                 need = brt.tree_reach(b.models, c["camera"])[2]
-                if stats["tree_reach"] < need:
-                    raise AssertionError(f"resident tree built for reach {stats['tree_reach']}, this camera needs {need}")
                 if stats["tree_reach"] != 0.0:
                     reach_checked += 1
                     ob = brt.Buffers(b.models, b.materials, brt.build_bvh_sah(b.models, stats["tree_reach"]))
+                # (built for at least this camera's reach -- or the very same bytes, where every pad is at its clamp either way)
+                if stats["tree_reach"] < need and ob.bvh.tobytes() != brt.build_bvh_sah(b.models, need).tobytes():
+                    raise AssertionError(f"resident tree built for reach {stats['tree_reach']}, this camera needs {need}")
             want, cnt = oracle.render(ob, c["level"], c["camera"], c["window"], c["w"], c["h"], raster_rgba=c["raster"],
                                       raster_depth=c["depth"])
             bad = frames_differ(got, want)

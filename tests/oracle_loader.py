@@ -74,6 +74,8 @@ class Oracle:
         lib.oracle_ray_bounding_dst.argtypes = [C.POINTER(F)] * 4
         lib.oracle_hit_sphere.restype = F
         lib.oracle_hit_sphere.argtypes = [C.POINTER(F)] * 3 + [F]
+        lib.oracle_encode_frame.restype = C.c_int
+        lib.oracle_encode_frame.argtypes = [VP, C.c_uint64, C.c_int, VP]
         lib.oracle_raycast.restype = C.c_int
         lib.oracle_raycast.argtypes = [VP, U32, VP, U32, C.POINTER(F), C.POINTER(F), C.POINTER(F), C.POINTER(U32),
                                        C.POINTER(C.c_int)]
@@ -100,6 +102,16 @@ class Oracle:
             raise RuntimeError(f"oracle_render failed: {rc}")
         names = ["rays", "node_pops", "interior_visits", "sphere_tests", "hits"]
         return out, dict(zip(names, [int(x) for x in cnt]))
+
+    def encode_frame(self, frame, fmt):
+        """The colour target's store conversion of an (H, W, 4) f32 frame: fmt "srgb8" / "unorm8" -> (H, W, 4) u8, "f16" -> (H, W, 4) u16 bits."""
+        frame = np.ascontiguousarray(frame, np.float32)
+        code = {"srgb8": 1, "f16": 2, "unorm8": 3}[fmt]
+        out = np.zeros(frame.shape, np.uint16 if fmt == "f16" else np.uint8)
+        rc = self.lib.oracle_encode_frame(frame.ctypes.data, frame.size // 4, code, out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"oracle_encode_frame failed: {rc}")
+        return out
 
     def policy(self, or_short_circuit=False, minmax="minnum", pow="mul"):
         """Context manager: render under an alternative policy (same names as numpy_restatement.DEFAULT_POLICY)."""

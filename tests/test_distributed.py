@@ -71,6 +71,61 @@ def test_single_rank_is_identity():
     assert torch.equal(frame, _pattern(np.arange(24), 8))
 
 
+class _StubRcclPlugin:
+    """what RcclGather.create needs of a RaytracePlugin, with a rank that cannot resolve librccl / cannot create its communicator"""
+
+    def __init__(self, rank, fail_probe_on, fail_create_on, log):
+        self.rank, self.fail_probe_on, self.fail_create_on, self.log = rank, fail_probe_on, fail_create_on, log
+
+    def rccl_unique_id(self):
+        if self.rank == self.fail_probe_on:
+            raise RuntimeError("librccl not found")
+        return bytes([self.rank]) * 128
+
+    def rccl_comm_create(self, uid, rank, world):
+        self.log.append(("create", uid[0]))
+        if self.rank == self.fail_create_on:
+            raise RuntimeError("device error")
+        return 1000 + rank
+
+    def rccl_comm_destroy(self, comm):
+        self.log.append(("destroy", comm))
+
+
+def _create_worker(rank, world, port, fail_probe_on, fail_create_on, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bevyray_amd.parallel import RcclGather
+        log = []
+        g = RcclGather.create(_StubRcclPlugin(rank, fail_probe_on, fail_create_on, log), rank, world)
+        with open(os.path.join(out_dir, f"r{rank}.txt"), "w") as f:
+            f.write(repr((None if g is None else g.comm, log)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_probe_on,fail_create_on", [(-1, -1), (1, -1), (0, -1), (-1, 1)])
+def test_rccl_gather_create_every_rank_takes_the_same_path(tmp_path, fail_probe_on, fail_create_on):
+    """RcclGather.create probed librccl on rank 0 only -- a rank != 0 without it fell back alone and left the others in
+    ncclCommInitRank.  Now every rank probes, the flags are min-reduced before and after the communicator is created, and all
+    ranks return a gather object or all return None (a communicator a rank did get is given back)."""
+    import ast
+    mp.spawn(_create_worker, args=(2, _free_port(), fail_probe_on, fail_create_on, str(tmp_path)), nprocs=2, join=True)
+    res = [ast.literal_eval((tmp_path / f"r{r}.txt").read_text()) for r in range(2)]
+    if fail_probe_on < 0 and fail_create_on < 0:
+        assert [r[0] for r in res] == [1000, 1001]
+        assert res[0][1] == [("create", 0)] and res[1][1] == [("create", 0)]          # rank 0's id is the communicator's
+    else:
+        assert [r[0] for r in res] == [None, None]
+        if fail_probe_on >= 0:
+            assert res[0][1] == [] and res[1][1] == []                                # nobody entered ncclCommInitRank
+        else:
+            assert res[0][1] == [("create", 0), ("destroy", 1000)] and res[1][1] == [("create", 0)]
+
+
 def _run_bench(extra_env, *argv):
     import json
     import subprocess

@@ -446,3 +446,51 @@ def test_far_camera_frames_in_the_callee_tree_equal_the_reference_tree(oracle):
         assert np.array_equal(frames[0].view(np.uint32), frames[2].view(np.uint32))
         lost += int((frames[3].view(np.uint32) != frames[2].view(np.uint32)).any(axis=2).sum())
     assert lost > 100            # the camera-blind tree does lose pixels out there: the case is real
+
+
+def test_rccl_not_found_is_an_error_code_not_a_crash():
+    """a host without librccl (the single-GPU case the header says needs none) must get BRT_ERR_RCCL from every
+    brt_rccl_* / brt_gather_rccl call -- the message built from ONE dlerror() call (a second one returns NULL).  Own process: the
+    library resolves librccl once.  BRT_RCCL_LIB names the only library tried."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        "from bevyray_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "buf = (C.c_char * 128)()\n"
+        "rc = lib.brt_rccl_unique_id(buf)\n"
+        "msg = lib.brt_last_error(None).decode()\n"
+        "rc2 = lib.brt_rccl_unique_id(buf)\n"
+        "print(rc, rc2, msg)\n")
+    env = dict(os.environ, BRT_RCCL_LIB="/nonexistent/librccl_not_here.so", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    rc, rc2, msg = proc.stdout.strip().split(" ", 2)
+    assert (rc, rc2) == ("-10", "-10")
+    assert "librccl not found" in msg and "librccl_not_here" in msg
+
+
+def test_srgb_store_thresholds_and_the_oracle_formula_agree_at_every_decision_point(oracle):
+    """BRT_FLAG_OUT_RGBA8_UNORM_SRGB (the store into TextureFormat::bevy_default(), pipeline.rs:311-315): the product counts 255
+    precomputed f32 thresholds (exact: scripts/gen_srgb_table.py evaluates them in 60-digit arithmetic), the oracle evaluates
+    round(255 * OETF(c)) in double.  They must agree on every f32 -- it suffices to look where the code changes: at each threshold the
+    oracle says k, one float below it k - 1; plus a dense sample, the segment joint and the specials."""
+    t = brt.srgb_thresholds()
+    assert t.shape == (255,) and np.all(np.diff(t) > 0) and 0 < t[0] and t[-1] < 1
+    below = np.nextafter(t, np.float32(-1.0), dtype=np.float32)
+    enc = lambda x: oracle.encode_frame(np.stack([x, x, x, x], axis=-1).reshape(-1, 1, 4), "srgb8")[:, 0, 0].astype(np.int64)
+    assert np.array_equal(enc(t), np.arange(1, 256)) and np.array_equal(enc(below), np.arange(0, 255))
+    rng = np.random.default_rng(9)
+    x = np.concatenate([rng.random(300000).astype(np.float32), (rng.random(100000) * 0.01).astype(np.float32),
+                        np.array([0.0, -0.0, 1.0, 2.0, -1.0, np.inf, -np.inf, np.nan, 0.0031308, 0.00313080495, 0.04045, 1e-30], np.float32)])
+    with np.errstate(invalid="ignore"):
+        want = np.searchsorted(t, x, side="right")       # thresholds <= x  (NaN sorts last: fixed below)
+    want[np.isnan(x)] = 0
+    assert np.array_equal(enc(x), want)
+    # the regenerated table is the committed one
+    import subprocess, sys
+    header = os.path.join(ROOT, "bevyray_amd", "csrc", "brt_srgb_table.h")
+    before = open(header).read()
+    subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_srgb_table.py")], check=True, capture_output=True)
+    assert open(header).read() == before

@@ -435,11 +435,22 @@ def _render_device_frames(device_ids, oracle):
         for f, want in zip(frames, wants):
             assert_frames_equal(f.cpu().numpy(), want)
         # depth blend with raster inputs on the first device (forwarded to the others), and the passthrough level
+        n = len(device_ids)
         for level in (brt.Raytracing.FallbackRaytraced, brt.Raytracing.FallbackRaster, brt.Raytracing.Skip):
             lvl, cam, win = brt.cover_camera(w, h, 2, 4, level)
-            p.node.render_device(lvl, cam, win, w, h, frame.data_ptr(), d_raster.data_ptr(), d_depth.data_ptr())
+            st = p.node.render_device(lvl, cam, win, w, h, frame.data_ptr(), d_raster.data_ptr(), d_depth.data_ptr())
             want, _ = oracle.render(b, lvl, cam, win, w, h, raster_rgba=raster, raster_depth=depth)
             assert_frames_equal(frame.cpu().numpy(), want)
+            # only each device's own strips of the raster inputs travel (the whole frame went to every device): the
+            # tiles of devices 1 .. n-1, colour (+ depth unless the level is the passthrough, which reads no depth)
+            strips = brt.tile_rows(h, n) * w * (16 + (4 if level != brt.Raytracing.Skip else 0)) * (n - 1)
+            assert st["forwarded_bytes"] == strips and strips <= 1.1 * (n - 1) / n * (h + 8 * n) * w * 20
+        # ... and the host-pointer form (brt_render): every device is sent its strips by one strided copy
+        for level in (brt.Raytracing.FallbackRaytraced, brt.Raytracing.FallbackRaster, brt.Raytracing.Skip):
+            lvl, cam, win = brt.cover_camera(w, h, 2, 4, level, seed=0.61)
+            got = p.node.run(lvl, cam, win, w, h, raster_rgba=raster, raster_depth=depth)
+            want, _ = oracle.render(b, lvl, cam, win, w, h, raster_rgba=raster, raster_depth=depth)
+            assert_frames_equal(got, want)
 
 
 @pytest.mark.parametrize("ids", [[0], [0, 0], [0, 0, 0, 0, 0]])
@@ -685,6 +696,28 @@ def test_gpu_sah_build_is_byte_identical_to_cpu_build(plugin, oracle):
     assert_frames_equal(got2, want)
 
 
+def test_bringup_kernel_after_frames_with_half_sample_jobs(plugin, oracle):
+    """a dispatch order with half-sample jobs has n_tiles + n_split entries laid out [non-sky | second halves | sky], which
+    only the persistent kernel understands; the bring-up kernel (BRT_FLAG_KERNEL_SIMPLE) indexed it as a plain order -- split tiles
+    twice, the last sky tiles never, stale pixels of the previous camera there.  It now runs in raster order whatever the history."""
+    b = fixture_buffers()[0]
+    w, h = 192, 104
+    with plugin.tuning(BRT_SPLIT_FORCE=40):
+        lvl, cam, win = uniforms(w, h, 16, 4, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 0.4, 0.5)
+        f1 = plugin.node.run(lvl, cam, win, w, h, buffers=b)
+        f2 = plugin.node.run(lvl, cam, win, w, h)                       # in the order the first frame measured: half-sample jobs
+        plugin.debug_profile()
+        assert plugin.last_order_meta["split_tiles"] > 0
+        assert_frames_equal(f1, f2)
+        lvl, cam, win = uniforms(w, h, 16, 4, (11.0, 3.5, -4.0), (0.5, 0.0, 0.0), 0.5, 0.25)      # another camera, another seed
+        got = plugin.node.run(lvl, cam, win, w, h, flags=brt.FLAG_KERNEL_SIMPLE | brt.FLAG_COUNTERS)
+        st = dict(plugin.node.last_stats)
+        want, cnt = oracle.render(b, lvl, cam, win, w, h)
+        assert_frames_equal(got, want)
+        assert {q: st[q] for q in COUNTER_KEYS} == cnt
+        assert_frames_equal(plugin.node.run(lvl, cam, win, w, h), want)      # and the persistent kernel again, same view
+
+
 def _far_camera(k, w, h, spp, bounces):
     """the cover view from k times the distance, field of view narrowed by k: the same picture, rays k times as long"""
     return uniforms(w, h, spp, bounces, (13.0 * k, 2.0 * k, 3.0 * k), (0.0, 0.0, 0.0), 0.4 / k, 0.5, far=1.0e5)
@@ -715,8 +748,11 @@ def test_far_camera_callee_tree_is_rebuilt_for_the_camera(plugin, oracle, kind):
         st = dict(plugin.node.last_stats)
         rebuilt.setdefault(k, []).append(st["tree_rebuilt"])
         level, reach = brt.tree_reach(b.models, cam)[1:]
-        assert st["tree_reach"] >= reach and (st["tree_reach"] == reach or k == 57)     # never below what this camera needs
         twin = brt.build_bvh_sah(b.models, st["tree_reach"])
+        # never a tree whose pads are below what this camera needs: built for at least its reach -- or, where every pad has already
+        # reached the reference's 0.1 (the grid's pads do at x 30), the very same bytes
+        assert st["tree_reach"] >= reach or np.array_equal(twin.view(np.uint8), brt.build_bvh_sah(b.models, reach).view(np.uint8))
+        assert st["tree_reach"] == reach or k in (57, 60)
         want, cnt = oracle.render(brt.Buffers(b.models, b.materials, twin), lvl, cam, win, w, h)
         assert_frames_equal(got, want)
         assert {q: st[q] for q in COUNTER_KEYS} == cnt
@@ -735,7 +771,7 @@ def test_far_camera_callee_tree_is_rebuilt_for_the_camera(plugin, oracle, kind):
             assert (~ref_ok).sum() > 100                                     # the reference's own tree is past its limit here
             assert (differs & ref_ok).sum() <= 32, (k, int((differs & ref_ok).sum()))
             assert (got.view(np.uint32) != truth.view(np.uint32)).any(axis=2).sum() <= 1.05 * (~ref_ok).sum() + 16
-    assert rebuilt[20] == [1] and rebuilt[30] == [1] and rebuilt[60] == [1] and rebuilt[57] == [0]
+    assert rebuilt[20] == [1] and rebuilt[30] == [1] and rebuilt[60] == [1 if kind == brt.SCENE_COVER else 0] and rebuilt[57] == [0]
     assert rebuilt[1] == [0, 1]                  # the upload's tree serves the cover camera; coming back from x 57 rebuilds the tight one
     # the tree of the scene's own extent does lose pixels out there (what round 4 shipped): the case is real
     lvl, cam, win = _far_camera(30, w, h, spp, bounces)
@@ -1437,6 +1473,109 @@ def test_half_sample_jobs_hand_the_pixel_state_over_without_changing_pixels_or_r
         p.debug_profile()
         meta = p.last_order_meta
         assert meta["split_tiles"] > 0 and meta["second_halves_taken"] > 50 * meta["second_halves_left"], meta
+
+
+def test_store_conversions_on_single_values(plugin, oracle):
+    """BRT_DBG_ENCODE: the three store conversions of BRT_FLAG_OUT_* on the device, value by value, against the oracle's restatement:
+    every sRGB threshold and its predecessor, the unorm ties (k + 0.5) / 255 neighbourhoods, f16 ties / overflow / denormals, specials."""
+    t = brt.srgb_thresholds()
+    rng = np.random.default_rng(4)
+    ties = ((np.arange(0, 255) + 0.5) / 255.0).astype(np.float32)
+    x = np.concatenate([t, np.nextafter(t, np.float32(-1)), ties, np.nextafter(ties, np.float32(2)), np.nextafter(ties, np.float32(-1)),
+                        rng.random(200000).astype(np.float32), (np.float32(10.0) ** rng.uniform(-12, 6, 100000)).astype(np.float32) * rng.choice([-1, 1], 100000).astype(np.float32),
+                        np.array([0.0, -0.0, 1.0, np.inf, -np.inf, np.nan, 65504.0, 65519.9, 65520.0, 2.9802322e-8, 2.9802326e-8, 5.96e-8, 6.1e-5, 6.0975e-5], np.float32)])
+    x = x[:len(x) // 4 * 4]
+    out = plugin.debug_eval(9, _inputs([x]))
+    f = x.reshape(-1, 1, 4)
+    assert np.array_equal(out[:, 0].astype(np.int64), oracle.encode_frame(f, "srgb8").reshape(-1).astype(np.int64))
+    assert np.array_equal(out[:, 1].astype(np.int64), oracle.encode_frame(f, "unorm8").reshape(-1).astype(np.int64))
+    got16, want16 = out[:, 2].astype(np.int64), oracle.encode_frame(f, "f16").reshape(-1).astype(np.int64)
+    nan = np.isnan(x)
+    assert np.array_equal(got16[~nan], want16[~nan]) and np.all((got16[nan] & 0x7c00) == 0x7c00) and np.all((got16[nan] & 0x3ff) != 0)
+
+
+@pytest.mark.parametrize("ids", [[0], [0, 0, 0]])
+def test_frame_stored_in_the_colour_targets_own_format(oracle, ids):
+    """SURVEY 8(f3), VERDICT r4 #5: the reference's pass writes into post_process.destination, whose format is
+    TextureFormat::bevy_default() (pipeline.rs:311-315) -- 8-bit sRGB, or Rgba16Float under HDR.  brt_render_device stores the
+    assembled frame in that format (BRT_FLAG_OUT_*), here into an IMPORTED buffer (a dma-buf, as a Vulkan export would hand over),
+    read back through the exporter's mapping: bit for bit the oracle's f32 frame put through the oracle's store conversion.  The
+    f32 frame stays the parity contract; the conversion is exact (brt_srgb_table.h)."""
+    import os as _os
+    import torch
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    w, h = 200, 117
+    rng = np.random.default_rng(5)
+    raster = (rng.random((h, w, 4), dtype=np.float32) * np.float32(1.5) - np.float32(0.2)).astype(np.float32)      # some values outside [0, 1]
+    raster[::7, ::5, 0] = np.nan
+    depth = (rng.random((h, w), dtype=np.float32) * np.float32(0.05)).astype(np.float32)
+    with brt.RaytracePlugin(ids) as p:
+        p.node.write_buffers(b)
+        torch.cuda.set_device(ids[0])
+        d_raster, d_depth = torch.from_numpy(raster).cuda(), torch.from_numpy(depth).cuda()
+        torch.cuda.synchronize()
+        for fmt, name, dt in ((brt.FLAG_OUT_RGBA8_UNORM_SRGB, "srgb8", np.uint8), (brt.FLAG_OUT_RGBA16F, "f16", np.uint16),
+                              (brt.FLAG_OUT_RGBA8_UNORM, "unorm8", np.uint8), (brt.FLAG_OUT_RGBA32F, None, np.float32)):
+            nbytes = w * h * brt.OUT_PIXEL_BYTES[fmt]
+            fd, d_exported = p.debug_export_frame_fd(nbytes)
+            d_imported = p.import_frame_fd(fd, nbytes, brt.EXTMEM_DMABUF_FD)
+            for level in (brt.Raytracing.Pure, brt.Raytracing.FallbackRaster, brt.Raytracing.Skip):
+                lvl, cam, win = brt.cover_camera(w, h, 3, 4, level, seed=0.31)
+                p.node.render_device(lvl, cam, win, w, h, d_imported, d_raster.data_ptr(), d_depth.data_ptr(), flags=fmt)
+                want, _ = oracle.render(b, lvl, cam, win, w, h, raster_rgba=raster, raster_depth=depth)
+                got = p.debug_copy_to_host(d_exported, (h, w, 4), dt)
+                if name is None:
+                    assert_frames_equal(got, want)
+                elif name == "f16":
+                    w16 = oracle.encode_frame(want, name)
+                    nan = np.isnan(want)
+                    assert np.array_equal(got[~nan], w16[~nan]) and np.all((got[nan] & 0x7c00) == 0x7c00)
+                else:
+                    assert np.array_equal(got, oracle.encode_frame(want, name)), (name, level)
+            p.release_frame(d_imported)
+            p.release_frame(d_exported)
+            _os.close(fd)
+        # the format flags belong to the assembled device frame: the host frame and a rank's tile stay f32
+        lvl, cam, win = brt.cover_camera(w, h, 1, 1)
+        with pytest.raises(brt.BrtError):
+            p.node.run(lvl, cam, win, w, h, flags=brt.FLAG_OUT_RGBA16F)
+        # ... and the root side of the one-process-per-GPU form applies it too (brt_deinterleave_device)
+        tiles = torch.zeros((2, brt.tile_rows(h, 2), w, 4), dtype=torch.float32, device="cuda")
+        for part in range(2):
+            p.node.render_part_device(lvl, cam, win, w, h, part, 2, tiles[part].data_ptr())
+        frame8 = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        p.node.deinterleave_device(tiles.data_ptr(), 2, w, h, frame8.data_ptr(), out_format=brt.FLAG_OUT_RGBA8_UNORM_SRGB)
+        want, _ = oracle.render(b, lvl, cam, win, w, h)
+        assert np.array_equal(frame8.cpu().numpy(), oracle.encode_frame(want, "srgb8"))
+
+
+def test_half_sample_jobs_stress_every_tile_split_at_1080p():
+    """The hand-over's ordering (brt_trace.h BRT_SLICE_SYNC: wide agent-scope stores, their acknowledgements, then the flag; the
+    taker's exchange, then wide agent-scope loads) under load: EVERY tile of a 1920x1080 frame handed out as two half-sample jobs,
+    a new seed per frame, each frame against the same frame rendered without a single split on a second context -- bytes and ray
+    count.  (scripts/split_stress.py runs 200 frames of it: profiles/r05/split_stress.txt.)"""
+    w, h, spp = 1920, 1080, 16
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    nb = brt.Buffers(b.models, b.materials, None)
+    n_tiles = (w // 8) * (h // 8)
+    with brt.RaytracePlugin([0]) as split, brt.RaytracePlugin([0]) as plain:
+        split.set_tuning("BRT_SPLIT_FORCE", n_tiles)
+        plain.set_tuning("BRT_SPLIT_TAIL", 0)
+        taken = 0
+        for i in range(14):
+            seed = 0.5 if i < 2 else float(np.float32(0.01 + 0.07 * i))      # (the first two frames of the view build its order)
+            lvl, cam, win = brt.cover_camera(w, h, spp, 8, seed=seed)
+            fa = split.node.run(lvl, cam, win, w, h, buffers=nb)
+            ra = split.node.last_stats["rays"]
+            fb = plain.node.run(lvl, cam, win, w, h, buffers=nb)
+            assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32)) and ra == plain.node.last_stats["rays"], i
+            split.debug_profile()
+            plain.debug_profile()
+            assert plain.last_order_meta["split_tiles"] == 0
+            if i >= 2:
+                assert split.last_order_meta["split_tiles"] > 0.3 * n_tiles, split.last_order_meta
+                taken += split.last_order_meta["second_halves_taken"]
+        assert taken > 12 * 0.2 * w * h
 
 
 def test_order_built_on_host_and_on_gpu_render_the_same_frames(oracle, monkeypatch):
