@@ -251,6 +251,13 @@ def main():
                "step": step, "tile": tile, "last_stats": st, "variants": sorted(set(variants)), "measuring_frames": measuring}
         return res
 
+    # every rank is there and rank r renders on device ordinal r (one process per GPU: a launcher that put two ranks on one card, or
+    # fewer ranks than --gpus, must not produce a line that looks like an N-GPU figure)
+    ranks_seen = dist.get_world_size() if world > 1 else 1
+    ordinals = [int(x) for x in all_list(float(torch.cuda.current_device() if stub is None else rank))]
+    if ranks_seen != args.gpus or ordinals != list(range(args.gpus)):
+        raise SystemExit(f"bench.py --gpus {args.gpus}: {ranks_seen} ranks on device ordinals {ordinals}")
+
     head = run_workload(WORKLOAD, brt.SCENE_COVER, args.steps, args.warmup)
     W, H, spp = head["W"], head["H"], head["spp"]
 
@@ -376,7 +383,7 @@ def main():
                               "`caller_ploc_tree_ms` = the same frame in the caller's PLOC tree",
                        "scene_seed": WORKLOAD["scene_seed"], "random_seed": WORKLOAD["random_seed"], "level": "Pure",
                        "parallelism": f"interleaved 8-row strips over {world} GPU(s), one RCCL gather per frame"},
-            "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
+            "n_ranks_seen": ranks_seen, "device_ordinals": ordinals,
             "rays_per_frame": head["total_rays"] / args.steps, "paths_per_frame": W * H * spp,
             "mpaths_per_s": W * H * spp * args.steps / head["elapsed"] / 1e6,
             "kernel_ms_per_rank": head["kernel_ms_per_rank"], "rays_per_frame_per_rank": head["rays_per_rank"],
@@ -402,7 +409,8 @@ def main():
             blk = {"workload": name, "spheres": int(len(r["buffers"].models)), "steps": r["steps"], "warmup": 2,
                    "value": r["total_rays"] / r["elapsed"] / 1e6, "unit": "Mrays/s", "ms_per_step": r["elapsed"] / r["steps"] * 1e3,
                    "kernel_ms": r["kernel_ms"], "rays_per_frame": r["total_rays"] / r["steps"], "scene_in_lds": c["scene_in_lds"],
-                   "roofline": roofline_block(args, 1, False, r["kernel_ms"], alg_c, tag, counted=c, paths=r["W"] * r["H"] * r["spp"]),
+                   "roofline": roofline_block(args, 1, False, r["kernel_ms"], alg_c, tag, counted=c, paths=r["W"] * r["H"] * r["spp"],
+                                              memory_side=(key == "config5")),
                    "sampled_rows_bit_exact": sampled_rows_exact(r)}
             out[key] = blk
         if not args.no_cpu_baseline:
@@ -424,6 +432,14 @@ PMC_PASSES = [
     "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES",
     "FETCH_SIZE",
     "WRITE_SIZE",
+]
+# the memory side of a launch (config 5: BASELINE.json's "BVH-bandwidth bound, rocprof HBM GB/s focus"): where the wave
+# cycles go (issuing / issue-stalled / parked in s_waitcnt), the vector-memory path (L1 accesses, L1 -> L2 requests, texture
+# addresser busy and stalled by the cache) and the L2's hit rate -- one rocprofv3 pass each (8 SQ slots, 4 TCC slots per pass)
+PMC_PASSES_MEMORY = [
+    "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE",
+    "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_BUSY_avr",
+    "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum",
 ]
 
 
@@ -503,7 +519,7 @@ def sampled_rows_exact(r, n_rows=4):
     return ok
 
 
-def roofline_block(args, world, is_stub, kernel_ms, alg, workload, counted=None, paths=None):
+def roofline_block(args, world, is_stub, kernel_ms, alg, workload, counted=None, paths=None, memory_side=False):
     """The roofline object of one workload.  kernel_ms: the slowest rank's mean kernel time.  Counters: of the WHOLE frame
     on ONE GPU (a live rocprofv3 --pmc pass made now by rank 0 in a one-GPU child process, or the committed summary taken on
     the same device code); for N > 1 the frame's lane-operations are set against N GPUs' peak."""
@@ -513,8 +529,9 @@ def roofline_block(args, world, is_stub, kernel_ms, alg, workload, counted=None,
     head = workload == PMC_WORKLOAD_TAG
     if not is_stub and not args.no_pmc and workload != PMC_WORKLOAD4_TAG:
         # (config 4 renders for seconds per frame and minutes per counter pass: its block takes the committed, hash-checked summary
-        #  directly instead of a live pass that would hit its time budget; the config 3 / 5 blocks are secondary: their SQ set only)
-        pmc, why = live_pmc(workload=workload, passes=None if head else PMC_PASSES[:1], timeout_s=90.0 if head else 60.0)
+        #  directly instead of a live pass that would hit its time budget; config 5 also takes the memory-side sets)
+        pmc, why = live_pmc(workload=workload, passes=PMC_PASSES + (PMC_PASSES_MEMORY if memory_side else []),
+                            timeout_s=90.0 if head else (150.0 if memory_side else 75.0))
         if pmc and "SQ_INSTS_VALU" in pmc:
             source = "live: rocprofv3 --pmc passes made by this run after the timed region (scripts/pmc_frame.py, one GPU, last dispatch)"
         else:
@@ -542,7 +559,7 @@ def roofline_block(args, world, is_stub, kernel_ms, alg, workload, counted=None,
                     "the slowest rank's kernel time; peak = n_gpus x 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz (the guide's 2-cycle wave64 issue; "
                     "tests/tools/issue_bench.hip measures 2.2-2.4 cycles for the f32 add/mul/fma group in a pure stream and 4 for min/max, "
                     "compares, v_cndmask, conversions and integer multiplies, 8 for v_rcp/v_sqrt -- DESIGN.md section 5). The scene is LDS "
-                    "resident and ray state lives in registers, so HBM only sees the scene load per workgroup, one 16-B store per pixel and the 32-B pixel states that change hands between the two half-sample jobs of a tile (device-scope atomics, DESIGN.md section 6): "
+                    "resident and ray state lives in registers, so HBM only sees the scene load per workgroup, one 16-B store per pixel and the 32-B pixel states that change hands between the two half-sample jobs of a tile (two wide agent-scope stores / loads per pixel, DESIGN.md section 6): "
                     "`traffic` (measured HBM bytes of the frame) / kernel time is `hbm_frac_measured` of the HBM peak; the SURVEY 8(d) "
                     "algorithmic bytes are informational (they are served from LDS/registers)",
             "counter_source": source, "counter_note": why}
@@ -575,6 +592,22 @@ def roofline_block(args, world, is_stub, kernel_ms, alg, workload, counted=None,
             # rocprofv3 reports KB; on gfx950 FETCH_SIZE counts 64 B per 128-B request: doubled (MI355X_MICROARCH.md, HBM)
             roof["traffic"] = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
             roof["hbm_frac_measured"] = roof["traffic"] / secs / 1e9 / (HBM_PEAK_GBS * world) if secs > 0 else None
+        if memory_side and "SQ_WAIT_ANY" in pmc:
+            wc = pmc.get("SQ_WAVE_CYCLES") or 0.0
+            mem = {"wave_cycles_frac": {"issuing": pmc.get("SQ_ACTIVE_INST_ANY", 0.0) / wc if wc else None,
+                                        "issue_stalled": pmc.get("SQ_WAIT_INST_ANY", 0.0) / wc if wc else None,
+                                        "parked_in_waitcnt": pmc["SQ_WAIT_ANY"] / wc if wc else None},
+                   "vmem_read_instructions": pmc.get("SQ_INSTS_VMEM_RD"), "lds_bank_conflict_frac": (pmc.get("SQ_LDS_BANK_CONFLICT", 0.0) / pmc["SQ_LDS_IDX_ACTIVE"]) if pmc.get("SQ_LDS_IDX_ACTIVE") else None}
+            if "TCP_TOTAL_CACHE_ACCESSES_sum" in pmc:
+                mem.update({"l1_accesses": pmc["TCP_TOTAL_CACHE_ACCESSES_sum"], "l1_to_l2_read_requests": pmc.get("TCP_TCC_READ_REQ_sum"),
+                            "l1_hit_frac": 1.0 - pmc.get("TCP_TCC_READ_REQ_sum", 0.0) / pmc["TCP_TOTAL_CACHE_ACCESSES_sum"] if pmc["TCP_TOTAL_CACHE_ACCESSES_sum"] else None,
+                            "l1_pending_stall_cycles": pmc.get("TCP_PENDING_STALL_CYCLES_sum"),
+                            "ta_busy_avr_cycles": pmc.get("TA_BUSY_avr"), "ta_addr_stalled_by_tc_cycles": pmc.get("TA_ADDR_STALLED_BY_TC_CYCLES_sum"),
+                            "l2_read_GBs_at_64B_per_request": pmc.get("TCP_TCC_READ_REQ_sum", 0.0) * 64.0 / secs / 1e9 if secs > 0 else None})
+            if "TCC_HIT_sum" in pmc and (pmc["TCC_HIT_sum"] + pmc.get("TCC_MISS_sum", 0.0)) > 0:
+                mem["l2_hit_frac"] = pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc.get("TCC_MISS_sum", 0.0))
+                mem["l2_requests"] = pmc.get("TCC_REQ_sum")
+            roof["memory_side"] = mem
     return roof
 
 

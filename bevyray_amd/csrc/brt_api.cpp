@@ -345,7 +345,7 @@ int32_t attach_tile_order(brt_ctx* ctx, DeviceCtx& dc, FrameParams& fp, hipStrea
         // half-sample jobs at the end of the order: where they are (a GPU-built order says so in d_order_meta) and where the pixel
         // states wait between a tile's two jobs
         if (split_tail_of(ctx, dc, n_tiles) != 0u) {
-            const size_t bytes = (size_t)fp.local_strips * BRT_STRIP_ROWS * fp.width * 32u;
+            const size_t bytes = (size_t)fp.queue_size * 36u;       // three planes of 16 + 16 + 4 bytes per queue slot (brt_trace.h slice_slot)
             const bool fresh = bytes > dc.slice_state_cap;
             int32_t rc = ensure(ctx, &dc.d_slice_state, &dc.slice_state_cap, bytes);
             if (rc != BRT_OK) return rc;

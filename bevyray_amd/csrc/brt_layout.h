@@ -205,8 +205,9 @@ struct FrameParams {
                                      // [2], [3] = split_nonsky, split_tiles below
     // Half-sample jobs (brt_host.cpp build_tile_order): order positions [split_nonsky - split_tiles, split_nonsky) are FIRST halves (the
     // lane ends after sample_count / 2 samples and leaves its pixel state in slice_state), the next split_tiles positions the SECOND
-    // halves of the same tiles; the tile queue then has split_tiles * 64 more slots than queue_size.  slice_state: 8 words per pixel
-    // of the tile buffer {rng, sum.x, sum.y, sum.z, depth sum, rays so far, -, stamp}; a record is valid when its stamp is slice_serial.
+    // halves of the same tiles; the tile queue then has split_tiles * 64 more slots than queue_size.  slice_state: 9 words per queue slot
+    // (tile * 64 + position in the tile) in three planes -- {rng, sum.x, sum.y, sum.z} | {depth sum, rays so far, -, -} | flag -- a
+    // record is valid when its flag carries slice_serial (brt_trace.h slice_slot).
     uint32_t split_nonsky, split_tiles;
     uint32_t* slice_state;
     uint32_t slice_serial;

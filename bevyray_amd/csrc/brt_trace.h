@@ -23,7 +23,8 @@ namespace brt {
 struct PixelCoord {
     uint32_t px, py;        // frame coordinates
     uint32_t local_row;     // row in the dense tile buffer
-    uint32_t tile;          // tile id (strip * tiles_x + tx)
+    uint32_t tile;          // tile id (strip * tiles_x + tx), < 2^24
+    uint32_t t;             // position inside the tile (row-major 8x8), 0 .. 63
     bool inside;
 };
 BRT_DEV uint32_t slot_tile(const FrameParams& fp, uint32_t slot_tile_index) {
@@ -41,6 +42,7 @@ BRT_DEV PixelCoord slot_to_pixel(const FrameParams& fp, uint32_t q, uint32_t til
     c.local_row = strip * 8u + r;
     c.py = (strip * fp.n_parts + fp.part) * 8u + r;
     c.tile = tile;
+    c.t = t;
     c.inside = (c.px < fp.width) && (c.py < fp.height);
     return c;
 }
@@ -65,7 +67,8 @@ struct PixelState {
     uint32_t sample;
     uint32_t out_index;     // pixel index in the tile buffer
     uint32_t frame_index;   // pixel index in the frame (raster inputs)
-    uint32_t tile;          // for the per-tile cost measurement; bits 30-31: kSliceFinal / kSliceFirst (what happens at sample_end) / kSliceDone
+    uint32_t tile;          // bits 0-23: tile id (per-tile cost measurement, slice slot); 24-29: the pixel's position in the tile (slice slot);
+                            // 30-31: kSliceFinal / kSliceFirst (what happens at sample_end) / kSliceDone
     uint32_t rays_begin;    // lane's ray counter when the pixel started
     uint32_t sample_end;    // the lane leaves the pixel after this many samples (sample_count, or half of it: a first-half job)
 };
@@ -84,7 +87,8 @@ struct PixelState {
 // A first-half lane does not go to memory at once: the exchanges are a round trip (microseconds) and the lanes of a tile end in ~30
 // different rounds -- one by one that cost the headline frame 4 %.  The lane just goes idle (kSliceDone: its registers keep the state)
 // and the WAVE settles all of them in one go the next time it runs its management code (slice_settle, top of the kernel's loop).
-constexpr uint32_t kSliceFinal = 0u, kSliceFirst = 1u, kSliceDone = 3u, kSliceShift = 30u, kTileMask = 0x3fffffffu;
+constexpr uint32_t kSliceFinal = 0u, kSliceFirst = 1u, kSliceDone = 3u, kSliceShift = 30u, kTileMask = 0x00ffffffu, kTileLaneShift = 24u,
+                   kSliceFlagsMask = 0xc0000000u;
 constexpr uint32_t kSliceReady = 1u, kSliceGaveUp = 2u;      // flag word = serial << 2 | one of these
 #ifndef BRT_SLICE_EIGHTHS
 #define BRT_SLICE_EIGHTHS 4
@@ -98,11 +102,14 @@ BRT_DEV uint32_t slice_point(const FrameParams& fp) { return (uint32_t)(((uint64
 //   1 (default)  every access to the record is an agent-scope access of its own: the state as two wide stores with sc1 (written
 //                through to the memory side: what the memory model lowers an agent-scope atomic store to, 128 and 64 bits wide --
 //                tearing does not matter, nobody reads before the flag), `s_waitcnt vmcnt(0)` (their acknowledgements), THEN the
-//                flag by an agent-scope exchange; the taker's exchange first, and behind its return two wide sc1 loads (read at the
+//                flag by an agent-scope exchange; the taker's exchange first, and behind its return two dwordx4 sc1 loads (read at the
 //                memory side, never from a stale line of this L2).  This is the release / acquire pair of (2) with the cache-wide
 //                operations left out that this record does not need: `buffer_wbl2 sc1` writes back lines that were NOT written
-//                through (ours were), `buffer_inv sc1` drops lines that plain loads might hit (ours bypass).  2 stores + 1 atomic |
-//                1 atomic + 2 loads per pixel; HBM traffic of the headline launch 342 -> ~100 MB.
+//                through (ours were), `buffer_inv sc1` drops lines that plain loads might hit (ours bypass) -- the form
+//                MI355X_MICROARCH.md lists under "Valid forms" (every store of the handed-off bytes sc1 and drained before the
+//                flag, every load of them a global sc1 load to registers), which it marks as measured, not architectural; so is
+//                this one (stress: scripts/split_stress.py).  2 stores + 1 atomic | 1 atomic + 2 loads per pixel; HBM traffic of
+//                the headline launch 342 -> ~100 MB.
 //   2            the memory model's recipe verbatim: plain wide stores, the flag exchange with RELEASE semantics (hipcc emits
 //                buffer_wbl2 sc1 + s_waitcnt before it), the taker's with ACQUIRE (buffer_inv sc1 behind it), plain wide loads.
 //                Correct by the book and measurably slower, because the invalidate drops this XCD's whole L2 every time a wave
@@ -120,54 +127,71 @@ typedef uint32_t slice_u2 __attribute__((ext_vector_type(2)));
 BRT_DEV uint32_t slice_xchg(uint32_t* p, uint32_t v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 BRT_DEV uint32_t slice_read(uint32_t* p) { return __hip_atomic_fetch_add(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Where a pixel's record lives: slot = tile * 64 + position in the tile, in three planes -- A {rng, sum.xyz} 16 B, B {depth sum, rays
+// so far, -, -} 16 B, F the flag word -- so that the 64 lanes of a tile, which settle together (slice_settle: the wave's management
+// code), write and read WHOLE 128-byte lines with one instruction each (a wave's dwordx4 = 1 KB contiguous), and the flags sit in
+// lines of their own.  (Round 4 / the first form of round 5 kept 32-byte records in pixel order: half-filled lines, 240 MB of HBM
+// traffic per headline launch.)  Plane B is only needed by frames that average depth (levels 1, 2) or measure tile costs: the
+// steady-state frame of a Pure-level view moves 16 + 16 bytes per split pixel.
+struct SliceSlot { uint32_t* a; uint32_t* b; uint32_t* f; };
+BRT_DEV SliceSlot slice_slot(const FrameParams& fp, const PixelState& ps) {
+    const size_t slot = (size_t)(ps.tile & kTileMask) * 64u + ((ps.tile >> kTileLaneShift) & 63u), n = fp.queue_size;   // n = tiles * 64
+    SliceSlot r;
+    // (flags first: a frame of another size in the same buffer then finds, where its flags are, only flags of earlier launches --
+    //  never a state word that might look like one; the buffer only grows with a fresh, zeroed allocation: attach_tile_order)
+    r.f = fp.slice_state + slot;
+    r.a = fp.slice_state + n + 4u * slot;
+    r.b = fp.slice_state + 5u * n + 4u * slot;
+    return r;
+}
+
 // first half: true when the second-half lane has already given up on this pixel (the caller then carries on with it)
-BRT_DEV bool slice_store(const FrameParams& fp, const PixelState& ps, uint32_t rays) {
-    uint32_t* rec = fp.slice_state + 8u * (size_t)ps.out_index;
+BRT_DEV bool slice_store(const FrameParams& fp, const PixelState& ps, uint32_t rays, bool with_b) {
+    const SliceSlot rec = slice_slot(fp, ps);
     const uint32_t ready = (fp.slice_serial << 2) | kSliceReady, gave_up = (fp.slice_serial << 2) | kSliceGaveUp;
-#if BRT_SLICE_SYNC == 2
-    *reinterpret_cast<slice_u4*>(rec) = slice_u4{ps.rng, __float_as_uint(ps.sum.x), __float_as_uint(ps.sum.y), __float_as_uint(ps.sum.z)};
-    *reinterpret_cast<slice_u2*>(rec + 4) = slice_u2{__float_as_uint(ps.dsum), rays};
-    return __hip_atomic_exchange(rec + 7, ready, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == gave_up;
-#elif BRT_SLICE_SYNC == 1
     const slice_u4 a = {ps.rng, __float_as_uint(ps.sum.x), __float_as_uint(ps.sum.y), __float_as_uint(ps.sum.z)};
-    const slice_u2 b = {__float_as_uint(ps.dsum), rays};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx2 %0, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
-                 :: "v"(rec), "v"(a), "v"(b) : "memory");
-    return slice_xchg(rec + 7, ready) == gave_up;
+    const slice_u4 b = {__float_as_uint(ps.dsum), rays, 0u, 0u};
+#if BRT_SLICE_SYNC == 2
+    *reinterpret_cast<slice_u4*>(rec.a) = a;
+    if (with_b) *reinterpret_cast<slice_u4*>(rec.b) = b;
+    return __hip_atomic_exchange(rec.f, ready, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == gave_up;
+#elif BRT_SLICE_SYNC == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(rec.a), "v"(a) : "memory");
+    if (with_b) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(rec.b), "v"(b) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the stores are acknowledged (written through) before the flag goes out
+    return slice_xchg(rec.f, ready) == gave_up;
 #else
-    uint32_t seen = slice_xchg(rec + 0, ps.rng);
-    seen |= slice_xchg(rec + 1, __float_as_uint(ps.sum.x));
-    seen |= slice_xchg(rec + 2, __float_as_uint(ps.sum.y));
-    seen |= slice_xchg(rec + 3, __float_as_uint(ps.sum.z));
-    seen |= slice_xchg(rec + 4, __float_as_uint(ps.dsum));
-    seen |= slice_xchg(rec + 5, rays);
+    uint32_t seen = slice_xchg(rec.a + 0, a.x);
+    seen |= slice_xchg(rec.a + 1, a.y);
+    seen |= slice_xchg(rec.a + 2, a.z);
+    seen |= slice_xchg(rec.a + 3, a.w);
+    seen |= slice_xchg(rec.b + 0, b.x);
+    seen |= slice_xchg(rec.b + 1, b.y);
     // the flag goes out when the six exchanges have RETURNED (performed): its value is made to depend on what they returned
     uint32_t flag = ready;
     asm volatile("v_and_b32 %1, 0, %1\n\tv_or_b32 %0, %0, %1" : "+v"(flag), "+v"(seen));
-    return slice_xchg(rec + 7, flag) == gave_up;
+    return slice_xchg(rec.f, flag) == gave_up;
 #endif
 }
 
 // second half: true when the state was there (ps continues at sample_count / 2; *rays_before = rays of the first half)
-BRT_DEV bool slice_load(const FrameParams& fp, PixelState& ps, uint32_t* rays_before) {
-    uint32_t* rec = fp.slice_state + 8u * (size_t)ps.out_index;
+BRT_DEV bool slice_load(const FrameParams& fp, PixelState& ps, uint32_t* rays_before, bool with_b) {
+    const SliceSlot rec = slice_slot(fp, ps);
     const uint32_t ready = (fp.slice_serial << 2) | kSliceReady, gave_up = (fp.slice_serial << 2) | kSliceGaveUp;
+    slice_u4 a, b = {0u, 0u, 0u, 0u};
 #if BRT_SLICE_SYNC == 2
-    if (__hip_atomic_exchange(rec + 7, gave_up, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ready) return false;
-    const slice_u4 a = *reinterpret_cast<const slice_u4*>(rec);
-    const slice_u2 b = *reinterpret_cast<const slice_u2*>(rec + 4);
+    if (__hip_atomic_exchange(rec.f, gave_up, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ready) return false;
+    a = *reinterpret_cast<const slice_u4*>(rec.a);
+    if (with_b) b = *reinterpret_cast<const slice_u4*>(rec.b);
 #elif BRT_SLICE_SYNC == 1
-    if (slice_xchg(rec + 7, gave_up) != ready) return false;
-    slice_u4 a;
-    slice_u2 b;
-    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(a), "=&v"(b) : "v"(rec) : "memory");
+    if (slice_xchg(rec.f, gave_up) != ready) return false;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(a) : "v"(rec.a) : "memory");
+    if (with_b) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+&v"(b) : "v"(rec.b) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b) :: "memory");      // (the loads' results are not the compiler's to wait for: it did not issue them)
 #else
-    if (slice_xchg(rec + 7, gave_up) != ready) return false;
-    slice_u4 a;
-    slice_u2 b;
-    a.x = slice_read(rec + 0); a.y = slice_read(rec + 1); a.z = slice_read(rec + 2); a.w = slice_read(rec + 3);
-    b.x = slice_read(rec + 4); b.y = slice_read(rec + 5);
+    if (slice_xchg(rec.f, gave_up) != ready) return false;
+    a.x = slice_read(rec.a + 0); a.y = slice_read(rec.a + 1); a.z = slice_read(rec.a + 2); a.w = slice_read(rec.a + 3);
+    b.x = slice_read(rec.b + 0); b.y = slice_read(rec.b + 1);
 #endif
     ps.rng = a.x;
     ps.sum = mk3(__uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
@@ -188,7 +212,7 @@ BRT_DEV void pixel_begin(const FrameParams& fp, const PixelCoord& c, PixelState&
     ps.sample = 0;
     ps.out_index = c.local_row * fp.width + c.px;
     ps.frame_index = fp.raster_dense ? ps.out_index : c.py * fp.width + c.px;
-    ps.tile = c.tile;
+    ps.tile = c.tile | (c.t << kTileLaneShift);
 }
 
 // PURE_LEVEL: the launch is known to be level 3 (Raytracing::Pure): no depth average, no raster inputs
@@ -548,6 +572,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     const uint32_t split_mid = (fp.order_meta ? fp.order_meta[2] : fp.split_nonsky) * 64u;
     const uint32_t split_lo = split_mid - split_tiles * 64u, split_hi = split_mid + split_tiles * 64u;
     const bool slices = kSlices && fp.sample_count >= 16u;
+    const bool slice_b = LEAN == 0 || fp.tile_cost != nullptr;      // the hand-over carries {depth sum, rays so far} too (slice_store)
     const uint32_t queue_size = fp.queue_size + split_tiles * 64u;
 
     PixelState ps;
@@ -586,8 +611,8 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         const bool done = kSlices && !active && (ps.tile >> kSliceShift) == kSliceDone;
         if (__ballot(done) == 0ull) return;
         if (done) {
-            ps.tile &= kTileMask;
-            if (slice_store(fp, ps, n_rays - ps.rays_begin)) {
+            ps.tile &= ~kSliceFlagsMask;
+            if (slice_store(fp, ps, n_rays - ps.rays_begin, slice_b)) {
                 ps.sample_end = fp.sample_count;        // (sample, rng, sums: as the first half left them; need_cam is set, bounce is 0)
                 active = true;
             }
@@ -607,7 +632,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                 ps.tile |= kSliceFirst << kSliceShift;
             } else if (slices && second_half) {
                 uint32_t rays_before = 0u;
-                taken = slice_load(fp, ps, &rays_before);
+                taken = slice_load(fp, ps, &rays_before, slice_b);
                 ps.rays_begin = n_rays - rays_before;
                 // (diagnostic, brt_debug_profile [62], [63]: second halves that took the pixel over / that left it to the first-half lane)
                 const uint64_t tm = __ballot(taken), lm = __ballot(!taken);

@@ -1484,12 +1484,12 @@ def test_store_conversions_on_single_values(plugin, oracle):
     x = np.concatenate([t, np.nextafter(t, np.float32(-1)), ties, np.nextafter(ties, np.float32(2)), np.nextafter(ties, np.float32(-1)),
                         rng.random(200000).astype(np.float32), (np.float32(10.0) ** rng.uniform(-12, 6, 100000)).astype(np.float32) * rng.choice([-1, 1], 100000).astype(np.float32),
                         np.array([0.0, -0.0, 1.0, np.inf, -np.inf, np.nan, 65504.0, 65519.9, 65520.0, 2.9802322e-8, 2.9802326e-8, 5.96e-8, 6.1e-5, 6.0975e-5], np.float32)])
-    x = x[:len(x) // 4 * 4]
     out = plugin.debug_eval(9, _inputs([x]))
-    f = x.reshape(-1, 1, 4)
-    assert np.array_equal(out[:, 0].astype(np.int64), oracle.encode_frame(f, "srgb8").reshape(-1).astype(np.int64))
-    assert np.array_equal(out[:, 1].astype(np.int64), oracle.encode_frame(f, "unorm8").reshape(-1).astype(np.int64))
-    got16, want16 = out[:, 2].astype(np.int64), oracle.encode_frame(f, "f16").reshape(-1).astype(np.int64)
+    f = np.stack([x, x, x, x], axis=-1).reshape(-1, 1, 4)          # (the value in every channel; channel 0 is a colour channel)
+    assert np.array_equal(out[:, 0].astype(np.int64), oracle.encode_frame(f, "srgb8")[:, 0, 0].astype(np.int64))
+    assert np.array_equal(out[:, 1].astype(np.int64), oracle.encode_frame(f, "unorm8")[:, 0, 0].astype(np.int64))
+    assert np.array_equal(oracle.encode_frame(f, "srgb8")[:, 0, 3], oracle.encode_frame(f, "unorm8")[:, 0, 3])      # alpha is linear in both
+    got16, want16 = out[:, 2].astype(np.int64), oracle.encode_frame(f, "f16")[:, 0, 0].astype(np.int64)
     nan = np.isnan(x)
     assert np.array_equal(got16[~nan], want16[~nan]) and np.all((got16[nan] & 0x7c00) == 0x7c00) and np.all((got16[nan] & 0x3ff) != 0)
 
