@@ -232,6 +232,11 @@ static inline void raycast_against_range(const Scene* s, Ray ray, uint32_t start
 
 #define STACKSIZE 32  /* raytrace.wgsl:310 */
 
+/* Diagnostic (tests/tools/visit_hist.py): interior visits per BVH node of the renders that follow, summed into a caller's array
+ * of n_nodes words -- which records of the tree a view actually walks.  NULL switches it off.  Process-wide. */
+static uint64_t* g_visit_counts = NULL;
+void oracle_set_visit_counts(uint64_t* per_node) { g_visit_counts = per_node; }
+
 /* raytrace.wgsl:313-346 */
 static HitInfo raycast(const Scene* s, Ray ray, Counters* cnt) {
     HitInfo closest;
@@ -256,6 +261,7 @@ static HitInfo raycast(const Scene* s, Ray ray, Counters* cnt) {
             raycast_against_range(s, ray, bvh_node->index, bvh_node->model_count, &closest, cnt);
         } else {
             cnt->interior++;
+            if (g_visit_counts) __atomic_fetch_add(&g_visit_counts[next], 1, __ATOMIC_RELAXED);
             const BVHNode* node_1 = &s->bvh[bvh_node->index];
             float dst_1 = ray_bounding_dst(ray, V(node_1->minx, node_1->miny, node_1->minz),
                                            V(node_1->maxx, node_1->maxy, node_1->maxz));

@@ -42,6 +42,9 @@ float oracle_hit_sphere(const float* o3, const float* d3, const float* center3, 
 int oracle_raycast(const void* models, uint32_t n_models, const void* bvh_nodes, uint32_t n_nodes,
                    const float* o3, const float* d3, float* out7, uint32_t* out_material, int* out_front);
 
+/* Diagnostic: interior visits per BVH node of the renders that follow go into per_node[n_nodes] (NULL: off). */
+void oracle_set_visit_counts(uint64_t* per_node);
+
 /* The colour target's store conversion of an RGBA f32 frame (checker side; bevyray_oracle.c): format 1 = RGBA8 sRGB
  * (4 bytes per pixel), 2 = RGBA16F (8 bytes), 3 = RGBA8 unorm (4 bytes).  Returns 0 on success. */
 int oracle_encode_frame(const float* rgba, uint64_t n_pixels, int format, void* out);
