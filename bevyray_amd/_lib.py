@@ -30,6 +30,7 @@ class BrtStats(C.Structure):
         ("threads_per_workgroup", C.c_uint32), ("prepass_ms", C.c_double),
         ("kernel_variant", C.c_uint32), ("measured_tile_costs", C.c_uint32),
         ("tree_rebuilt", C.c_uint32), ("tree_reach", C.c_float), ("forwarded_bytes", C.c_uint64),
+        ("hot_records", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
     def as_dict(self):

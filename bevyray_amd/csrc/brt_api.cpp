@@ -126,6 +126,7 @@ struct LaunchPlan {
 // The knobs BRT_FORCE_GLOBAL_SCENE / BRT_FORCE_LDS_TOP=<records> / BRT_BLOCK_THREADS / BRT_WG_PER_CU override (tests, tuning).
 LaunchPlan plan_launch(const Knobs& kn, const DeviceCtx& dc, const FrameParams& fp) {
     LaunchPlan lp{};
+    const uint32_t hist = fp.record_hits ? dc.view.n_pairs : 0u;      // a pre-pass that counts record visits keeps a histogram in LDS (SCENE_LDS_TOP only)
     const bool force_global = kn[K_FORCE_GLOBAL_SCENE] != 0;
     const uint32_t force_top = kn[K_FORCE_LDS_TOP];
     const uint32_t block_env = kn[K_BLOCK_THREADS];
@@ -176,7 +177,7 @@ LaunchPlan plan_launch(const Knobs& kn, const DeviceCtx& dc, const FrameParams& 
         const uint32_t per_cu = wg_env ? wg_env : 1u;
         const size_t share = dc.max_lds / per_cu;
         const uint32_t pool = pool_of(block) < 192u / per_cu ? pool_of(block) : 192u / per_cu;   // half the pool: the tile is worth more
-        const size_t fixed = trace_lds_bytes(v, SCENE_LDS_TOP, block, pool);
+        const size_t fixed = trace_lds_bytes(v, SCENE_LDS_TOP, block, pool, hist);
         if (fixed + 64 * PAIR_BYTES <= share && per_cu * (block / 64u) <= max_waves_cu) {
             uint32_t k = (uint32_t)((share - fixed) / PAIR_BYTES);
             if (k > v.n_pairs) k = v.n_pairs;
@@ -187,7 +188,7 @@ LaunchPlan plan_launch(const Knobs& kn, const DeviceCtx& dc, const FrameParams& 
             lp.block = block;
             lp.wg_per_cu = per_cu;
             lp.pool_cap = pool;
-            lp.lds_bytes = trace_lds_bytes(v, SCENE_LDS_TOP, block, pool);
+            lp.lds_bytes = trace_lds_bytes(v, SCENE_LDS_TOP, block, pool, hist);
         }
     }
     if (lp.scene_mode == SCENE_GLOBAL) {
@@ -504,6 +505,58 @@ int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const fl
     return BRT_OK;
 }
 
+// ---- pair records in the order of their use ------------------------------------------------------------------------------------
+// A scene whose tree does not fit the LDS is walked from a tile of the first K records in LDS and the rest from L2 (SCENE_LDS_TOP).
+// validate_and_encode numbers the records breadth first, so the tile is the top ~9.8 levels of the tree, everywhere in the scene; a
+// view, though, walks a small part of the tree over and over: of the 10 004-sphere frame's interior visits the breadth-first tile
+// of 879 records serves 78 %, the 879 records this view visits most would serve 98 % (3.7 -> 0.3 global steps per ray;
+// profiles/r05/visit_hist_config5.txt), and the global steps are what the walk waits on (40 % of the wave cycles parked, the texture
+// addresser 71 % busy: profiles/r05/config5_memory_side_before.json).  So the pre-pass of a first frame counts the visits per record
+// (FrameParams::record_hits), and here the records are re-numbered by them, most visited first (ties: breadth-first order), the child
+// descriptors and the root re-written, the records re-sent -- 1.1 MB and a host sort of 10 003 counts per pre-pass and device.
+// Only the NUMBERING of the records changes: the walk visits the same nodes in the same order, pixels and all five counters stay.
+int32_t apply_hot_order(brt_ctx* ctx, DeviceCtx& dc, hipStream_t stream) {
+    const uint32_t n = dc.view.n_pairs;
+    const EncodedScene& e = ctx->enc;
+    if (n == 0u || e.pairs.size() != (size_t)n * PAIR_WORDS) return BRT_OK;
+    // the records as they are on the device now: breadth first after an upload, else the order of this device's last pre-pass (the
+    // counts are indexed by THAT numbering)
+    if (dc.hot_tree != ctx->tree_epoch) dc.h_pairs_cur = e.pairs;
+    const std::vector<float>& cur = dc.h_pairs_cur;
+    const uint32_t cur_root = dc.hot_tree != ctx->tree_epoch ? e.root_desc : dc.view.root_desc;
+    dc.h_hits.resize(n);
+    HIP_TRY(ctx, hipMemcpyAsync(dc.h_hits.data(), dc.d_record_hits, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    std::vector<uint32_t>& rank = dc.h_rank;        // rank[old index] = new index
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return dc.h_hits[a] > dc.h_hits[b]; });
+    rank.resize(n);
+    uint32_t visited = 0;
+    for (uint32_t i = 0; i < n; i++) { rank[order[i]] = i; visited += dc.h_hits[order[i]] != 0u ? 1u : 0u; }
+    auto remap = [&](uint32_t d) { return ((int32_t)d >= 0 && d < n) ? rank[d] : d; };      // interior descriptors (16-bit form: the record's index)
+    dc.h_pairs_hot.resize(cur.size());
+    constexpr uint32_t kDescWord = PAIR_DESC / 4u;
+    for (uint32_t i = 0; i < n; i++) {
+        const float* src = cur.data() + (size_t)order[i] * PAIR_WORDS;
+        float* dst = dc.h_pairs_hot.data() + (size_t)i * PAIR_WORDS;
+        std::memcpy(dst, src, PAIR_BYTES);
+        for (uint32_t k = 0; k < 2u; k++) {
+            uint32_t d;
+            std::memcpy(&d, src + kDescWord + k, 4);
+            d = remap(d);
+            std::memcpy(dst + kDescWord + k, &d, 4);
+        }
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(const_cast<float*>(dc.view.pairs), dc.h_pairs_hot.data(), dc.h_pairs_hot.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));       // (the vectors are reused by the next call)
+    dc.h_pairs_cur.swap(dc.h_pairs_hot);
+    dc.view.root_desc = remap(cur_root);
+    dc.hot_tree = ctx->tree_epoch;
+    dc.hot_records = visited;
+    return BRT_OK;
+}
+
 // The first frame of a view has no measured dispatch order (raster order: 12.9 instead of 9.6 ms on the headline
 // frame).  A pre-pass of the same view at a few samples per pixel measures the tile costs first -- pixels are sequential
 // chains of samples, so k samples predict the chain lengths of the full frame -- and the frame itself then runs in that
@@ -540,12 +593,28 @@ int32_t prepass_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const 
     if (rc != BRT_OK) return rc;
     HIP_TRY(ctx, hipMemsetAsync(dc.d_tile_cost, 0, (size_t)n_tiles * 8, stream));
     pp.tile_cost = dc.d_tile_cost;
+    // a scene that is walked from the LDS tile + global memory: the pre-pass also counts the interior visits per pair record, and the
+    // records are then re-numbered by them (apply_hot_order): every pre-pass does (first frame of a view, camera jump)
+    bool count_hits = false;
+    if (ctx->knobs[K_HOT_RECORDS] != 0u && dc.view.desc16 && dc.view.simple_tree && dc.view.n_pairs > 64u &&
+        plan_launch(ctx->knobs, dc, pp).scene_mode == SCENE_LDS_TOP) {
+        rc = ensure(ctx, &dc.d_record_hits, &dc.record_hits_cap, (size_t)dc.view.n_pairs * 4);
+        if (rc != BRT_OK) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(dc.d_record_hits, 0, (size_t)dc.view.n_pairs * 4, stream));
+        pp.record_hits = dc.d_record_hits;
+        count_hits = plan_launch(ctx->knobs, dc, pp).scene_mode == SCENE_LDS_TOP;      // (the histogram must leave room for a tile)
+        if (!count_hits) pp.record_hits = nullptr;
+    }
     HIP_TRY(ctx, hipEventRecord(dc.ev_p0, stream));
     rc = launch_part(ctx, dc, pp, d_raster_rgba, d_raster_depth, d_out_tile, stream, flags & ~(uint32_t)BRT_FLAG_COUNTERS, false, nullptr);
     if (rc != BRT_OK) return rc;
     HIP_TRY(ctx, hipEventRecord(dc.ev_p1, stream));
     rc = update_tile_order(ctx, dc, pp, stream);      // on the GPU, behind the pre-pass, no host round trip (default settings)
     if (rc != BRT_OK) return rc;
+    if (count_hits) {
+        rc = apply_hot_order(ctx, dc, stream);
+        if (rc != BRT_OK) return rc;
+    }
     dc.remeasure_in = 1u;                             // the frame that follows measures again, at full sample count
     *ran = true;
     return BRT_OK;
@@ -601,6 +670,7 @@ void free_device(DeviceCtx& dc) {
     if (dc.d_order_meta) (void)hipFree(dc.d_order_meta);
     if (dc.d_order_scratch) (void)hipFree(dc.d_order_scratch);
     if (dc.d_slice_state) (void)hipFree(dc.d_slice_state);
+    if (dc.d_record_hits) (void)hipFree(dc.d_record_hits);
     if (dc.d_bvh_models) (void)hipFree(dc.d_bvh_models);
     if (dc.ev0) (void)hipEventDestroy(dc.ev0);
     if (dc.ev1) (void)hipEventDestroy(dc.ev1);
@@ -911,13 +981,22 @@ int32_t upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, const 
         v.simple_tree = e.simple_tree ? 1u : 0u;
         v.boxes_ordered = e.boxes_ordered ? 1u : 0u;
         dc.view = v;
+        dc.hot_records = 0u;
     }
+    ctx->tree_epoch++;          // (the records on the devices are in breadth-first order again: DeviceCtx::hot_tree no longer matches)
     for (auto& dc : ctx->devs) {
         HIP_TRY(ctx, hipSetDevice(dc.device));
         HIP_TRY(ctx, hipStreamSynchronize(dc.stream));  // the caller's vectors are no longer referenced
     }
     ctx->has_scene = true;
-    if (rebuild) { ctx->tree_rebuilds++; return BRT_OK; }     // (the bytes are ctx->last_* themselves; order history, centre: unchanged)
+    if (rebuild) {                                            // (the bytes are ctx->last_* themselves; centre, dirty tracking: unchanged)
+        ctx->tree_rebuilds++;
+        // another tree: its records have no visit counts yet -- the next frame of a view is a first frame again (pre-pass), as after
+        // the camera jump that usually comes with a rebuild
+        if (ctx->enc.n_models != 0u && !ctx->enc.pairs.empty())
+            for (auto& dc : ctx->devs) if (dc.hot_tree != 0u) { dc.order_valid = false; dc.view_rays = 0; }
+        return BRT_OK;
+    }
     ctx->last_models.assign(static_cast<const char*>(models), static_cast<const char*>(models) + mb);
     ctx->last_materials.assign(static_cast<const char*>(materials), static_cast<const char*>(materials) + tb);
     if (bb) ctx->last_bvh.assign(static_cast<const char*>(bvh_nodes), static_cast<const char*>(bvh_nodes) + bb);
@@ -1008,6 +1087,7 @@ int32_t render_part_device(brt_ctx* ctx, const void* camera80, const void* windo
         stats->threads_per_workgroup = lp.block;
         stats->kernel_variant = lp.variant;
         stats->measured_tile_costs = lp.measured;
+        stats->hot_records = dc.hot_tree == ctx->tree_epoch ? dc.hot_records : 0u;
     }
     if (own_stream) {
         // the order of the next frames is built on the same stream behind the frame, BEFORE the one synchronisation of this
@@ -1167,6 +1247,7 @@ int32_t render_frame(brt_ctx* ctx, const void* camera80, const void* window16, u
         stats->threads_per_workgroup = lp.block;
         stats->kernel_variant = lp.variant;
         stats->measured_tile_costs = lp.measured;
+        stats->hot_records = ctx->devs[0].hot_tree == ctx->tree_epoch ? ctx->devs[0].hot_records : 0u;
     }
     return BRT_OK;
 }
@@ -1331,6 +1412,7 @@ int32_t render_frame_device(brt_ctx* ctx, const void* camera80, const void* wind
         stats->threads_per_workgroup = lp.block;
         stats->kernel_variant = lp.variant;
         stats->measured_tile_costs = lp.measured;
+        stats->hot_records = ctx->devs[0].hot_tree == ctx->tree_epoch ? ctx->devs[0].hot_records : 0u;
     }
     return BRT_OK;
 }

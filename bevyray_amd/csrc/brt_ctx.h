@@ -74,6 +74,13 @@ struct DeviceCtx {
     uint32_t order_key[6] = {0, 0, 0, 0, 0, 0};   // width, height, part, n_parts, scene epoch, n_tiles
     std::vector<uint32_t> h_cost;
     std::vector<uint32_t> h_order;
+    // pair records re-numbered by how often the view visits them (brt_api.cpp apply_hot_order)
+    uint32_t* d_record_hits = nullptr;                   // FrameParams::record_hits of a pre-pass
+    size_t record_hits_cap = 0;
+    uint32_t hot_tree = 0;                               // brt_ctx::tree_epoch of the tree whose records are in hot order on this device (0: none)
+    uint32_t hot_records = 0;                            // ... and how many of them the measuring pre-pass visited at all
+    std::vector<uint32_t> h_hits, h_rank;
+    std::vector<float> h_pairs_hot, h_pairs_cur;          // scratch / the records as they are on the device (when hot_tree matches)
     // GPU BVH build
     char* d_bvh_scratch = nullptr;
     size_t bvh_scratch_cap = 0;
@@ -90,7 +97,7 @@ struct DeviceCtx {
 enum Knob : int {
     K_BOTTOM_UP, K_REFILL_MIN, K_WALK_EXIT, K_LEAF_VOTE, K_DRAIN_DONATE, K_POOL_ADOPT, K_WGQ_BATCH, K_LPT_LANE_PERMILLE, K_TUNABLE,
     K_FORCE_GLOBAL_SCENE, K_FORCE_LDS_TOP, K_BLOCK_THREADS, K_WG_PER_CU, K_POOL_CAP, K_LPT, K_LPT_SORT, K_LPT_SKY_SLACK, K_CRIT,
-    K_ORDER_ON_HOST, K_NO_LEAN, K_PREPASS_SPP, K_NO_DIRTY_TRACKING, K_CPU_BVH, K_PLOC_ONE_BLOCK_MAX, K_BVH_QUALITY, K_POOL_FORCE, K_LPT_REFRESH_EVERY, K_LEAN_MEASURE, K_LPT_DILATE, K_SPLIT_TAIL, K_SPLIT_FORCE, K_COUNT
+    K_ORDER_ON_HOST, K_NO_LEAN, K_PREPASS_SPP, K_NO_DIRTY_TRACKING, K_CPU_BVH, K_PLOC_ONE_BLOCK_MAX, K_BVH_QUALITY, K_POOL_FORCE, K_LPT_REFRESH_EVERY, K_LEAN_MEASURE, K_LPT_DILATE, K_SPLIT_TAIL, K_SPLIT_FORCE, K_HOT_RECORDS, K_COUNT
 };
 struct KnobDef { const char* name; uint32_t dflt; };
 constexpr KnobDef kKnobs[K_COUNT] = {
@@ -99,7 +106,7 @@ constexpr KnobDef kKnobs[K_COUNT] = {
     {"BRT_TUNABLE", 0}, {"BRT_FORCE_GLOBAL_SCENE", 0}, {"BRT_FORCE_LDS_TOP", 0}, {"BRT_BLOCK_THREADS", 0}, {"BRT_WG_PER_CU", 0},
     {"BRT_POOL_CAP", 384}, {"BRT_LPT", 1}, {"BRT_LPT_SORT", 1}, {"BRT_LPT_SKY_SLACK", 20}, {"BRT_CRIT", 1}, {"BRT_ORDER_ON_HOST", 0},
     {"BRT_NO_LEAN", 0}, {"BRT_PREPASS_SPP", 4}, {"BRT_NO_DIRTY_TRACKING", 0}, {"BRT_CPU_BVH", 0},
-    {"BRT_PLOC_ONE_BLOCK_MAX", kPlocOneBlockMax}, {"BRT_BVH_QUALITY", 1}, {"BRT_POOL_FORCE", 0}, {"BRT_LPT_REFRESH_EVERY", 0}, {"BRT_LEAN_MEASURE", 1}, {"BRT_LPT_DILATE", 3}, {"BRT_SPLIT_TAIL", 16}, {"BRT_SPLIT_FORCE", 0}};
+    {"BRT_PLOC_ONE_BLOCK_MAX", kPlocOneBlockMax}, {"BRT_BVH_QUALITY", 1}, {"BRT_POOL_FORCE", 0}, {"BRT_LPT_REFRESH_EVERY", 0}, {"BRT_LEAN_MEASURE", 1}, {"BRT_LPT_DILATE", 3}, {"BRT_SPLIT_TAIL", 16}, {"BRT_SPLIT_FORCE", 0}, {"BRT_HOT_RECORDS", 1}};
 struct Knobs {
     uint32_t v[K_COUNT];
     Knobs() { for (int i = 0; i < K_COUNT; i++) v[i] = kKnobs[i].dflt; }
@@ -125,6 +132,7 @@ struct brt_ctx {
     brt::EncodedScene enc;
     bool has_scene = false;
     uint32_t scene_epoch = 0;   // bumped by every upload
+    uint32_t tree_epoch = 0;    // bumped whenever the encoded tree on the devices is rewritten (uploads, rebuilds for the camera's reach)
     uint32_t last_n_models = 0; // spheres of the last successful upload
     std::vector<std::pair<char*, size_t>> pinned;   // brt_host_alloc blocks
     // bytes of the last successful upload (dirty tracking: an unchanged scene is not re-sent)

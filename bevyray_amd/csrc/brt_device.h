@@ -321,6 +321,7 @@ struct ScenePtrs {
     const uint32_t* sphere_material;
     const float4* materials;
     const uint2* leaf_table;
+    uint32_t* hits;          // pre-pass of a SCENE_LDS_TOP scene: interior visits per pair record, a histogram in LDS (else null)
 };
 
 struct HitCounters {
@@ -452,10 +453,11 @@ BRT_DEV bool ray_is_safe(f3 o, f3 inv) {
 // tests, push/pop as selects.  FIX: apply min/max to the {near, far} values read (needed when some ray
 // of the wave is not safe or the boxes are not ordered); without it the read offset has already made
 // that choice.
-template <int STRIDE, bool COUNTERS, bool FIX, bool D16, int MODE, typename StackT>
+template <int STRIDE, bool COUNTERS, bool FIX, bool D16, int MODE, typename StackT, bool HITS = false>
 BRT_DEV void walk_interior_step(const ScenePtrs& sc, f3 o, f3 inv, uint32_t ox, uint32_t oy, uint32_t oz, float below,
                                 uint32_t& cur, StackT*& sp, uint32_t& n, HitCounters& hc) {
     if (COUNTERS) { hc.node_pops++; hc.interior++; }
+    if (HITS) atomicAdd(sc.hits + cur, 1u);              // (16-bit descriptors: an interior descriptor is the record's index)
     if (STRIDE == 64) prof_section<COUNTERS>(hc, SEC_INTERIOR, true);
     const uint32_t ro = Desc<D16>::record_offset(cur);   // byte offset of the pair record
     float4 gx, gy, gz;                                   // per axis { near L, near R, far L, far R }
@@ -541,7 +543,7 @@ BRT_DEV void walk_interior_step(const ScenePtrs& sc, f3 o, f3 inv, uint32_t ox, 
 }
 
 // The wave-level walk loop (see walk_run).
-template <bool COUNTERS, bool D16, bool SIMPLE_TREE, bool FIX, int MODE, typename StackT>
+template <bool COUNTERS, bool D16, bool SIMPLE_TREE, bool FIX, int MODE, typename StackT, bool HITS = false>
 BRT_DEV void walk_loop_wave(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, uint32_t ox, uint32_t oy, uint32_t oz,
                             float& closest, uint32_t& closest_idx, uint32_t& cur, StackT*& sp, uint32_t& n,
                             uint32_t exit_at, uint32_t vote, HitCounters& hc) {
@@ -551,7 +553,7 @@ BRT_DEV void walk_loop_wave(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, ui
         for (;;) {
             const bool interior = DS::is_interior(cur) && (SIMPLE_TREE || n < 31u);
             if (__ballot(interior) == 0ull) break;
-            if (interior) walk_interior_step<64, COUNTERS, FIX, D16, MODE>(sc, o, inv, ox, oy, oz, below, cur, sp, n, hc);
+            if (interior) walk_interior_step<64, COUNTERS, FIX, D16, MODE, StackT, HITS>(sc, o, inv, ox, oy, oz, below, cur, sp, n, hc);
             if (wave_count(DS::is_leaf(cur) && (SIMPLE_TREE || n < 31u)) >= vote) break;
         }
         if (DS::is_leaf(cur) && (SIMPLE_TREE || n < 31u)) {
@@ -961,7 +963,9 @@ BRT_DEV void walk_loop_wave_top(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv
     sp = (StackT*)reinterpret_cast<lds_stack*>((uintptr_t)spa);
 }
 
-template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, int MODE, typename StackT>
+// HITS: the instantiation can count interior visits per record (sc.hits; the pre-pass of a SCENE_LDS_TOP scene): such a launch walks
+// in the compiler's loop, the repairing form (a superset of the plain one: the min / max it adds change nothing for safe rays).
+template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, int MODE, typename StackT, bool HITS = false>
 BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, f3 o, f3 d,
                       uint32_t exit_lanes, uint32_t leaf_vote, HitCounters& hc) {
     using DS = Desc<D16>;
@@ -1001,8 +1005,12 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, f3
             // For the same reason the (rare) wave with an unsafe ray does not take the repairing loop INSTEAD of the hand-written one
             // but BEFORE it: that loop leaves with at most exit_at lanes walking, and the hand-written one then returns at its first test.
             constexpr bool kByHand = BRT_WALK_FAST && MODE == SCENE_LDS && !COUNTERS && SIMPLE_TREE && D16;
-            const bool any_unsafe = __ballot(unsafe) != 0ull;
-            if (any_unsafe)
+            const bool counting = HITS && D16 && sc.hits != nullptr;           // (wave-uniform: a kernel argument)
+            const bool any_unsafe = __ballot(unsafe) != 0ull || counting;
+            if (counting)
+                walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, true, MODE, StackT, HITS && D16>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp,
+                                                                                            n, exit_at, vote, hc);
+            else if (any_unsafe)
                 walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, true, MODE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp,
                                                                        n, exit_at, vote, hc);
             constexpr bool kByHandTop = BRT_WALK_FAST && BRT_WALK_FAST_TOP && MODE != SCENE_LDS && !COUNTERS && SIMPLE_TREE && D16;

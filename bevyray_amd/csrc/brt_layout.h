@@ -211,6 +211,11 @@ struct FrameParams {
     uint32_t split_nonsky, split_tiles;
     uint32_t* slice_state;
     uint32_t slice_serial;
+    // Pre-pass of a scene walked from the LDS tile + global memory (SCENE_LDS_TOP): interior visits per pair record are counted (a
+    // histogram in each workgroup's LDS, added here at the end of the launch); the host then re-numbers the records by how often THIS
+    // view visits them, so that the tile holds the records the walk actually uses instead of the breadth-first top (brt_api.cpp
+    // apply_hot_order).  n_pairs words, or null.  TUNABLE instantiation only.
+    uint32_t* record_hits;
     uint32_t raster_dense;           // 1: the raster inputs hold this part's strips only, in the tile's own layout (row k * 8 + r = frame row
                                      // (k * n_parts + part) * 8 + r): what a device of an N-device context is sent; 0: the full frame
     uint32_t tunable;                // 1: some knob above differs from its default -> the TUNABLE kernel instantiation

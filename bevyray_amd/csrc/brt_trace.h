@@ -490,6 +490,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     sc.near_bytes = 0u;
     sc.near_base = 0u;
     sc.sph_base = 0u;
+    sc.hits = nullptr;
     if (MODE == SCENE_LDS) {
         // carve: pair records | spheres | leaf_table | sphere_material | stacks
         const uint32_t pair_granules = (uint32_t)(pair_array_bytes(sv.n_pairs) / 16);
@@ -551,6 +552,15 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         pool_ctl = reinterpret_cast<uint32_t*>(lds + off);
         pool = reinterpret_cast<float4*>(lds + off + 16u);
         if (threadIdx.x == 0) { pool_ctl[0] = 0u; pool_ctl[1] = 0u; pool_ctl[2] = n_waves; pool_ctl[3] = 0u; }
+    }
+    // pre-pass of a scene walked from the tile + global memory: this workgroup's histogram of interior visits per record, behind the pool
+    constexpr bool kHits = TUNABLE && MODE == SCENE_LDS_TOP;
+    uint32_t* hist = nullptr;
+    if (kHits && fp.record_hits != nullptr) {
+        if (fp.pool_cap != 0u) off += 16u + fp.pool_cap * POOL_RECORD_BYTES;
+        hist = reinterpret_cast<uint32_t*>(lds + off);
+        for (uint32_t i = threadIdx.x; i < sv.n_pairs; i += blockDim.x) hist[i] = 0u;
+        sc.hits = hist;
     }
     if (threadIdx.x < WGQ_BYTES / 4u) wgq[threadIdx.x] = 0u;
     __syncthreads();
@@ -835,7 +845,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         if (fresh) walk_begin<D16>(walk, sc, sv.root_desc, stk, d);
         if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_pre += now - t_mark; t_mark = now; }
         if (kPhasePrio == 1 && !wave_crit) __builtin_amdgcn_s_setprio(1);
-        if (active) walk_run<64, COUNTERS, D16, SIMPLE, MODE>(sc, walk, stk, o, d, finish_walks ? 0u : walk_exit_lanes, leaf_vote, hc);
+        if (active) walk_run<64, COUNTERS, D16, SIMPLE, MODE, StackT, kHits>(sc, walk, stk, o, d, finish_walks ? 0u : walk_exit_lanes, leaf_vote, hc);
         in_flight = active && walk_pending<D16, SIMPLE>(walk);
         if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_walk += now - t_mark; t_mark = now; }
         const bool landed = active && !in_flight;      // walk finished: shade this segment now
@@ -863,6 +873,14 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         again_mark = false;
     }
 
+    // ---- pre-pass: the workgroup's histogram of record visits into the launch's (every wave of the workgroup ends up here) ----
+    if (kHits && hist != nullptr) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < sv.n_pairs; i += blockDim.x) {
+            const uint32_t c = hist[i];
+            if (c != 0u) atomicAdd(&fp.record_hits[i], c);
+        }
+    }
     // ---- counters: one atomic per wave ----
     const uint32_t r = wave_sum(n_rays);
     if (lane == 0) atomicAdd(&counters[0], (unsigned long long)r);

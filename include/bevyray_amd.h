@@ -123,6 +123,10 @@ typedef struct brt_stats {
     float    tree_reach;       /* the `reach` the resident callee-built SAH tree was built with (what brt_build_bvh_sah takes: 0 = the
                                   scene's own extent); 0 for a caller's tree */
     uint64_t forwarded_bytes;  /* brt_render_device: bytes of the raster inputs forwarded to the other devices of the context */
+    uint32_t hot_records;      /* a scene walked from an LDS tile + L2 (scene_in_lds == 2): the tree's records are numbered by how often this
+                                  view visits them (measured by the pre-pass of a first frame), so that the tile holds the ones the walk
+                                  uses; this many of them were visited at all.  0: breadth-first numbering (no pre-pass yet / another mode) */
+    uint32_t reserved;
 } brt_stats;
 
 uint32_t brt_abi_version(void);

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), "ctypes prototypes out of sync with the header"
     assert _lib.load().brt_abi_version() == 5
     import ctypes
-    assert ctypes.sizeof(_lib.BrtStats) == 120         # 9 x 8 + 4 x 4 + prepass_ms + kernel_variant, measured_tile_costs + tree_rebuilt, tree_reach, forwarded_bytes (include/bevyray_amd.h, ABI 5)
+    assert ctypes.sizeof(_lib.BrtStats) == 128         # 9 x 8 + 4 x 4 + prepass_ms + kernel_variant, measured_tile_costs + tree_rebuilt, tree_reach, forwarded_bytes (include/bevyray_amd.h, ABI 5)
 
 
 def test_wire_layouts_match_the_wgsl_structs():

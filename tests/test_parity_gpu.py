@@ -718,6 +718,41 @@ def test_bringup_kernel_after_frames_with_half_sample_jobs(plugin, oracle):
         assert_frames_equal(plugin.node.run(lvl, cam, win, w, h), want)      # and the persistent kernel again, same view
 
 
+def test_records_numbered_by_visits_same_pixels_and_counters(oracle):
+    """a scene whose tree does not fit the LDS is walked from a tile of the first K pair records in LDS and the rest
+    from L2.  The pre-pass of a first frame counts the interior visits per record and the records are re-numbered by them (most
+    visited first), so that the tile holds what THIS view walks instead of the breadth-first top of the tree
+    (brt_api.cpp apply_hot_order).  Only the numbering changes: pixels, ray count and all five counters equal the oracle's, with
+    the order on and off, after a camera jump (counted again, permutations compose), with a tile of a handful of records, over three
+    sub-contexts, and in the counting and the production instantiations."""
+    b = brt.generate_scene(brt.SCENE_STRESS_GRID, 1)
+    nb = brt.Buffers(b.models, b.materials, None)
+    tree = brt.Buffers(b.models, b.materials, brt.build_bvh_sah(b.models))
+    w, h, spp, bounces = 640, 360, 64, 4
+    views = [brt.cover_camera(w, h, spp, bounces), uniforms(w, h, spp, bounces, (-30.0, 6.0, 22.0), (10.0, 0.0, -5.0), 0.7, 0.31)]
+    wants = [oracle.render(tree, *v, w, h) for v in views]
+    for ids, knobs in (([0], {}), ([0], {"BRT_HOT_RECORDS": 0}), ([0], {"BRT_FORCE_LDS_TOP": 70}), ([0, 0, 0], {})):
+        with brt.RaytracePlugin(ids) as p:
+            for k, v in knobs.items():
+                p.set_tuning(k, v)
+            for (lvl, cam, win), (want, cnt) in zip(views, wants):         # the second view is a camera jump: pre-pass, counted again
+                for frame in range(3):
+                    got = p.node.run(lvl, cam, win, w, h, buffers=nb if frame == 0 else None)
+                    st = dict(p.node.last_stats)
+                    assert_frames_equal(got, want)
+                    assert st["rays"] == cnt["rays"] and st["scene_in_lds"] == 2
+                    assert (st["hot_records"] > 1000) == (knobs.get("BRT_HOT_RECORDS", 1) == 1), st
+                got = p.node.run(lvl, cam, win, w, h, flags=brt.FLAG_COUNTERS)
+                assert_frames_equal(got, want)
+                assert {q: p.node.last_stats[q] for q in COUNTER_KEYS} == cnt
+    # a scene that fits the LDS is never re-numbered (nothing to gain), whatever the pre-pass does
+    c = brt.generate_scene(brt.SCENE_COVER, 1)
+    with brt.RaytracePlugin([0]) as p:
+        lvl, cam, win = brt.cover_camera(320, 180, 64, 4)
+        p.node.run(lvl, cam, win, 320, 180, buffers=brt.Buffers(c.models, c.materials, None))
+        assert p.node.last_stats["hot_records"] == 0 and p.node.last_stats["scene_in_lds"] == 1
+
+
 def _far_camera(k, w, h, spp, bounces):
     """the cover view from k times the distance, field of view narrowed by k: the same picture, rays k times as long"""
     return uniforms(w, h, spp, bounces, (13.0 * k, 2.0 * k, 3.0 * k), (0.0, 0.0, 0.0), 0.4 / k, 0.5, far=1.0e5)
