@@ -514,14 +514,15 @@ int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const fl
 // addresser 71 % busy: profiles/r05/config5_memory_side_before.json).  So the pre-pass of a first frame counts the visits per record
 // (FrameParams::record_hits), and here the records are re-numbered by them, most visited first (ties: breadth-first order), the child
 // descriptors and the root re-written, the records re-sent -- 1.1 MB and a host sort of 10 003 counts per pre-pass and device.
+// The spheres are re-numbered with them (an internal numbering: nothing outside sees a sphere's index), see below.
 // Only the NUMBERING of the records changes: the walk visits the same nodes in the same order, pixels and all five counters stay.
 int32_t apply_hot_order(brt_ctx* ctx, DeviceCtx& dc, hipStream_t stream) {
-    const uint32_t n = dc.view.n_pairs;
+    const uint32_t n = dc.view.n_pairs, m = dc.view.n_models;
     const EncodedScene& e = ctx->enc;
-    if (n == 0u || e.pairs.size() != (size_t)n * PAIR_WORDS) return BRT_OK;
-    // the records as they are on the device now: breadth first after an upload, else the order of this device's last pre-pass (the
-    // counts are indexed by THAT numbering)
-    if (dc.hot_tree != ctx->tree_epoch) dc.h_pairs_cur = e.pairs;
+    if (n == 0u || e.pairs.size() != (size_t)n * PAIR_WORDS || e.spheres.size() != (size_t)m * 4u || e.sphere_material.size() != m) return BRT_OK;
+    // the records (and spheres) as they are on the device now: as encoded after an upload, else in the order of this device's last
+    // pre-pass (the counts are indexed by THAT numbering)
+    if (dc.hot_tree != ctx->tree_epoch) { dc.h_pairs_cur = e.pairs; dc.h_spheres_cur = e.spheres; dc.h_sphmat_cur = e.sphere_material; }
     const std::vector<float>& cur = dc.h_pairs_cur;
     const uint32_t cur_root = dc.hot_tree != ctx->tree_epoch ? e.root_desc : dc.view.root_desc;
     dc.h_hits.resize(n);
@@ -534,9 +535,34 @@ int32_t apply_hot_order(brt_ctx* ctx, DeviceCtx& dc, hipStream_t stream) {
     rank.resize(n);
     uint32_t visited = 0;
     for (uint32_t i = 0; i < n; i++) { rank[order[i]] = i; visited += dc.h_hits[order[i]] != 0u ? 1u : 0u; }
-    auto remap = [&](uint32_t d) { return ((int32_t)d >= 0 && d < n) ? rank[d] : d; };      // interior descriptors (16-bit form: the record's index)
-    dc.h_pairs_hot.resize(cur.size());
+    // the spheres likewise, by the visits of the record they hang under (a sphere is tested when its parent is visited and its box is
+    // hit: the parent's count ranks it well enough -- the first 1 024 take 97 % of the 10 004-sphere frame's tests -- and needs no
+    // second histogram): the leaf steps' sphere reads then fall on a few hot lines of the L1 (staging the first 512 / 1 024 / 2 048 of them
+    // in LDS for the leaf step of the hand-written loop was built and measured: 13.88 / 13.97 / 14.2 ms against 13.92 without, not kept:
+    // profiles/r05/config5_hot_records_ab.txt)
+    using D = Desc<true>;
     constexpr uint32_t kDescWord = PAIR_DESC / 4u;
+    std::vector<uint32_t> score(m, 0u), sorder(m), srank(m);
+    auto leaf_sphere = [&](uint32_t d, uint32_t* id) {
+        if ((int32_t)d < -1 && (d & D::LEAF1)) { *id = d & D::INDEX_MASK; return *id < m; }
+        return false;
+    };
+    for (uint32_t r = 0; r < n; r++)
+        for (uint32_t k = 0; k < 2u; k++) {
+            uint32_t d, id;
+            std::memcpy(&d, cur.data() + (size_t)r * PAIR_WORDS + kDescWord + k, 4);
+            if (leaf_sphere(d, &id) && dc.h_hits[r] > score[id]) score[id] = dc.h_hits[r];
+        }
+    for (uint32_t i = 0; i < m; i++) sorder[i] = i;
+    std::stable_sort(sorder.begin(), sorder.end(), [&](uint32_t a, uint32_t b) { return score[a] > score[b]; });
+    for (uint32_t i = 0; i < m; i++) srank[sorder[i]] = i;
+    auto remap = [&](uint32_t d) {
+        uint32_t id;
+        if ((int32_t)d >= 0 && d < n) return rank[d];                             // interior (16-bit form: the record's index)
+        if (leaf_sphere(d, &id)) return (d & ~D::INDEX_MASK) | srank[id];       // single-sphere leaf
+        return d;
+    };
+    dc.h_pairs_hot.resize(cur.size());
     for (uint32_t i = 0; i < n; i++) {
         const float* src = cur.data() + (size_t)order[i] * PAIR_WORDS;
         float* dst = dc.h_pairs_hot.data() + (size_t)i * PAIR_WORDS;
@@ -548,9 +574,19 @@ int32_t apply_hot_order(brt_ctx* ctx, DeviceCtx& dc, hipStream_t stream) {
             std::memcpy(dst + kDescWord + k, &d, 4);
         }
     }
+    std::vector<float> sph(dc.h_spheres_cur.size());
+    std::vector<uint32_t> mat(m);
+    for (uint32_t i = 0; i < m; i++) {
+        std::memcpy(sph.data() + (size_t)i * 4, dc.h_spheres_cur.data() + (size_t)sorder[i] * 4, 16);
+        mat[i] = dc.h_sphmat_cur[sorder[i]];
+    }
     HIP_TRY(ctx, hipMemcpyAsync(const_cast<float*>(dc.view.pairs), dc.h_pairs_hot.data(), dc.h_pairs_hot.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(ctx, hipMemcpyAsync(const_cast<float*>(dc.view.spheres), sph.data(), sph.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(ctx, hipMemcpyAsync(const_cast<uint32_t*>(dc.view.sphere_material), mat.data(), mat.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));       // (the vectors are reused by the next call)
     dc.h_pairs_cur.swap(dc.h_pairs_hot);
+    dc.h_spheres_cur.swap(sph);
+    dc.h_sphmat_cur.swap(mat);
     dc.view.root_desc = remap(cur_root);
     dc.hot_tree = ctx->tree_epoch;
     dc.hot_records = visited;

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void k_trace_simple(DeviceSceneView sv, FrameP
     sc.near_bytes = 0u;
     sc.near_base = 0u;
     sc.sph_base = 0u;
+    sc.hits = nullptr;
     sc.boxes_ordered = sv.boxes_ordered != 0u;
     sc.spheres = reinterpret_cast<const float4*>(sv.spheres);
     sc.sphere_material = sv.sphere_material;

@@ -209,12 +209,20 @@ static inline float ray_bounding_dst(Ray ray, vec3 box_min, vec3 box_max) {
     return hit ? (t_near > 0.0f ? t_near : 0.0f) : INF;
 }
 
+/* Diagnostic (tests/tools/visit_hist.py): interior visits per BVH node of the renders that follow, summed into a caller's array
+ * of n_nodes words -- which records of the tree a view actually walks.  NULL switches it off.  Process-wide. */
+static uint64_t* g_visit_counts = NULL;
+static uint64_t* g_sphere_counts = NULL;      /* ... and sphere tests per model */
+void oracle_set_visit_counts(uint64_t* per_node) { g_visit_counts = per_node; }
+void oracle_set_sphere_counts(uint64_t* per_model) { g_sphere_counts = per_model; }
+
 /* raytrace.wgsl:348-362 */
 static inline void raycast_against_range(const Scene* s, Ray ray, uint32_t start_index, uint32_t amount,
                                          HitInfo* closest, Counters* cnt) {
     for (uint32_t model_index = start_index; model_index < start_index + amount; model_index++) {
         const Model* model = &s->models[model_index];
         cnt->sphere_tests++;
+        if (g_sphere_counts) __atomic_fetch_add(&g_sphere_counts[model_index], 1, __ATOMIC_RELAXED);
         float hit_distance = hit_sphere(model, ray);
         if (hit_distance != -1.0f && hit_distance > 0.001f) {
             if (hit_distance < closest->distance) {
@@ -232,10 +240,6 @@ static inline void raycast_against_range(const Scene* s, Ray ray, uint32_t start
 
 #define STACKSIZE 32  /* raytrace.wgsl:310 */
 
-/* Diagnostic (tests/tools/visit_hist.py): interior visits per BVH node of the renders that follow, summed into a caller's array
- * of n_nodes words -- which records of the tree a view actually walks.  NULL switches it off.  Process-wide. */
-static uint64_t* g_visit_counts = NULL;
-void oracle_set_visit_counts(uint64_t* per_node) { g_visit_counts = per_node; }
 
 /* raytrace.wgsl:313-346 */
 static HitInfo raycast(const Scene* s, Ray ray, Counters* cnt) {

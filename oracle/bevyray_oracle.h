@@ -44,6 +44,7 @@ int oracle_raycast(const void* models, uint32_t n_models, const void* bvh_nodes,
 
 /* Diagnostic: interior visits per BVH node of the renders that follow go into per_node[n_nodes] (NULL: off). */
 void oracle_set_visit_counts(uint64_t* per_node);
+void oracle_set_sphere_counts(uint64_t* per_model);      /* sphere tests per model */
 
 /* The colour target's store conversion of an RGBA f32 frame (checker side; bevyray_oracle.c): format 1 = RGBA8 sRGB
  * (4 bytes per pixel), 2 = RGBA16F (8 bytes), 3 = RGBA8 unorm (4 bytes).  Returns 0 on success. */

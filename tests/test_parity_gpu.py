@@ -727,10 +727,11 @@ def test_records_numbered_by_visits_same_pixels_and_counters(oracle):
     sub-contexts, and in the counting and the production instantiations."""
     b = brt.generate_scene(brt.SCENE_STRESS_GRID, 1)
     nb = brt.Buffers(b.models, b.materials, None)
-    tree = brt.Buffers(b.models, b.materials, brt.build_bvh_sah(b.models))
     w, h, spp, bounces = 640, 360, 64, 4
     views = [brt.cover_camera(w, h, spp, bounces), uniforms(w, h, spp, bounces, (-30.0, 6.0, 22.0), (10.0, 0.0, -5.0), 0.7, 0.31)]
-    wants = [oracle.render(tree, *v, w, h) for v in views]
+    # (the second camera stands further out than the scene's own extent covers: its frames run in the tree rebuilt for its reach)
+    wants = [oracle.render(brt.Buffers(b.models, b.materials, brt.build_bvh_sah(b.models, brt.tree_reach(b.models, v[1])[2])), *v, w, h) for v in views]
+    assert brt.tree_reach(b.models, views[0][1])[1] == 0 and brt.tree_reach(b.models, views[1][1])[1] > 0
     for ids, knobs in (([0], {}), ([0], {"BRT_HOT_RECORDS": 0}), ([0], {"BRT_FORCE_LDS_TOP": 70}), ([0, 0, 0], {})):
         with brt.RaytracePlugin(ids) as p:
             for k, v in knobs.items():

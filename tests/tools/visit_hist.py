@@ -20,8 +20,12 @@ lvl, cam, win = brt.cover_camera(w, h, spp, 8)
 counts = np.zeros(len(tree), np.uint64)
 o.lib.oracle_set_visit_counts.argtypes = [C.c_void_p]
 o.lib.oracle_set_visit_counts(counts.ctypes.data)
+sph = np.zeros(len(b.models), np.uint64)
+o.lib.oracle_set_sphere_counts.argtypes = [C.c_void_p]
+o.lib.oracle_set_sphere_counts(sph.ctypes.data)
 _, cnt = o.render(brt.Buffers(b.models, b.materials, tree), lvl, cam, win, w, h)
 o.lib.oracle_set_visit_counts(None)
+o.lib.oracle_set_sphere_counts(None)
 interior = np.flatnonzero(tree["model_count"] == 0)
 # breadth-first rank of the interior nodes (what the encoder numbers pair records by)
 order, q = [], [0]
@@ -42,3 +46,9 @@ print(f"{'records in LDS':>15s} {'breadth-first':>14s} {'by visits':>10s}   (sha
 for k in (400, 879, 1240, 1550, 1774, 2400, 3100, 4096, len(order)):
     a, bb = c_bfs[:k].sum() / total, c_hot[:k].sum() / total
     print(f"{k:15d} {a:14.3f} {bb:10.3f}   global steps per ray: {(1 - a) * total / cnt['rays']:.2f} -> {(1 - bb) * total / cnt['rays']:.2f}")
+
+s_hot = np.sort(sph.astype(np.float64))[::-1]
+print(f"sphere tests per ray {s_hot.sum() / cnt['rays']:.2f}; spheres never tested: {(s_hot == 0).sum()} of {len(s_hot)}")
+print(f"{'spheres in LDS':>15s} {'by tests':>10s}   (share of the sphere tests served from LDS)")
+for k in (256, 512, 1024, 1536, 2048, 3072, 4096, 6144):
+    print(f"{k:15d} {s_hot[:k].sum() / s_hot.sum():10.3f}")
