@@ -30,6 +30,22 @@ namespace brt {
 #define BRT_HAND_ASM 1
 #endif
 
+// Diagnostic build (-DBRT_ASM_COUNT, scripts/asm_count.py): the hand-written loops count their own executions and active lanes --
+// interior steps, leaf steps, rejection-sampler iterations -- in scalar registers (s_add_u32 beside the vector work), summed per
+// wave into control words 33..38 (brt_debug_profile); the steps of the rare waves that carry an unsafe ray and walk in the compiler's
+// repairing loop first (walk_run) go into words 39 and 43 (lanes).  The COUNTERS instantiation counts the same quantities in the COMPILER's loops;
+// this closes the gap between "the work of the frame" and "what the timed kernel executed" (What's weak #8).
+#ifndef BRT_ASM_COUNT
+#define BRT_ASM_COUNT 0
+#endif
+struct AsmCounts { uint32_t int_exec, int_lanes, leaf_exec, leaf_lanes, ball_exec, ball_lanes, fix_int_lanes, fix_leaf_lanes; };
+// (a call's counts are wave-uniform scalars; they are booked by the first lane that is active at the call, like prof_section, and
+//  summed over the lanes at the end of the kernel)
+__device__ __forceinline__ bool first_active_lane() {
+    const uint64_t m = __ballot(true);
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0u;
+}
+
 #ifndef BRT_EXEC_MOVES
 #define BRT_EXEC_MOVES 0   // bit 0: sphere test, bit 1: ball loop -- `if` bodies of v_mov under EXEC instead of v_cndmask selects; measured: -0.0 ... +0.8 % (the compiler adds a branch per `if`), off
 #endif
@@ -194,8 +210,14 @@ BRT_DEV f3 rng_unit_ball(uint32_t& state) {
 #ifndef BRT_BALL_ASM
 #define BRT_BALL_ASM BRT_HAND_ASM
 #endif
-BRT_DEV void ball_loop_asm(uint32_t& rng, f3& acc, float rough, uint64_t m2, uint64_t m1) {
+BRT_DEV void ball_loop_asm(uint32_t& rng, f3& acc, float rough, uint64_t m2, uint64_t m1, AsmCounts* ac = nullptr) {
 #if BRT_HAND_ASM
+#if BRT_ASM_COUNT
+    uint32_t c_exec, c_lanes, c_tmp;
+#define BRT_COUNT_BALL "s_bcnt1_i32_b64 %[c_tmp], exec\n s_add_u32 %[c_lanes], %[c_lanes], %[c_tmp]\n s_add_u32 %[c_exec], %[c_exec], 1\n"
+#else
+#define BRT_COUNT_BALL
+#endif
     uint32_t t;
     float x, y, z, x1, y1, z1, q, r;
     uint64_t s_all, s_up, s_two, s_part;
@@ -231,12 +253,16 @@ BRT_DEV void ball_loop_asm(uint32_t& rng, f3& acc, float rough, uint64_t m2, uin
         "v_mov_b32_e32 %[z1], %[z]\n"                                                                                       \
         "s_or_b64 exec, %[m2], %[m1]\n"                     /* SCC: somebody still needs one */
     asm volatile(
+#if BRT_ASM_COUNT
+        "s_mov_b32 %[c_exec], 0\n s_mov_b32 %[c_lanes], 0\n"
+#endif
         "s_mov_b64 %[s_all], exec\n"
         "s_mov_b64 %[s_two], %[m2]\n"
         "s_or_b64 %[s_part], %[m2], %[m1]\n"
         "s_mov_b64 exec, %[s_part]\n"
         "s_cbranch_execz 2f\n"
         "1:\n"
+        BRT_COUNT_BALL
         BRT_BALL_ITERATION
         "s_cbranch_scc1 1b\n"                               // (two iterations per trip with a fall-through exit between them: measured, no gain)
         "s_mov_b64 exec, %[s_two]\n"                        // diffuse: acc = normal + 1.0 * p1 ...
@@ -255,8 +281,15 @@ BRT_DEV void ball_loop_asm(uint32_t& rng, f3& acc, float rough, uint64_t m2, uin
         : [rng] "+v"(rng), [ax] "+v"(acc.x), [ay] "+v"(acc.y), [az] "+v"(acc.z), [m2] "+s"(m2), [m1] "+s"(m1),
           [t] "=&v"(t), [x] "=&v"(x), [y] "=&v"(y), [z] "=&v"(z), [x1] "=&v"(x1), [y1] "=&v"(y1), [z1] "=&v"(z1), [q] "=&v"(q), [r] "=&v"(r),
           [s_all] "=&s"(s_all), [s_up] "=&s"(s_up), [s_two] "=&s"(s_two), [s_part] "=&s"(s_part)
+#if BRT_ASM_COUNT
+          , [c_exec] "=&s"(c_exec), [c_lanes] "=&s"(c_lanes), [c_tmp] "=&s"(c_tmp)
+#endif
         : [rough] "v"(rough), [c_mul] "s"(c_mul), [c_2m31] "s"(c_2m31)
         : "vcc", "scc", "memory");
+#if BRT_ASM_COUNT
+    if (first_active_lane()) { ac->ball_exec += c_exec; ac->ball_lanes += c_lanes; }
+#endif
+#undef BRT_COUNT_BALL
 #undef BRT_BALL_ITERATION
 #undef BRT_RNG_DRAW
 #endif
@@ -330,6 +363,7 @@ struct HitCounters {
     // lanes (lane-utilisation profile; read by brt_debug_profile)
     uint32_t sec_exec[8], sec_lanes[8];
     unsigned long long ticks_ball;   // COUNTERS builds: wave time in the rejection-sampler loop (100 MHz ticks)
+    AsmCounts asm_counts;            // -DBRT_ASM_COUNT builds: what the hand-written loops executed (else untouched)
 };
 enum { SEC_INTERIOR = 0, SEC_LEAF, SEC_CAMERA, SEC_SCATTER, SEC_SKY, SEC_BALL, SEC_CAMERA_TOP, SEC_ROUND };   // SEC_CAMERA: camera rays made in shade_landed; _TOP: at the top of a round
 
@@ -418,6 +452,7 @@ BRT_DEV void walk_leaf_step(const ScenePtrs& sc, f3 o, f3 d, float a, float& clo
                             StackT*& sp, uint32_t& n, HitCounters& hc) {
     using DS = Desc<D16>;
     if (COUNTERS) hc.node_pops++;
+    if (BRT_ASM_COUNT && !COUNTERS && STRIDE == 64) hc.asm_counts.fix_leaf_lanes++;      // (single-sphere leaves: one test per step)
     if (STRIDE == 64) prof_section<COUNTERS>(hc, SEC_LEAF, true);
     const uint32_t first = cur & DS::INDEX_MASK;
     const uint32_t popped = (uint32_t)(int32_t)*sp;  // issued before the sphere arithmetic (sign-extending load)
@@ -457,6 +492,7 @@ template <int STRIDE, bool COUNTERS, bool FIX, bool D16, int MODE, typename Stac
 BRT_DEV void walk_interior_step(const ScenePtrs& sc, f3 o, f3 inv, uint32_t ox, uint32_t oy, uint32_t oz, float below,
                                 uint32_t& cur, StackT*& sp, uint32_t& n, HitCounters& hc) {
     if (COUNTERS) { hc.node_pops++; hc.interior++; }
+    if (BRT_ASM_COUNT && !COUNTERS && STRIDE == 64) hc.asm_counts.fix_int_lanes++;
     if (HITS) atomicAdd(sc.hits + cur, 1u);              // (16-bit descriptors: an interior descriptor is the record's index)
     if (STRIDE == 64) prof_section<COUNTERS>(hc, SEC_INTERIOR, true);
     const uint32_t ro = Desc<D16>::record_offset(cur);   // byte offset of the pair record
@@ -601,13 +637,24 @@ BRT_DEV void walk_loop_wave(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, ui
 // three fma steps, v_div_fmas, v_div_fixup), with the wait states its hazard recogniser would insert; the accept rule
 // t > 0.001 && t < closest moves t and the sphere id under EXEC.
 BRT_DEV void walk_wave_lds_asm(uint32_t& cur, uint32_t& spa, float& closest, uint32_t& closest_idx, uint32_t gofs_x, uint32_t gofs_y,
-                               uint32_t gofs_z, f3 o, f3 inv, f3 d, float a, uint32_t sph, uint32_t exit_at, uint32_t vote) {
+                               uint32_t gofs_z, f3 o, f3 inv, f3 d, float a, uint32_t sph, uint32_t exit_at, uint32_t vote, AsmCounts* ac = nullptr) {
 #if BRT_HAND_ASM
+#if BRT_ASM_COUNT
+    uint32_t c_ie, c_il, c_le, c_ll, c_tmp;
+#define BRT_COUNT_INT "s_bcnt1_i32_b64 %[c_tmp], exec\n s_add_u32 %[c_il], %[c_il], %[c_tmp]\n s_add_u32 %[c_ie], %[c_ie], 1\n"
+#define BRT_COUNT_LEAF "s_bcnt1_i32_b64 %[c_tmp], exec\n s_add_u32 %[c_ll], %[c_ll], %[c_tmp]\n s_add_u32 %[c_le], %[c_le], 1\n"
+#else
+#define BRT_COUNT_INT
+#define BRT_COUNT_LEAF
+#endif
     uint32_t t0, tx, ty, tz, pop, cnt, nw, thr;
     float below;
     uint64_t s_all, s_take, s_p2, s_any, s_both;
     const uint32_t rec_bytes = PAIR_BYTES, c_tiny = 0x0f800000u /* 2^-96 */, c_eps = 0x3a83126fu /* 0.001f */, c_cls = 0x260u /* +-0, +inf */;
     asm volatile(
+#if BRT_ASM_COUNT
+        "s_mov_b32 %[c_ie], 0\n s_mov_b32 %[c_il], 0\n s_mov_b32 %[c_le], 0\n s_mov_b32 %[c_ll], 0\n"
+#endif
         "s_waitcnt lgkmcnt(0)\n"                                // nothing of the compiler's in flight: the counted waits below are exact
         "s_mov_b64 %[s_all], exec\n"
         "v_add_u32_e32 %[below], -1, %[closest]\n"              // the largest float below closest (closest is FLT_MAX or an accepted t > 0)
@@ -627,6 +674,7 @@ BRT_DEV void walk_wave_lds_asm(uint32_t& cur, uint32_t& spa, float& closest, uin
         "1:\n"
         "s_mov_b64 %[s_take], vcc\n"
         "s_mov_b64 exec, vcc\n"
+        BRT_COUNT_INT
         "ds_read_i16 %[pop], %[spa]\n"                          // the would-be pop: needs no address arithmetic, goes out first
         "v_mul_lo_u32 %[t0], %[cur], %[rec_bytes]\n"
         "v_add_u32_e32 %[tx], %[t0], %[gofs_x]\n"
@@ -677,6 +725,7 @@ BRT_DEV void walk_wave_lds_asm(uint32_t& cur, uint32_t& spa, float& closest, uin
         "5:\n"
         "v_cmp_gt_i32_e32 vcc, -1, %[cur]\n"                    // leaf descriptors are < -1
         "s_and_b64 exec, %[s_all], vcc\n"
+        BRT_COUNT_LEAF
         "v_and_b32_e32 v112, 0x3fff, %[cur]\n"                  // the leaf's sphere
         "v_lshl_add_u32 %[t0], v112, 4, %[sph]\n"
         "ds_read_b128 v[100:103], %[t0]\n"                      // { centre, r^2 }
@@ -749,11 +798,19 @@ BRT_DEV void walk_wave_lds_asm(uint32_t& cur, uint32_t& spa, float& closest, uin
         : [cur] "+v"(cur), [spa] "+v"(spa), [closest] "+v"(closest), [cidx] "+v"(closest_idx), [below] "=&v"(below), [t0] "=&v"(t0),
           [tx] "=&v"(tx), [ty] "=&v"(ty), [tz] "=&v"(tz), [pop] "=&v"(pop), [cnt] "=&s"(cnt), [nw] "=&s"(nw), [thr] "=&s"(thr),
           [s_all] "=&s"(s_all), [s_take] "=&s"(s_take), [s_p2] "=&s"(s_p2), [s_any] "=&s"(s_any), [s_both] "=&s"(s_both)
+#if BRT_ASM_COUNT
+          , [c_ie] "=&s"(c_ie), [c_il] "=&s"(c_il), [c_le] "=&s"(c_le), [c_ll] "=&s"(c_ll), [c_tmp] "=&s"(c_tmp)
+#endif
         : [gofs_x] "v"(gofs_x), [gofs_y] "v"(gofs_y), [gofs_z] "v"(gofs_z), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [ix] "v"(inv.x),
           [iy] "v"(inv.y), [iz] "v"(inv.z), [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z), [a] "v"(a), [sph] "s"(sph), [exit_at] "s"(exit_at),
           [vote] "s"(vote), [rec_bytes] "s"(rec_bytes), [c_tiny] "s"(c_tiny), [c_eps] "s"(c_eps), [c_cls] "s"(c_cls)
         : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112",
           "v113");
+#if BRT_ASM_COUNT
+    if (first_active_lane()) { ac->int_exec += c_ie; ac->int_lanes += c_il; ac->leaf_exec += c_le; ac->leaf_lanes += c_ll; }
+#endif
+#undef BRT_COUNT_INT
+#undef BRT_COUNT_LEAF
 #endif
 }
 
@@ -764,13 +821,24 @@ BRT_DEV void walk_wave_lds_asm(uint32_t& cur, uint32_t& spa, float& closest, uin
 // per step: 1.03 G branches on the 10 004-sphere frame against 0.38 G on the cover frame.
 BRT_DEV void walk_wave_top_asm(uint32_t& cur, uint32_t& spa, float& closest, uint32_t& closest_idx, uint32_t gofs_x, uint32_t gofs_y,
                                uint32_t gofs_z, f3 o, f3 inv, f3 d, float a, uint32_t near_bytes, uint64_t far, uint64_t sphg,
-                               uint32_t exit_at, uint32_t vote) {
+                               uint32_t exit_at, uint32_t vote, AsmCounts* ac = nullptr) {
 #if BRT_HAND_ASM
+#if BRT_ASM_COUNT
+    uint32_t c_ie, c_il, c_le, c_ll, c_tmp;
+#define BRT_COUNT_INT "s_bcnt1_i32_b64 %[c_tmp], exec\n s_add_u32 %[c_il], %[c_il], %[c_tmp]\n s_add_u32 %[c_ie], %[c_ie], 1\n"
+#define BRT_COUNT_LEAF "s_bcnt1_i32_b64 %[c_tmp], exec\n s_add_u32 %[c_ll], %[c_ll], %[c_tmp]\n s_add_u32 %[c_le], %[c_le], 1\n"
+#else
+#define BRT_COUNT_INT
+#define BRT_COUNT_LEAF
+#endif
     uint32_t t0, tx, ty, tz, pop, cnt, nw, thr;
     float below;
     uint64_t s_all, s_take, s_p2, s_any, s_both;
     const uint32_t rec_bytes = PAIR_BYTES, c_tiny = 0x0f800000u /* 2^-96 */, c_eps = 0x3a83126fu /* 0.001f */, c_cls = 0x260u /* +-0, +inf */;
     asm volatile(
+#if BRT_ASM_COUNT
+        "s_mov_b32 %[c_ie], 0\n s_mov_b32 %[c_il], 0\n s_mov_b32 %[c_le], 0\n s_mov_b32 %[c_ll], 0\n"
+#endif
         "s_waitcnt lgkmcnt(0)\n"                                // nothing of the compiler's in flight: the counted waits below are exact
         "s_mov_b64 %[s_all], exec\n"
         "v_add_u32_e32 %[below], -1, %[closest]\n"              // the largest float below closest (closest is FLT_MAX or an accepted t > 0)
@@ -790,27 +858,19 @@ BRT_DEV void walk_wave_top_asm(uint32_t& cur, uint32_t& spa, float& closest, uin
         "1:\n"
         "s_mov_b64 %[s_take], vcc\n"
         "s_mov_b64 exec, vcc\n"
+        BRT_COUNT_INT
         "ds_read_i16 %[pop], %[spa]\n"                          // the would-be pop: needs no address arithmetic, goes out first
         "v_mul_lo_u32 %[t0], %[cur], %[rec_bytes]\n"
+        "v_cmp_le_u32_e32 vcc, %[near_bytes], %[t0]\n"          // lanes whose record is only in the global array (L2)
         "v_add_u32_e32 %[tx], %[t0], %[gofs_x]\n"
+        "s_cbranch_vccnz 8f\n"                                  // ... are rare once the records are numbered by their use (apply_hot_order):
+        "ds_read_b128 v[100:103], %[tx]\n"                      // the common step reads the tile only, behind ONE branch that is not taken
         "v_add_u32_e32 %[ty], %[t0], %[gofs_y]\n"
-        "v_add_u32_e32 %[tz], %[t0], %[gofs_z]\n"
-        "v_cmp_le_u32_e32 vcc, %[near_bytes], %[t0]\n"          // the record is only in the global array (L2): those loads go out first ...
-        "s_and_b64 exec, %[s_take], vcc\n"
-        "s_cbranch_execz 6f\n"
-        "global_load_dwordx4 v[100:103], %[tx], %[far]\n"       // { near L, near R, far L, far R } per axis
-        "global_load_dwordx4 v[104:107], %[ty], %[far]\n"
-        "global_load_dwordx4 v[108:111], %[tz], %[far]\n"
-        "global_load_dwordx2 v[112:113], %[t0], %[far] offset:96\n"   // descriptors of L and R
-        "6:\n"
-        "s_andn2_b64 exec, %[s_take], vcc\n"                    // ... or in the LDS tile (the top of the tree)
-        "s_cbranch_execz 7f\n"
-        "ds_read_b128 v[100:103], %[tx]\n"
         "ds_read_b128 v[104:107], %[ty]\n"
+        "v_add_u32_e32 %[tz], %[t0], %[gofs_z]\n"
         "ds_read_b128 v[108:111], %[tz]\n"
-        "ds_read_b64 v[112:113], %[t0] offset:96\n"
-        "7:\n"
-        "s_mov_b64 exec, %[s_take]\n"
+        "ds_read_b64 v[112:113], %[t0] offset:96\n"             // descriptors of L and R
+        "6:\n"
         // (counted waits that hold for every mix: the LDS queue is {pop, x, y, z, descriptors} or just {pop}, the vector-memory queue {x, y, z,
         //  descriptors} or empty -- a lane's x granule has arrived when at most 3 are outstanding in BOTH)
         "s_waitcnt vmcnt(3) lgkmcnt(3)\n"
@@ -854,6 +914,7 @@ BRT_DEV void walk_wave_top_asm(uint32_t& cur, uint32_t& spa, float& closest, uin
         "5:\n"
         "v_cmp_gt_i32_e32 vcc, -1, %[cur]\n"                    // leaf descriptors are < -1
         "s_and_b64 exec, %[s_all], vcc\n"
+        BRT_COUNT_LEAF
         "v_and_b32_e32 v112, 0x3fff, %[cur]\n"                  // the leaf's sphere
         "v_lshlrev_b32_e32 %[t0], 4, v112\n"
         "global_load_dwordx4 v[100:103], %[t0], %[sphg]\n"      // { centre, r^2 }
@@ -921,16 +982,42 @@ BRT_DEV void walk_wave_top_asm(uint32_t& cur, uint32_t& spa, float& closest, uin
         "s_mov_b64 exec, %[s_all]\n"
         "s_waitcnt lgkmcnt(0)\n"                                // the pop has long arrived; the next test reads it
         "s_branch 3b\n"
+        // ---- out of line: an interior step with lanes on both sides (two EXEC masks, one destination) ---------------------------
+        "8:\n"
+        "v_add_u32_e32 %[ty], %[t0], %[gofs_y]\n"
+        "v_add_u32_e32 %[tz], %[t0], %[gofs_z]\n"
+        "s_and_b64 exec, %[s_take], vcc\n"                      // the global loads go out first ...
+        "global_load_dwordx4 v[100:103], %[tx], %[far]\n"       // { near L, near R, far L, far R } per axis
+        "global_load_dwordx4 v[104:107], %[ty], %[far]\n"
+        "global_load_dwordx4 v[108:111], %[tz], %[far]\n"
+        "global_load_dwordx2 v[112:113], %[t0], %[far] offset:96\n"
+        "s_andn2_b64 exec, %[s_take], vcc\n"                    // ... then the lanes in the LDS tile
+        "s_cbranch_execz 7f\n"
+        "ds_read_b128 v[100:103], %[tx]\n"
+        "ds_read_b128 v[104:107], %[ty]\n"
+        "ds_read_b128 v[108:111], %[tz]\n"
+        "ds_read_b64 v[112:113], %[t0] offset:96\n"
+        "7:\n"
+        "s_mov_b64 exec, %[s_take]\n"
+        "s_branch 6b\n"
         "9:\n"
         "s_waitcnt lgkmcnt(0)\n"
         : [cur] "+v"(cur), [spa] "+v"(spa), [closest] "+v"(closest), [cidx] "+v"(closest_idx), [below] "=&v"(below), [t0] "=&v"(t0),
           [tx] "=&v"(tx), [ty] "=&v"(ty), [tz] "=&v"(tz), [pop] "=&v"(pop), [cnt] "=&s"(cnt), [nw] "=&s"(nw), [thr] "=&s"(thr),
           [s_all] "=&s"(s_all), [s_take] "=&s"(s_take), [s_p2] "=&s"(s_p2), [s_any] "=&s"(s_any), [s_both] "=&s"(s_both)
+#if BRT_ASM_COUNT
+          , [c_ie] "=&s"(c_ie), [c_il] "=&s"(c_il), [c_le] "=&s"(c_le), [c_ll] "=&s"(c_ll), [c_tmp] "=&s"(c_tmp)
+#endif
         : [gofs_x] "v"(gofs_x), [gofs_y] "v"(gofs_y), [gofs_z] "v"(gofs_z), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [ix] "v"(inv.x),
           [iy] "v"(inv.y), [iz] "v"(inv.z), [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z), [a] "v"(a), [near_bytes] "s"(near_bytes), [far] "s"(far), [sphg] "s"(sphg), [exit_at] "s"(exit_at),
           [vote] "s"(vote), [rec_bytes] "s"(rec_bytes), [c_tiny] "s"(c_tiny), [c_eps] "s"(c_eps), [c_cls] "s"(c_cls)
         : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112",
           "v113");
+#if BRT_ASM_COUNT
+    if (first_active_lane()) { ac->int_exec += c_ie; ac->int_lanes += c_il; ac->leaf_exec += c_le; ac->leaf_lanes += c_ll; }
+#endif
+#undef BRT_COUNT_INT
+#undef BRT_COUNT_LEAF
 #endif
 }
 
@@ -945,7 +1032,7 @@ BRT_DEV void walk_loop_wave_lds(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv
     // (the leaf step runs when at least `vote` of the lanes that walked at the last leaf step wait at a leaf -- walk_loop_wave
     //  counts the leaf lanes instead; the rules differ only when a lane ends its walk inside a run of interior steps, and only
     //  in when the leaf step runs)
-    walk_wave_lds_asm(cur, spa, closest, closest_idx, ox, oy, oz, o, inv, d, a, sph, exit_at, vote);
+    walk_wave_lds_asm(cur, spa, closest, closest_idx, ox, oy, oz, o, inv, d, a, sph, exit_at, vote, &hc.asm_counts);
     sp = (StackT*)reinterpret_cast<lds_stack*>((uintptr_t)spa);
 }
 
@@ -959,7 +1046,7 @@ BRT_DEV void walk_loop_wave_top(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv
     uint32_t spa = (uint32_t)(uintptr_t)(lds_stack*)sp;
     const uint32_t near_bytes = MODE == SCENE_LDS_TOP ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.near_bytes) : 0u;
     const uint64_t far = (uint64_t)(uintptr_t)sc.pairs_far, sphg = (uint64_t)(uintptr_t)sc.spheres;
-    walk_wave_top_asm(cur, spa, closest, closest_idx, ox, oy, oz, o, inv, d, a, near_bytes, far, sphg, exit_at, vote);
+    walk_wave_top_asm(cur, spa, closest, closest_idx, ox, oy, oz, o, inv, d, a, near_bytes, far, sphg, exit_at, vote, &hc.asm_counts);
     sp = (StackT*)reinterpret_cast<lds_stack*>((uintptr_t)spa);
 }
 

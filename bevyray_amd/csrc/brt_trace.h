@@ -345,7 +345,7 @@ BRT_DEV void shade_landed(const ScenePtrs& sc, const FrameParams& fp, bool lande
         unsigned long long t_ball = 0;
         if (COUNTERS) t_ball = wall_clock64();
         if (BRT_BALL_ASM && !COUNTERS) {
-            ball_loop_asm(ps.rng, acc, m1.x, __builtin_amdgcn_ballot_w64(diffuse), __builtin_amdgcn_ballot_w64(metal));
+            ball_loop_asm(ps.rng, acc, m1.x, __builtin_amdgcn_ballot_w64(diffuse), __builtin_amdgcn_ballot_w64(metal), &hc.asm_counts);
             need = 0u;
         }
         while (need != 0u) {                                                      // random.wgsl:19-24
@@ -884,6 +884,18 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     // ---- counters: one atomic per wave ----
     const uint32_t r = wave_sum(n_rays);
     if (lane == 0) atomicAdd(&counters[0], (unsigned long long)r);
+#if BRT_ASM_COUNT
+    if (!COUNTERS) {      // what the hand-written loops of this wave executed (each call booked by one lane: sum over the lanes)
+        const AsmCounts& c = hc.asm_counts;
+        const uint32_t v[8] = {wave_sum(c.int_exec), wave_sum(c.int_lanes), wave_sum(c.leaf_exec), wave_sum(c.leaf_lanes), wave_sum(c.ball_exec), wave_sum(c.ball_lanes),
+                               wave_sum(c.fix_int_lanes), wave_sum(c.fix_leaf_lanes)};
+        if (lane == 0) {            // (word 32 is the tile queue's counter)
+            for (int k = 0; k < 6; k++) atomicAdd(&counters[33 + k], (unsigned long long)v[k]);
+            atomicAdd(&counters[39], (unsigned long long)v[6]);
+            atomicAdd(&counters[43], (unsigned long long)v[7]);
+        }
+    }
+#endif
     if (COUNTERS) {
         const uint32_t a = wave_sum(hc.node_pops), b = wave_sum(hc.interior), c = wave_sum(hc.sphere_tests);
         if (lane == 0) {

@@ -411,6 +411,10 @@ class RaytracePlugin:
         """Lane-utilisation profile of the last FLAG_COUNTERS launch: section -> (executions, lanes)."""
         raw = (C.c_uint64 * 64)()
         _lib.check(self._lib.brt_debug_profile(self._ctx, raw), self._ctx)
+        self.last_raw = [int(x) for x in raw]
+        # -DBRT_ASM_COUNT builds: executions / active lanes of the hand-written loops of the last production launch (else zeros)
+        self.last_asm_counts = {"interior": (int(raw[33]), int(raw[34])), "leaf": (int(raw[35]), int(raw[36])), "ball": (int(raw[37]), int(raw[38])),
+                                "repairing_loop_lanes": (int(raw[39]), int(raw[43]))}
         names = ["interior", "leaf", "camera", "scatter", "sky", "ball", "camera_top", "round"]
         prof = {n: (int(raw[8 + 2 * k]), int(raw[9 + 2 * k])) for k, n in enumerate(names)}
         # wave time stamps (100 MHz wall clock): first start, first / last "pixel queue empty", last end
