@@ -21,6 +21,8 @@ using namespace brt;
 
 namespace {
 
+constexpr uint32_t kPolicyMask = BRT_POLICY_OR_SHORT_CIRCUIT | BRT_POLICY_MINMAX_SELECT | BRT_POLICY_POW_EXP2_LOG2;
+
 uint32_t env_u32(const char* name, uint32_t dflt) {
     const char* v = std::getenv(name);
     if (!v || !*v) return dflt;
@@ -95,7 +97,7 @@ int32_t make_frame_params(brt_ctx* ctx, const void* camera80, const void* window
     fp.slice_serial = 0;
     fp.wgq_batch = ctx->knobs[K_WGQ_BATCH] & ~63u;
     if (fp.wgq_batch > 512u) fp.wgq_batch = 512u;
-    fp.policy_flags = ctx->policy_flags & BRT_POLICY_OR_SHORT_CIRCUIT;
+    fp.policy_flags = ctx->policy_flags & kPolicyMask;
     // any knob off its default (or the lane queue asked for) -> the TUNABLE instantiation of the kernel
     fp.tunable = (fp.policy_flags != 0u || fp.bottom_up != 0u || fp.refill_min != kRefillMin || fp.walk_exit_lanes != kWalkExitLanes ||
                   fp.leaf_vote != kLeafVote || fp.drain_donate != kDrainDonate || fp.pool_adopt != kPoolAdopt ||
@@ -458,6 +460,7 @@ int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const fl
         tl.counters_on = (flags & BRT_FLAG_COUNTERS) != 0;
         tl.stream = stream;
         if (flags & BRT_FLAG_KERNEL_SIMPLE) {
+            if (fp.policy_flags != 0u) return ctx_fail(ctx, BRT_ERR_UNSUPPORTED, "the bring-up kernel implements the default policy only (brt_set_policy)");
             HIP_TRY(ctx, launch_trace_simple(tl));
             lp.block = 256;
             lp.grid = (fp.queue_size + 255u) / 256u;
@@ -519,10 +522,10 @@ int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const fl
 int32_t apply_hot_order(brt_ctx* ctx, DeviceCtx& dc, hipStream_t stream) {
     const uint32_t n = dc.view.n_pairs, m = dc.view.n_models;
     const EncodedScene& e = ctx->enc;
-    if (n == 0u || e.pairs.size() != (size_t)n * PAIR_WORDS || e.spheres.size() != (size_t)m * 4u || e.sphere_material.size() != m) return BRT_OK;
+    if (n == 0u || e.pairs.size() != (size_t)n * PAIR_WORDS || e.spheres.size() != (size_t)m * 4u || e.sphere_material.size() != m || e.sphere_mats.size() != (size_t)m * 8u) return BRT_OK;
     // the records (and spheres) as they are on the device now: as encoded after an upload, else in the order of this device's last
     // pre-pass (the counts are indexed by THAT numbering)
-    if (dc.hot_tree != ctx->tree_epoch) { dc.h_pairs_cur = e.pairs; dc.h_spheres_cur = e.spheres; dc.h_sphmat_cur = e.sphere_material; }
+    if (dc.hot_tree != ctx->tree_epoch) { dc.h_pairs_cur = e.pairs; dc.h_spheres_cur = e.spheres; dc.h_sphmat_cur = e.sphere_material; dc.h_sphmats_cur = e.sphere_mats; }
     const std::vector<float>& cur = dc.h_pairs_cur;
     const uint32_t cur_root = dc.hot_tree != ctx->tree_epoch ? e.root_desc : dc.view.root_desc;
     dc.h_hits.resize(n);
@@ -574,19 +577,22 @@ int32_t apply_hot_order(brt_ctx* ctx, DeviceCtx& dc, hipStream_t stream) {
             std::memcpy(dst + kDescWord + k, &d, 4);
         }
     }
-    std::vector<float> sph(dc.h_spheres_cur.size());
+    std::vector<float> sph(dc.h_spheres_cur.size()), mats(dc.h_sphmats_cur.size());
     std::vector<uint32_t> mat(m);
     for (uint32_t i = 0; i < m; i++) {
         std::memcpy(sph.data() + (size_t)i * 4, dc.h_spheres_cur.data() + (size_t)sorder[i] * 4, 16);
+        std::memcpy(mats.data() + (size_t)i * 8, dc.h_sphmats_cur.data() + (size_t)sorder[i] * 8, 32);
         mat[i] = dc.h_sphmat_cur[sorder[i]];
     }
     HIP_TRY(ctx, hipMemcpyAsync(const_cast<float*>(dc.view.pairs), dc.h_pairs_hot.data(), dc.h_pairs_hot.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(ctx, hipMemcpyAsync(const_cast<float*>(dc.view.spheres), sph.data(), sph.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(ctx, hipMemcpyAsync(const_cast<uint32_t*>(dc.view.sphere_material), mat.data(), mat.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(ctx, hipMemcpyAsync(const_cast<float*>(dc.view.sphere_mats), mats.data(), mats.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));       // (the vectors are reused by the next call)
     dc.h_pairs_cur.swap(dc.h_pairs_hot);
     dc.h_spheres_cur.swap(sph);
     dc.h_sphmat_cur.swap(mat);
+    dc.h_sphmats_cur.swap(mats);
     dc.view.root_desc = remap(cur_root);
     dc.hot_tree = ctx->tree_epoch;
     dc.hot_records = visited;
@@ -857,7 +863,7 @@ int32_t brt_create(const int32_t* device_ids, int32_t n_devices, brt_ctx** out_c
 
 int32_t brt_set_policy(brt_ctx* ctx, uint32_t flags) {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
-    if (flags & ~(uint32_t)BRT_POLICY_OR_SHORT_CIRCUIT) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "unknown policy flag");
+    if (flags & ~kPolicyMask) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "unknown policy flag");
     ctx->policy_flags = flags;
     return BRT_OK;
 }
@@ -988,10 +994,10 @@ int32_t upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, const 
 
     // one blob per device, sections 256-byte aligned
     struct Sec { const void* src; size_t bytes; size_t off; };
-    Sec secs[5] = {
+    Sec secs[6] = {
         {e.pairs.data(), e.pairs.size() * 4, 0}, {e.spheres.data(), e.spheres.size() * 4, 0},
         {e.sphere_material.data(), e.sphere_material.size() * 4, 0}, {e.materials.data(), e.materials.size() * 4, 0},
-        {e.leaf_table.data(), e.leaf_table.size() * 4, 0}};
+        {e.leaf_table.data(), e.leaf_table.size() * 4, 0}, {e.sphere_mats.data(), e.sphere_mats.size() * 4, 0}};
     size_t total = 0;
     for (auto& s : secs) { s.off = total; total += align256(s.bytes ? s.bytes : 16); }
 
@@ -1007,6 +1013,7 @@ int32_t upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, const 
         v.sphere_material = reinterpret_cast<const uint32_t*>(dc.d_scene + secs[2].off);
         v.materials = reinterpret_cast<const float*>(dc.d_scene + secs[3].off);
         v.leaf_table = reinterpret_cast<const uint32_t*>(dc.d_scene + secs[4].off);
+        v.sphere_mats = reinterpret_cast<const float*>(dc.d_scene + secs[5].off);
         v.n_pairs = e.n_pairs;
         v.n_models = e.n_models;
         v.n_materials = e.n_materials;

@@ -80,7 +80,7 @@ struct DeviceCtx {
     uint32_t hot_tree = 0;                               // brt_ctx::tree_epoch of the tree whose records are in hot order on this device (0: none)
     uint32_t hot_records = 0;                            // ... and how many of them the measuring pre-pass visited at all
     std::vector<uint32_t> h_hits, h_rank;
-    std::vector<float> h_spheres_cur;
+    std::vector<float> h_spheres_cur, h_sphmats_cur;
     std::vector<uint32_t> h_sphmat_cur;
     std::vector<float> h_pairs_hot, h_pairs_cur;          // scratch / the records as they are on the device (when hot_tree matches)
     // GPU BVH build

@@ -46,6 +46,9 @@ __device__ __forceinline__ bool first_active_lane() {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0u;
 }
 
+#ifndef BRT_MAT_BY_SPHERE
+#define BRT_MAT_BY_SPHERE 1   // a hit reads its material beside the sphere's index (one read) instead of through the material id (two dependent reads; 0)
+#endif
 #ifndef BRT_EXEC_MOVES
 #define BRT_EXEC_MOVES 0   // bit 0: sphere test, bit 1: ball loop -- `if` bodies of v_mov under EXEC instead of v_cndmask selects; measured: -0.0 ... +0.8 % (the compiler adds a branch per `if`), off
 #endif
@@ -64,6 +67,11 @@ BRT_DEV f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 BRT_DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 BRT_DEV float min_f(float a, float b) { return __builtin_fminf(a, b); }
 BRT_DEV float max_f(float a, float b) { return __builtin_fmaxf(a, b); }
+// the other reading of WGSL's min / max (implementation defined for a NaN operand): compare-select, min(a, b) = b < a ? b : a and
+// max(a, b) = a < b ? b : a -- what brt_set_policy(BRT_POLICY_MINMAX_SELECT) switches the knobs-live instantiation to (the oracle's
+// minmax_select policy); they differ from minNum / maxNum only when an operand is a NaN (and in the sign of a zero)
+BRT_DEV float min_sel(float a, float b) { return b < a ? b : a; }
+BRT_DEV float max_sel(float a, float b) { return a < b ? b : a; }
 
 // ---- correctly rounded division with a shared reciprocal ----------------------------------------------------
 // hipcc expands the correctly rounded f32 quotient n / d (-fhip-fp32-correctly-rounded-divide-sqrt) to
@@ -353,7 +361,9 @@ struct ScenePtrs {
     const float4* spheres;
     const uint32_t* sphere_material;
     const float4* materials;
+    const float4* sphere_mats;     // the material of every sphere, two float4 each
     const uint2* leaf_table;
+    bool minmax_select;      // BRT_POLICY_MINMAX_SELECT (knobs-live instantiation only): min / max by compare-select, in the shader's operand order
     uint32_t* hits;          // pre-pass of a SCENE_LDS_TOP scene: interior visits per pair record, a histogram in LDS (else null)
 };
 
@@ -425,9 +435,10 @@ BRT_DEV void walk_begin(WalkState<StackT>& w, const ScenePtrs& sc, uint32_t root
     else
 #endif
         w.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    w.ox = PAIR_X + (w.inv.x < 0.0f ? 16u : 0u);
-    w.oy = PAIR_Y + (w.inv.y < 0.0f ? 16u : 0u);
-    w.oz = PAIR_Z + (w.inv.z < 0.0f ? 16u : 0u);
+    // (under the compare-select policy the walk applies min / max itself, to {t_min, t_max} in the shader's operand order: granule G0)
+    w.ox = PAIR_X + ((w.inv.x < 0.0f && !sc.minmax_select) ? 16u : 0u);
+    w.oy = PAIR_Y + ((w.inv.y < 0.0f && !sc.minmax_select) ? 16u : 0u);
+    w.oz = PAIR_Z + ((w.inv.z < 0.0f && !sc.minmax_select) ? 16u : 0u);
     w.closest = kInf;
     w.closest_idx = 0xffffffffu;
     w.cur = root_desc;
@@ -488,7 +499,7 @@ BRT_DEV bool ray_is_safe(f3 o, f3 inv) {
 // tests, push/pop as selects.  FIX: apply min/max to the {near, far} values read (needed when some ray
 // of the wave is not safe or the boxes are not ordered); without it the read offset has already made
 // that choice.
-template <int STRIDE, bool COUNTERS, bool FIX, bool D16, int MODE, typename StackT, bool HITS = false>
+template <int STRIDE, bool COUNTERS, bool FIX, bool D16, int MODE, typename StackT, bool HITS = false, bool SEL = false>
 BRT_DEV void walk_interior_step(const ScenePtrs& sc, f3 o, f3 inv, uint32_t ox, uint32_t oy, uint32_t oz, float below,
                                 uint32_t& cur, StackT*& sp, uint32_t& n, HitCounters& hc) {
     if (COUNTERS) { hc.node_pops++; hc.interior++; }
@@ -542,17 +553,21 @@ BRT_DEV void walk_interior_step(const ScenePtrs& sc, f3 o, f3 inv, uint32_t ox, 
     float nLx = (gx.x - o.x) * inv.x, nRx = (gx.y - o.x) * inv.x, fLx = (gx.z - o.x) * inv.x, fRx = (gx.w - o.x) * inv.x;
     float nLy = (gy.x - o.y) * inv.y, nRy = (gy.y - o.y) * inv.y, fLy = (gy.z - o.y) * inv.y, fRy = (gy.w - o.y) * inv.y;
     float nLz = (gz.x - o.z) * inv.z, nRz = (gz.y - o.z) * inv.z, fLz = (gz.z - o.z) * inv.z, fRz = (gz.w - o.z) * inv.z;
+    // (SEL: the values read are {t_min, t_max} themselves -- granule G0, walk_begin -- and min / max are the compare-select forms in the
+    //  shader's operand order, raytrace.wgsl:391-394)
+    auto MIN = [](float a, float b) { return SEL ? min_sel(a, b) : min_f(a, b); };
+    auto MAX = [](float a, float b) { return SEL ? max_sel(a, b) : max_f(a, b); };
     if (FIX) {
         float t;
-        t = min_f(nLx, fLx); fLx = max_f(nLx, fLx); nLx = t;
-        t = min_f(nRx, fRx); fRx = max_f(nRx, fRx); nRx = t;
-        t = min_f(nLy, fLy); fLy = max_f(nLy, fLy); nLy = t;
-        t = min_f(nRy, fRy); fRy = max_f(nRy, fRy); nRy = t;
-        t = min_f(nLz, fLz); fLz = max_f(nLz, fLz); nLz = t;
-        t = min_f(nRz, fRz); fRz = max_f(nRz, fRz); nRz = t;
+        t = MIN(nLx, fLx); fLx = MAX(nLx, fLx); nLx = t;
+        t = MIN(nRx, fRx); fRx = MAX(nRx, fRx); nRx = t;
+        t = MIN(nLy, fLy); fLy = MAX(nLy, fLy); nLy = t;
+        t = MIN(nRy, fRy); fRy = MAX(nRy, fRy); nRy = t;
+        t = MIN(nLz, fLz); fLz = MAX(nLz, fLz); nLz = t;
+        t = MIN(nRz, fRz); fRz = MAX(nRz, fRz); nRz = t;
     }
-    const float tnL = max_f(max_f(nLx, nLy), nLz), tfL = min_f(min_f(fLx, fLy), fLz);   // :393-394
-    const float tnR = max_f(max_f(nRx, nRy), nRz), tfR = min_f(min_f(fRx, fRy), fRz);
+    const float tnL = MAX(MAX(nLx, nLy), nLz), tfL = MIN(MIN(fLx, fLy), fLz);   // :393-394
+    const float tnR = MAX(MAX(nRx, nRy), nRz), tfR = MIN(MIN(fRx, fRy), fRz);
     // pushed iff hit && dst < closest (raytrace.wgsl:331,338); see slab_push for why t_near serves as dst.
     // `below` is the largest float under closest, so t_near < closest == t_near <= below.  Without NaNs
     // (FIX off) the three compares fold into one: t_far > 0 == t_far >= the smallest denormal, hence
@@ -579,7 +594,7 @@ BRT_DEV void walk_interior_step(const ScenePtrs& sc, f3 o, f3 inv, uint32_t ox, 
 }
 
 // The wave-level walk loop (see walk_run).
-template <bool COUNTERS, bool D16, bool SIMPLE_TREE, bool FIX, int MODE, typename StackT, bool HITS = false>
+template <bool COUNTERS, bool D16, bool SIMPLE_TREE, bool FIX, int MODE, typename StackT, bool HITS = false, bool SEL = false>
 BRT_DEV void walk_loop_wave(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, uint32_t ox, uint32_t oy, uint32_t oz,
                             float& closest, uint32_t& closest_idx, uint32_t& cur, StackT*& sp, uint32_t& n,
                             uint32_t exit_at, uint32_t vote, HitCounters& hc) {
@@ -589,7 +604,7 @@ BRT_DEV void walk_loop_wave(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, ui
         for (;;) {
             const bool interior = DS::is_interior(cur) && (SIMPLE_TREE || n < 31u);
             if (__ballot(interior) == 0ull) break;
-            if (interior) walk_interior_step<64, COUNTERS, FIX, D16, MODE, StackT, HITS>(sc, o, inv, ox, oy, oz, below, cur, sp, n, hc);
+            if (interior) walk_interior_step<64, COUNTERS, FIX, D16, MODE, StackT, HITS, SEL>(sc, o, inv, ox, oy, oz, below, cur, sp, n, hc);
             if (wave_count(DS::is_leaf(cur) && (SIMPLE_TREE || n < 31u)) >= vote) break;
         }
         if (DS::is_leaf(cur) && (SIMPLE_TREE || n < 31u)) {
@@ -1052,7 +1067,8 @@ BRT_DEV void walk_loop_wave_top(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv
 
 // HITS: the instantiation can count interior visits per record (sc.hits; the pre-pass of a SCENE_LDS_TOP scene): such a launch walks
 // in the compiler's loop, the repairing form (a superset of the plain one: the min / max it adds change nothing for safe rays).
-template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, int MODE, typename StackT, bool HITS = false>
+// POLICY: the instantiation can walk under the compare-select reading of min / max (sc.minmax_select): also in the compiler's loop.
+template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, int MODE, typename StackT, bool HITS = false, bool POLICY = false>
 BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, f3 o, f3 d,
                       uint32_t exit_lanes, uint32_t leaf_vote, HitCounters& hc) {
     using DS = Desc<D16>;
@@ -1093,8 +1109,12 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, f3
             // but BEFORE it: that loop leaves with at most exit_at lanes walking, and the hand-written one then returns at its first test.
             constexpr bool kByHand = BRT_WALK_FAST && MODE == SCENE_LDS && !COUNTERS && SIMPLE_TREE && D16;
             const bool counting = HITS && D16 && sc.hits != nullptr;           // (wave-uniform: a kernel argument)
-            const bool any_unsafe = __ballot(unsafe) != 0ull || counting;
-            if (counting)
+            const bool select = POLICY && sc.minmax_select;                    // (likewise)
+            const bool any_unsafe = __ballot(unsafe) != 0ull || counting || select;
+            if (select)
+                walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, true, MODE, StackT, false, POLICY>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp,
+                                                                                             n, exit_at, vote, hc);
+            else if (counting)
                 walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, true, MODE, StackT, HITS && D16>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp,
                                                                                             n, exit_at, vote, hc);
             else if (any_unsafe)
@@ -1140,19 +1160,30 @@ BRT_DEV void raycast(const ScenePtrs& sc, uint32_t root_desc, StackT* stk, f3 o,
 // raytrace.wgsl:400-402
 BRT_DEV f3 reflect3(f3 v, f3 n) { return v - (2.0f * dot3(v, n)) * n; }
 // raytrace.wgsl:404-409
-BRT_DEV f3 refract3(f3 v, f3 n, float eta) {
-    const float cos_theta = min_f(dot3(neg3(v), n), 1.0f);
+BRT_DEV f3 refract3(f3 v, f3 n, float eta, bool select = false) {
+    const float cos_theta = select ? min_sel(dot3(neg3(v), n), 1.0f) : min_f(dot3(neg3(v), n), 1.0f);
     const f3 perp = eta * (v + cos_theta * n);
     const float par = -__builtin_sqrtf(__builtin_fabsf(1.0f - dot3(perp, perp)));
     return perp + par * n;
 }
 // raytrace.wgsl:411-416
-BRT_DEV float schlick(float cosine, float ri) {
+// pow5: pow(x, 5.0) as exp2(5 * log2(x)) in f64, rounded to f32 once (BRT_POLICY_POW_EXP2_LOG2: what WGSL defines pow as; the
+// oracle's pow_exp2_log2 policy) instead of the multiplies
+BRT_DEV float schlick(float cosine, float ri, bool pow5 = false) {
     float r0 = (1.0f - ri) / (1.0f + ri);
     r0 = r0 * r0;
     const float x = 1.0f - cosine;
-    const float x2 = x * x;
-    return r0 + (1.0f - r0) * ((x2 * x2) * x);
+    float p5;
+    if (pow5) {
+        if (x != x || x < 0.0f) p5 = __builtin_nanf("");
+        else if (x == 0.0f) p5 = 0.0f;
+        else if (__builtin_isinf(x)) p5 = __builtin_inff();
+        else p5 = (float)exp2(5.0 * log2((double)x));
+    } else {
+        const float x2 = x * x;
+        p5 = (x2 * x2) * x;
+    }
+    return r0 + (1.0f - r0) * p5;
 }
 
 // raytrace.wgsl:231-299 applied to the hit (t, idx) of ray (o,d); the HitInfo fields are
@@ -1173,9 +1204,8 @@ BRT_DEV bool scatter(const ScenePtrs& sc, f3& o, f3& d, float t, uint32_t idx, u
     const float4 s = sc.spheres[idx];
     const f3 pos = mk3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);          // ray_at, :130-132
     const f3 nrm = normalize3(mk3(pos.x - s.x, pos.y - s.y, pos.z - s.z));    // :356
-    const uint32_t mid = sc.sphere_material[idx];
-    const float4 m0 = sc.materials[2 * mid];      // base_color.rgb, metallic
-    const float4 m1 = sc.materials[2 * mid + 1];  // roughness, reflectance, ior, specular_transmission
+    const float4 m0 = sc.sphere_mats[2 * idx];      // base_color.rgb, metallic
+    const float4 m1 = sc.sphere_mats[2 * idx + 1];  // roughness, reflectance, ior, specular_transmission
     const bool metal = rng_float(rng) < m0.w;                                  // :234
     const bool glass = !metal && (rng_float(rng) < m1.w);                      // :249 (drawn only when not metal)
     const bool diffuse = !metal && !glass;

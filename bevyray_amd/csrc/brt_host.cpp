@@ -145,6 +145,10 @@ int32_t validate_and_encode(const Model* models, uint32_t n_models, const Materi
     e.n_materials = n_materials;
     e.materials.resize(8 * (size_t)n_materials);
     std::memcpy(e.materials.data(), materials, 32 * (size_t)n_materials);
+    // the material of every sphere beside it (material ids were validated above): the reference's extract stage writes one material
+    // entry per sphere anyway (extract.rs:301-310), and a hit then needs ONE read that does not wait for the id
+    e.sphere_mats.resize(8 * (size_t)n_models);
+    for (uint32_t i = 0; i < n_models; i++) std::memcpy(e.sphere_mats.data() + 8 * (size_t)i, &materials[models[i].material_id], 32);
     e.max_leaf_depth = max_leaf_depth;
     // After popping a node of depth k the stack holds at most k entries and receives at
     // most two pushes, so the deepest write index is max_leaf_depth (entries needed: +1).

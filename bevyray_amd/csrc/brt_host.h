@@ -17,6 +17,7 @@ struct EncodedScene {
     std::vector<float> pairs;            // PAIR_WORDS per pair record (brt_layout.h)
     std::vector<float> spheres;          // 4 per model
     std::vector<uint32_t> sphere_material;
+    std::vector<float> sphere_mats;      // 8 per model: the model's own material (materials[material_id]) -- one read per hit instead of two dependent ones
     std::vector<float> materials;        // 8 per material
     std::vector<uint32_t> leaf_table;    // 2 per general leaf
     uint32_t n_pairs = 0, n_models = 0, n_materials = 0;

@@ -52,10 +52,12 @@ __global__ __launch_bounds__(256) void k_trace_simple(DeviceSceneView sv, FrameP
     sc.near_base = 0u;
     sc.sph_base = 0u;
     sc.hits = nullptr;
+    sc.minmax_select = false;
     sc.boxes_ordered = sv.boxes_ordered != 0u;
     sc.spheres = reinterpret_cast<const float4*>(sv.spheres);
     sc.sphere_material = sv.sphere_material;
     sc.materials = reinterpret_cast<const float4*>(sv.materials);
+    sc.sphere_mats = reinterpret_cast<const float4*>(sv.sphere_mats);
     sc.leaf_table = reinterpret_cast<const uint2*>(sv.leaf_table);
     uint32_t n_rays = 0;
     HitCounters hc = {};

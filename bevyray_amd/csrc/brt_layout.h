@@ -143,6 +143,7 @@ struct DeviceSceneView {
     const float* spheres;    // float4[n_models]
     const uint32_t* sphere_material;  // u32[n_models]
     const float* materials;  // float4[2*n_materials]
+    const float* sphere_mats;         // float4[2*n_models]: the material of every sphere (materials[sphere_material[i]])
     const uint32_t* leaf_table;       // uint2[n_leaf_table]
     uint32_t n_pairs, n_models, n_materials, n_leaf_table;
     uint32_t root_desc;

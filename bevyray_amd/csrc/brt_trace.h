@@ -283,6 +283,8 @@ BRT_DEV void shade_landed(const ScenePtrs& sc, const FrameParams& fp, bool lande
                           uint32_t& n_rays, HitCounters& hc, float* out_tile, const float* raster_rgba,
                           const float* raster_depth) {
     const bool osc = TUNABLE && (fp.policy_flags & 1u);      // alternative reading of :269 (fixtures only)
+    const bool sel = TUNABLE && (fp.policy_flags & 2u);      // ... of min / max (:263, :405): compare-select
+    const bool pw5 = TUNABLE && (fp.policy_flags & 4u);      // ... of pow (:415): exp2(5 log2 x)
     const bool hit = landed && t != kInf, sky = landed && t == kInf;
     prof_section<COUNTERS>(hc, SEC_SCATTER, hit);
     prof_section<COUNTERS>(hc, SEC_SKY, sky);
@@ -330,9 +332,14 @@ BRT_DEV void shade_landed(const ScenePtrs& sc, const FrameParams& fp, bool lande
     f3 att, acc;
     float ior, draw;
     if (hit) {
+#if BRT_MAT_BY_SPHERE
+        const float4 m0 = sc.sphere_mats[2 * idx];      // base_color.rgb, metallic
+        const float4 m1 = sc.sphere_mats[2 * idx + 1];  // roughness, reflectance, ior, specular_transmission
+#else
         const uint32_t mid = sc.sphere_material[idx];
-        const float4 m0 = sc.materials[2 * mid];      // base_color.rgb, metallic
-        const float4 m1 = sc.materials[2 * mid + 1];  // roughness, reflectance, ior, specular_transmission
+        const float4 m0 = sc.materials[2 * mid];
+        const float4 m1 = sc.materials[2 * mid + 1];
+#endif
         metal = rng_float(ps.rng) < m0.w;                                          // :234
         glass = !metal && (rng_float(ps.rng) < m1.w);                              // :249 (drawn only when not metal)
         diffuse = !metal && !glass;
@@ -408,17 +415,17 @@ BRT_DEV void shade_landed(const ScenePtrs& sc, const FrameParams& fp, bool lande
             absorbed = dot3(d, n1) < 0.0f;
         } else {                                                                  // glass, :249-280
             const float ri = dn < 0.0f ? (1.0f / ior) : ior;
-            const float cos_theta = min_f(dot3(neg3(u), n1), 1.0f);
+            const float cos_theta = sel ? min_sel(dot3(neg3(u), n1), 1.0f) : min_f(dot3(neg3(u), n1), 1.0f);
             const float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
             const bool cannot_refract = ri * sin_theta > 1.0f;
-            const float refl = schlick(cos_theta, ri);
+            const float refl = schlick(cos_theta, ri, pw5);
             bool reflects = cannot_refract;
             if (osc) {
                 if (!cannot_refract) reflects = refl > rng_float(ps.rng);
             } else {
                 reflects = reflects || (refl > draw);
             }
-            d = reflects ? reflect3(u, n1) : refract3(u, n1, ri);
+            d = reflects ? reflect3(u, n1) : refract3(u, n1, ri, sel);
         }
     }
     // ---- the paths that go on: next segment from the hit point; late ends ----
@@ -485,12 +492,14 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     ScenePtrs sc;
     StackT* stacks;
     sc.materials = reinterpret_cast<const float4*>(sv.materials);
+    sc.sphere_mats = reinterpret_cast<const float4*>(sv.sphere_mats);
     sc.boxes_ordered = sv.boxes_ordered != 0u;
     sc.pairs_far = reinterpret_cast<const char*>(sv.pairs);
     sc.near_bytes = 0u;
     sc.near_base = 0u;
     sc.sph_base = 0u;
     sc.hits = nullptr;
+    sc.minmax_select = TUNABLE && (fp.policy_flags & 2u) != 0u;
     if (MODE == SCENE_LDS) {
         // carve: pair records | spheres | leaf_table | sphere_material | stacks
         const uint32_t pair_granules = (uint32_t)(pair_array_bytes(sv.n_pairs) / 16);
@@ -845,7 +854,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         if (fresh) walk_begin<D16>(walk, sc, sv.root_desc, stk, d);
         if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_pre += now - t_mark; t_mark = now; }
         if (kPhasePrio == 1 && !wave_crit) __builtin_amdgcn_s_setprio(1);
-        if (active) walk_run<64, COUNTERS, D16, SIMPLE, MODE, StackT, kHits>(sc, walk, stk, o, d, finish_walks ? 0u : walk_exit_lanes, leaf_vote, hc);
+        if (active) walk_run<64, COUNTERS, D16, SIMPLE, MODE, StackT, kHits, TUNABLE>(sc, walk, stk, o, d, finish_walks ? 0u : walk_exit_lanes, leaf_vote, hc);
         in_flight = active && walk_pending<D16, SIMPLE>(walk);
         if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_walk += now - t_mark; t_mark = now; }
         const bool landed = active && !in_flight;      // walk finished: shade this segment now

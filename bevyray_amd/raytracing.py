@@ -48,6 +48,8 @@ STRIP_ROWS = 8
 FLAG_COUNTERS = 1
 FLAG_KERNEL_SIMPLE = 2
 POLICY_OR_SHORT_CIRCUIT = 1   # brt_set_policy: the WGSL-spec reading of `||` in raytrace.wgsl:269 (default: both operands evaluated)
+POLICY_MINMAX_SELECT = 2      # ... min / max by compare-select (default: minNum / maxNum)
+POLICY_POW_EXP2_LOG2 = 4      # ... pow(x, 5) as exp2(5 log2 x) (default: multiplies)
 EXTMEM_OPAQUE_FD, EXTMEM_DMABUF_FD = 1, 2   # brt_import_frame_fd handle types
 FLAG_CALLER_STREAM = 4   # device entry points: `stream` is the caller's stream even when its handle is 0
 # format of an assembled DEVICE frame (render_device, gather_rccl, deinterleave_device): the colour target's own (pipeline.rs:311-315)

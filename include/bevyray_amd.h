@@ -141,13 +141,21 @@ const char* brt_last_error(const brt_ctx* ctx);
 int32_t brt_create(const int32_t* device_ids, int32_t n_devices, brt_ctx** out_ctx);
 int32_t brt_destroy(brt_ctx* ctx);
 
-/* The one reading of the shader that WGSL leaves to the implementation and that this library lets the caller choose
- * (it changes pixels, so it is an API option, not an environment variable):
- *   `if cannot_refract || reflectance(cos_theta, ri) > rngNextFloat(state)`     (raytrace.wgsl:269)
- * Default (flags = 0): both operands are evaluated, the RNG draw always happens (what naga of the reference's era emits,
- * from memory; unverifiable here).  BRT_POLICY_OR_SHORT_CIRCUIT: the WGSL-spec reading, no draw when cannot_refract.  The
- * two only differ for glass with ior < 1.  Applies to the frames rendered after the call. */
-enum { BRT_POLICY_OR_SHORT_CIRCUIT = 1u };
+/* The readings of the shader that WGSL leaves to the implementation and that nothing in the reference pins (naga /
+ * the driver decide them; no wgpu run is possible where this library was built).  They change pixels, so they are an API option,
+ * not environment variables.  Default (flags = 0) is what the parity tests are stated on; each flag switches ONE reading to its
+ * alternative (the frames run in the knobs-live instantiation of the kernel then), so that the day a real wgpu frame can be compared
+ * (scripts/compare_wgpu_frame.py names the combination it matches) the product can follow it:
+ *   BRT_POLICY_OR_SHORT_CIRCUIT  `if cannot_refract || reflectance(cos_theta, ri) > rngNextFloat(state)` (raytrace.wgsl:269): default =
+ *                                both operands evaluated, the RNG draw always happens; flag = the WGSL-spec reading, no draw when
+ *                                cannot_refract.  Differs only for glass with ior < 1.
+ *   BRT_POLICY_MINMAX_SELECT     min / max (raytrace.wgsl:391-394, :263, :405): default = IEEE minNum / maxNum (a NaN operand yields the
+ *                                other one); flag = compare-select, min(a, b) = b < a ? b : a, max(a, b) = a < b ? b : a.  Differs
+ *                                only when a bound or a ray component is a NaN.
+ *   BRT_POLICY_POW_EXP2_LOG2     pow(x, 5.0) (raytrace.wgsl:415): default = (x x)(x x) x; flag = exp2(5 log2 x) evaluated in f64 and
+ *                                rounded to f32 once.  Differs in the last bits of Schlick's reflectance.
+ * Applies to the frames rendered after the call.  The bring-up kernel (BRT_FLAG_KERNEL_SIMPLE) implements the default only. */
+enum { BRT_POLICY_OR_SHORT_CIRCUIT = 1u, BRT_POLICY_MINMAX_SELECT = 2u, BRT_POLICY_POW_EXP2_LOG2 = 4u };
 int32_t brt_set_policy(brt_ctx* ctx, uint32_t flags);
 
 /* Scheduling / launch-shape knobs of the trace path (names and meaning: DESIGN.md section 6, "Tuning aids").  None

@@ -1321,7 +1321,53 @@ def _short_circuit_policy_case(plugin, oracle, monkeypatch):
     plugin.set_policy(0)
     assert_frames_equal(plugin.node.run(lvl, cam, win, w, h, buffers=b), g("frame.default"))
     with pytest.raises(brt.BrtError):
-        plugin.set_policy(2)
+        plugin.set_policy(8)
+
+
+def test_every_policy_switch_matches_the_fixtures_and_the_oracle_under_that_policy(oracle):
+    """VERDICT r4, What's missing #4: the oracle has three switches for the readings WGSL leaves open (`||`, min / max with a NaN, pow);
+    the product had one.  brt_set_policy now takes all three (and their combinations): on every policy fixture
+    (tests/golden/policy_frames.npz: frames of the independent numpy restatement under each policy -- glass with ior < 1, NaN bounds,
+    grazing glass) the GPU frame equals the committed frame and the oracle's frame + counters under the same policy, through the
+    LDS-resident walk, the tile + global walk and the all-global walk.  The default stays what the parity suite is stated on."""
+    z = np.load(os.path.join(GOLDEN, "policy_frames.npz"))
+    names = sorted({k.split(".")[0] for k in z.files})
+    pols = {"default": (0, {}), "or_short_circuit": (brt.POLICY_OR_SHORT_CIRCUIT, dict(or_short_circuit=True)),
+            "minmax_select": (brt.POLICY_MINMAX_SELECT, dict(minmax="select")), "pow_exp2log2": (brt.POLICY_POW_EXP2_LOG2, dict(pow="exp2log2")),
+            "all_three": (7, dict(or_short_circuit=True, minmax="select", pow="exp2log2"))}
+    moved = {k: 0 for k in pols}
+    with brt.RaytracePlugin([0]) as p:
+        for knobs in ({}, {"BRT_FORCE_LDS_TOP": 3}, {"BRT_FORCE_GLOBAL_SCENE": 1}):
+            for k in ("BRT_FORCE_LDS_TOP", "BRT_FORCE_GLOBAL_SCENE"):
+                p.set_tuning(k, knobs.get(k, 0))
+            for name in names:
+                g = lambda k: z[f"{name}.{k}"]
+                b = brt.Buffers(g("models").view(brt.MODEL_DTYPE), g("materials").view(brt.MATERIAL_DTYPE), g("bvh").view(brt.BVH_NODE_DTYPE))
+                lvl, cam, win = g("level").view(brt.LEVEL_DTYPE), g("camera").view(brt.CAMERA_DTYPE), g("window").view(brt.WINDOW_DTYPE)
+                w, h = (int(x) for x in g("size"))
+                for pname, (flags, okw) in pols.items():
+                    p.set_policy(flags)
+                    for fl in (brt.FLAG_COUNTERS, 0):
+                        got = p.node.run(lvl, cam, win, w, h, buffers=b, flags=fl)
+                        st = dict(p.node.last_stats)
+                        assert_frames_equal(got, g(f"frame.{pname}"))
+                        assert st["rays"] == int(g(f"rays.{pname}")[0]), (name, pname)
+                        with oracle.policy(**okw):
+                            want, cnt = oracle.render(b, lvl, cam, win, w, h)
+                        assert_frames_equal(got, want)
+                        if fl:
+                            assert {q: st[q] for q in COUNTER_KEYS} == cnt, (name, pname, knobs)
+                    same = (g(f"frame.{pname}").view(np.uint32) == g("frame.default").view(np.uint32)) | (np.isnan(g(f"frame.{pname}")) & np.isnan(g("frame.default")))
+                    moved[pname] += int((~same).sum())
+        p.set_policy(0)
+        # the bring-up kernel implements the default reading only and says so
+        p.set_policy(brt.POLICY_MINMAX_SELECT)
+        with pytest.raises(brt.BrtError):
+            p.node.run(lvl, cam, win, w, h, flags=brt.FLAG_KERNEL_SIMPLE)
+        p.set_policy(0)
+    # the `||` and the min / max switches do change pixels of their fixtures (pow only moves the last bits of a reflectance, which
+    # rarely flips a reflect / refract decision at this size)
+    assert moved["default"] == 0 and moved["or_short_circuit"] > 0 and moved["minmax_select"] > 0 and moved["all_three"] > 0, moved
 
 
 def test_first_frame_prepass_orders_tiles_without_changing_pixels(oracle, monkeypatch):
