@@ -92,7 +92,9 @@ def random_case(rng):
     w, h = (int(rng.integers(1, 40)), int(rng.integers(1, 30))) if big else (int(rng.integers(1, 90)), int(rng.integers(1, 60)))
     if rng.random() < 0.1:
         h = int(rng.integers(60, 200))    # enough 8-row strips for every part of an 8-way split
-    spp = int(rng.choice([0, 1, 2, 3, 5, 9, 33], p=[0.03, 0.3, 0.25, 0.2, 0.12, 0.07, 0.03]))
+    # (32+ samples: the first frame of a view runs a pre-pass, which for a scene walked from an LDS tile + L2 also re-numbers the tree's
+    #  records by their use -- brt_api.cpp apply_hot_order)
+    spp = int(rng.choice([0, 1, 2, 3, 5, 9, 33, 64], p=[0.03, 0.29, 0.24, 0.19, 0.11, 0.06, 0.05, 0.03]))
     bounces = int(rng.choice([0, 1, 3, 8, 20, 70], p=[0.1, 0.15, 0.3, 0.3, 0.1, 0.05]))
     per_ray = n if topo in (1, 3, 4) else 40          # sphere/box tests per ray, roughly
     while w * h * max(spp, 1) * (bounces + 1) * per_ray > 2e8 and w * h > 1:   # keep the oracle under about a second
@@ -196,7 +198,7 @@ def main():
     rng = np.random.default_rng(args.seed)
     t_start = time.time()
     fails, done, pixels, rays, ploc_checked, rejected, tight_checked, split_checked, prod_checked = 0, 0, 0, 0, 0, 0, 0, 0, 0
-    reach_checked, ref_marginal = 0, 0
+    reach_checked, ref_marginal, hot_checked = 0, 0, 0
     lines = []
     t_progress = time.time()
     for case in range(args.cases):
@@ -268,6 +270,7 @@ def main():
                         raise AssertionError(f"production instantiation: {bad} of {got2.size} frame values differ, rays {st2['rays']} vs {cnt['rays']}")
                 prod_checked += 1
                 split_checked += 1 if "BRT_SPLIT_FORCE" in variant else 0
+                hot_checked += 1 if st2.get("hot_records", 0) else 0
             # the callee's SAH tree pads its leaf boxes by less than the reference's 0.1 (brt_sah.h sah_model_pad): on well-conditioned scenes
             # without coincident spheres (exact ties are decided by the visiting order) the frame must also be the one of the caller's
             # 0.1-padded PLOC tree -- i.e. the tighter boxes culled nothing a ray is accepted by.  Well-conditioned = no sphere of radius
@@ -312,7 +315,7 @@ def main():
                      window=np.asarray(c["window"]).view(np.uint8), size=np.array([c["w"], c["h"]]),
                      raster=np.zeros(0) if c["raster"] is None else c["raster"], depth=np.zeros(0) if c["depth"] is None else c["depth"])
     summary = (f"fuzz_parity seed {args.seed}: {done} cases bit-exact (frames + 5 counters), {fails} failed, {rejected} refused; "
-               f"{pixels} pixels, {rays} rays; {ploc_checked} callee-built trees byte-identical CPU vs GPU, {tight_checked} tight-box SAH frames equal to the PLOC-tree frame ({ref_marginal} skipped: the reference's own tree differs from brute force there), {reach_checked} frames in a tree rebuilt for a far camera, {prod_checked} cases also in the production instantiation (frame + rays), {split_checked} of them through half-sample jobs; "
+               f"{pixels} pixels, {rays} rays; {ploc_checked} callee-built trees byte-identical CPU vs GPU, {tight_checked} tight-box SAH frames equal to the PLOC-tree frame ({ref_marginal} skipped: the reference's own tree differs from brute force there), {reach_checked} frames in a tree rebuilt for a far camera, {hot_checked} with the tree's records numbered by use, {prod_checked} cases also in the production instantiation (frame + rays), {split_checked} of them through half-sample jobs; "
                f"{time.time() - t_start:.0f} s")
     print(summary, flush=True)
     if args.log:
