@@ -257,6 +257,25 @@ void view_key_of(const brt_ctx* ctx, const FrameParams& fp, uint32_t key[8]) {
 // How far, in 8-pixel tiles, the picture has moved since the costs were measured: the angle between the two viewing directions
 // and a translation as seen at the distance of the scene's centre, in pixels of this frame, plus one tile.
 constexpr uint32_t kMaxDilate = 8;      // beyond this the old costs say nothing about the new view: a first frame again (pre-pass)
+// how far, in pixels of this frame, the picture has moved between a remembered camera and this frame's (NaN-safe: "very far")
+double camera_motion_px(const brt_ctx* ctx, const float* pos0, const float* dir0, const FrameParams& fp) {
+    const float* a = dir0;
+    const float* b = fp.cam_dir;
+    const double la = std::sqrt((double)a[0] * a[0] + (double)a[1] * a[1] + (double)a[2] * a[2]);
+    const double lb = std::sqrt((double)b[0] * b[0] + (double)b[1] * b[1] + (double)b[2] * b[2]);
+    double c = ((double)a[0] * b[0] + (double)a[1] * b[1] + (double)a[2] * b[2]) / (la * lb);
+    if (!(c == c)) return 1e30;
+    c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+    const double px_per_rad = 0.5 * (double)fp.height / (double)fp.tan_half_fov;
+    double dp = 0.0, dist = 0.0;
+    for (int k = 0; k < 3; k++) {
+        dp += ((double)fp.cam_pos[k] - pos0[k]) * ((double)fp.cam_pos[k] - pos0[k]);
+        dist += ((double)fp.cam_pos[k] - ctx->scene_centre[k]) * ((double)fp.cam_pos[k] - ctx->scene_centre[k]);
+    }
+    const double rot_px = std::acos(c) * px_per_rad, trans_px = std::sqrt(dp) / std::max(std::sqrt(dist), 1e-3) * px_per_rad;
+    const double px = std::max(rot_px, trans_px);
+    return px == px ? px : 1e30;
+}
 uint32_t dilation_tiles(const brt_ctx* ctx, const DeviceCtx& dc, const FrameParams& fp) {
     const float* a = dc.cost_cam_dir;
     const float* b = fp.cam_dir;
@@ -616,8 +635,20 @@ int32_t prepass_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const 
     if (k == 0u || (k == 1u && knob != 1u) || !lpt_enabled(ctx) || fp.level == 0u || (flags & BRT_FLAG_KERNEL_SIMPLE)) return BRT_OK;
     uint32_t key[6];
     order_key_of(ctx, fp, key);
+    // the records of a scene walked from an LDS tile were numbered for another view: once the picture has moved a quarter of the
+    // frame's height since they were counted (a tile that holds another view's records serves fewer visits than the breadth-first one
+    // would), this frame is a first frame again -- a pre-pass of ~2 ms every dozen frames of a steady orbit
+    bool hot_stale = ctx->knobs[K_HOT_RECORDS] != 0u && dc.hot_tree == ctx->tree_epoch && dc.hot_records != 0u &&
+                     camera_motion_px(ctx, dc.hot_cam_pos, dc.hot_cam_dir, fp) > std::max(64.0, 0.25 * (double)fp.height);
+    // ... or were never numbered for this tree although the scene has stood still for two frames (an upload of a scene with the same
+    // number of spheres keeps the dispatch order and runs no pre-pass -- right for a scene that is re-uploaded every frame, whose
+    // tree changes under any count; a scene that then stays gets its records counted on its second frame)
+    if (dc.frames_since_upload < 1000u) dc.frames_since_upload++;
+    if (!hot_stale && ctx->knobs[K_HOT_RECORDS] != 0u && dc.hot_tree != ctx->tree_epoch && dc.frames_since_upload == 2u && dc.view.desc16 &&
+        dc.view.simple_tree && dc.view.n_pairs > 64u && plan_launch(ctx->knobs, dc, fp).scene_mode == SCENE_LDS_TOP)
+        hot_stale = true;
     // history matches and the camera has not jumped out of its reach: nothing to do
-    if (dc.order_valid && std::memcmp(key, dc.order_key, sizeof key) == 0 && !(ctx->knobs[K_LPT_DILATE] != 0u && camera_jumped(ctx, dc, fp)))
+    if (dc.order_valid && std::memcmp(key, dc.order_key, sizeof key) == 0 && !(ctx->knobs[K_LPT_DILATE] != 0u && camera_jumped(ctx, dc, fp)) && !hot_stale)
         return BRT_OK;
     FrameParams pp = fp;
     pp.sample_count = k;
@@ -656,6 +687,7 @@ int32_t prepass_order(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const 
     if (count_hits) {
         rc = apply_hot_order(ctx, dc, stream);
         if (rc != BRT_OK) return rc;
+        for (int q = 0; q < 3; q++) { dc.hot_cam_pos[q] = fp.cam_pos[q]; dc.hot_cam_dir[q] = fp.cam_dir[q]; }
     }
     dc.remeasure_in = 1u;                             // the frame that follows measures again, at full sample count
     *ran = true;
@@ -1025,6 +1057,7 @@ int32_t upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, const 
         v.boxes_ordered = e.boxes_ordered ? 1u : 0u;
         dc.view = v;
         dc.hot_records = 0u;
+        dc.frames_since_upload = 0u;
     }
     ctx->tree_epoch++;          // (the records on the devices are in breadth-first order again: DeviceCtx::hot_tree no longer matches)
     for (auto& dc : ctx->devs) {

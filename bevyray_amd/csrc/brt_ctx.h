@@ -79,6 +79,8 @@ struct DeviceCtx {
     size_t record_hits_cap = 0;
     uint32_t hot_tree = 0;                               // brt_ctx::tree_epoch of the tree whose records are in hot order on this device (0: none)
     uint32_t hot_records = 0;                            // ... and how many of them the measuring pre-pass visited at all
+    float hot_cam_pos[3] = {0, 0, 0}, hot_cam_dir[3] = {0, 0, 1};   // the camera they were counted with
+    uint32_t frames_since_upload = 0;                    // frames this device has rendered since the last scene upload / tree rebuild
     std::vector<uint32_t> h_hits, h_rank;
     std::vector<float> h_spheres_cur, h_sphmats_cur;
     std::vector<uint32_t> h_sphmat_cur;

@@ -281,7 +281,7 @@ size_t trace_lds_bytes(const DeviceSceneView& sv, int scene_mode, uint32_t block
     size_t bytes = 0;
     if (scene_mode == SCENE_LDS) {
         bytes += pair_array_bytes(sv.n_pairs) + (size_t)sv.n_models * 16;
-        bytes += (size_t)sv.n_leaf_table * 8 + (size_t)sv.n_models * 4;
+        bytes += (size_t)sv.n_leaf_table * 8 + (BRT_MAT_BY_SPHERE ? 0 : (size_t)sv.n_models * 4);   // (material ids only when a hit still goes through them)
     } else if (scene_mode == SCENE_LDS_TOP) {
         bytes += pair_array_bytes(sv.lds_pairs);
     }

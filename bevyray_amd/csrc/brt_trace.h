@@ -501,7 +501,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     sc.hits = nullptr;
     sc.minmax_select = TUNABLE && (fp.policy_flags & 2u) != 0u;
     if (MODE == SCENE_LDS) {
-        // carve: pair records | spheres | leaf_table | sphere_material | stacks
+        // carve: pair records | spheres | leaf_table | (material ids, when a hit still goes through them) | stacks
         const uint32_t pair_granules = (uint32_t)(pair_array_bytes(sv.n_pairs) / 16);
         float4* p = reinterpret_cast<float4*>(smem);
         float4* l_pairs = p; p += pair_granules;
@@ -509,18 +509,18 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         uint2* p2 = reinterpret_cast<uint2*>(p);
         uint2* l_lt = p2; p2 += sv.n_leaf_table;
         uint32_t* p1 = reinterpret_cast<uint32_t*>(p2);
-        uint32_t* l_sm = p1; p1 += sv.n_models;
+        uint32_t* l_sm = p1; p1 += BRT_MAT_BY_SPHERE ? 0u : sv.n_models;
         stacks = reinterpret_cast<StackT*>(p1);
         const float4* g_pairs = reinterpret_cast<const float4*>(sv.pairs);
         const float4* g_sp = reinterpret_cast<const float4*>(sv.spheres);
         const uint2* g_lt = reinterpret_cast<const uint2*>(sv.leaf_table);
         for (uint32_t i = threadIdx.x; i < pair_granules; i += blockDim.x) l_pairs[i] = g_pairs[i];
-        for (uint32_t i = threadIdx.x; i < sv.n_models; i += blockDim.x) { l_sp[i] = g_sp[i]; l_sm[i] = sv.sphere_material[i]; }
+        for (uint32_t i = threadIdx.x; i < sv.n_models; i += blockDim.x) { l_sp[i] = g_sp[i]; if (!BRT_MAT_BY_SPHERE) l_sm[i] = sv.sphere_material[i]; }
         for (uint32_t i = threadIdx.x; i < sv.n_leaf_table; i += blockDim.x) l_lt[i] = g_lt[i];
         sc.pairs = reinterpret_cast<const char*>(l_pairs);
         sc.near_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(l_pairs);   // LDS byte address (walk_loop_wave_lds)
         sc.sph_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(l_sp);
-        sc.spheres = l_sp; sc.sphere_material = l_sm; sc.leaf_table = l_lt;
+        sc.spheres = l_sp; sc.sphere_material = BRT_MAT_BY_SPHERE ? sv.sphere_material : l_sm; sc.leaf_table = l_lt;
     } else {
         sc.spheres = reinterpret_cast<const float4*>(sv.spheres);
         sc.sphere_material = sv.sphere_material;

@@ -746,6 +746,23 @@ def test_records_numbered_by_visits_same_pixels_and_counters(oracle):
                 got = p.node.run(lvl, cam, win, w, h, flags=brt.FLAG_COUNTERS)
                 assert_frames_equal(got, want)
                 assert {q: p.node.last_stats[q] for q in COUNTER_KEYS} == cnt
+    # a camera that keeps moving: the numbering is counted again once the picture has moved a quarter of the frame's height since
+    # (a pre-pass; frames stay the oracle's)
+    with brt.RaytracePlugin([0]) as p:
+        tree0 = brt.Buffers(b.models, b.materials, brt.build_bvh_sah(b.models))
+        prepasses = 0
+        for i in range(7):
+            a = np.deg2rad(3.0 * i)
+            pos = (13.0 * np.cos(a) - 3.0 * np.sin(a), 2.0, 13.0 * np.sin(a) + 3.0 * np.cos(a))
+            lvl, cam, win = uniforms(w, h, spp, bounces, tuple(float(x) for x in pos), (0.0, 0.0, 0.0), 0.4, 0.5)
+            assert brt.tree_reach(b.models, cam)[1] == 0
+            got = p.node.run(lvl, cam, win, w, h, buffers=nb if i == 0 else None)
+            st = dict(p.node.last_stats)
+            want, cnt = oracle.render(tree0, lvl, cam, win, w, h)
+            assert_frames_equal(got, want)
+            assert st["rays"] == cnt["rays"] and st["hot_records"] > 1000
+            prepasses += 1 if (i > 0 and st["prepass_ms"] > 0.0) else 0
+        assert 1 <= prepasses <= 4, prepasses
     # a scene that fits the LDS is never re-numbered (nothing to gain), whatever the pre-pass does
     c = brt.generate_scene(brt.SCENE_COVER, 1)
     with brt.RaytracePlugin([0]) as p:
