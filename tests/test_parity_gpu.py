@@ -901,7 +901,8 @@ def test_sample_count_zero_is_zero_over_zero(plugin, oracle, level):
     # switches the pool off for launches of at most ~2.5 tiles per wave slot (every frame of this size), so the pool cases force it on
     {"BRT_DRAIN_DONATE": "0"}, {"BRT_DRAIN_DONATE": "56", "BRT_POOL_FORCE": "1"}, {"BRT_DRAIN_DONATE": "8", "BRT_POOL_CAP": "16", "BRT_POOL_FORCE": "1"},
     {"BRT_DRAIN_DONATE": "40", "BRT_BLOCK_THREADS": "256", "BRT_POOL_FORCE": "1"}, {"BRT_DRAIN_DONATE": "33", "BRT_FORCE_GLOBAL_SCENE": "1", "BRT_POOL_FORCE": "1"},
-    {"BRT_DRAIN_DONATE": "48", "BRT_WALK_EXIT": "0", "BRT_BLOCK_THREADS": "512", "BRT_WG_PER_CU": "2", "BRT_POOL_FORCE": "1"},
+    # (two 512-thread workgroups per CU hold the cover scene twice since round 5 -- no room for a pool beside it: one per CU here)
+    {"BRT_DRAIN_DONATE": "48", "BRT_WALK_EXIT": "0", "BRT_BLOCK_THREADS": "512", "BRT_WG_PER_CU": "1", "BRT_POOL_FORCE": "1"},
     {"BRT_POOL_FORCE": "1"}, {"BRT_POOL_FORCE": "1", "BRT_TUNABLE": "1"}, {"BRT_POOL_FORCE": "1", "BRT_POOL_CAP": "40"},
     {"BRT_POOL_FORCE": "1", "BRT_LEAF_VOTE": "64", "BRT_WALK_EXIT": "63"},
     # workgroup share of the pixel queue: one tile at a time, the maximum, with other workgroup shapes
@@ -1613,11 +1614,16 @@ def test_frame_stored_in_the_colour_targets_own_format(oracle, ids):
         torch.cuda.set_device(ids[0])
         d_raster, d_depth = torch.from_numpy(raster).cuda(), torch.from_numpy(depth).cuda()
         torch.cuda.synchronize()
-        for fmt, name, dt in ((brt.FLAG_OUT_RGBA8_UNORM_SRGB, "srgb8", np.uint8), (brt.FLAG_OUT_RGBA16F, "f16", np.uint16),
-                              (brt.FLAG_OUT_RGBA8_UNORM, "unorm8", np.uint8), (brt.FLAG_OUT_RGBA32F, None, np.float32)):
+        formats = ((brt.FLAG_OUT_RGBA8_UNORM_SRGB, "srgb8", np.uint8), (brt.FLAG_OUT_RGBA16F, "f16", np.uint16),
+                   (brt.FLAG_OUT_RGBA8_UNORM, "unorm8", np.uint8), (brt.FLAG_OUT_RGBA32F, None, np.float32))
+        # (all four targets exist side by side and are released at the end: an exporter's mapping that lands on virtual addresses
+        #  another mapping has just left was seen to read stale pages through hipMemcpy on one box -- HIP's VMM, not this library)
+        targets = []
+        for fmt, _, _ in formats:
             nbytes = w * h * brt.OUT_PIXEL_BYTES[fmt]
             fd, d_exported = p.debug_export_frame_fd(nbytes)
-            d_imported = p.import_frame_fd(fd, nbytes, brt.EXTMEM_DMABUF_FD)
+            targets.append((fd, d_exported, p.import_frame_fd(fd, nbytes, brt.EXTMEM_DMABUF_FD)))
+        for (fmt, name, dt), (fd, d_exported, d_imported) in zip(formats, targets):
             for level in (brt.Raytracing.Pure, brt.Raytracing.FallbackRaster, brt.Raytracing.Skip):
                 lvl, cam, win = brt.cover_camera(w, h, 3, 4, level, seed=0.31)
                 p.node.render_device(lvl, cam, win, w, h, d_imported, d_raster.data_ptr(), d_depth.data_ptr(), flags=fmt)
@@ -1631,6 +1637,7 @@ def test_frame_stored_in_the_colour_targets_own_format(oracle, ids):
                     assert np.array_equal(got[~nan], w16[~nan]) and np.all((got[nan] & 0x7c00) == 0x7c00)
                 else:
                     assert np.array_equal(got, oracle.encode_frame(want, name)), (name, level)
+        for fd, d_exported, d_imported in targets:
             p.release_frame(d_imported)
             p.release_frame(d_exported)
             _os.close(fd)
