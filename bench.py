@@ -345,6 +345,40 @@ def main():
             node.write_buffers(head["upload"])
             for _ in range(3):
                 step()
+        # (g) what a following frame started before this one has ended would buy (lever (b)) -- measured, not
+        #     part of `value`: the contract line times synchronous frames.  K frames asynchronously on ONE context and stream (no host
+        #     round trip between frames), then alternating between TWO contexts on two streams (the second frame's workgroups start
+        #     on the CUs the first one's tail frees; each context has its own control block, order and pixel-state buffers)
+        if world == 1:
+            try:
+                K = 24
+                p2 = brt.RaytracePlugin([local_rank])
+                p2.node.write_buffers(head["upload"])
+                tile2 = torch.zeros_like(head["tile"])
+                sync()
+                lvl0, cam0, win0 = head["lvl"], head["cam"], head["win"]
+                for _ in range(4):      # the second context learns its dispatch order (pre-pass, measuring frame) synchronously
+                    p2.node.render_part_device(lvl0, cam0, win0, W, H, 0, 1, tile2.data_ptr())
+                streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+                def run_async(ctxs):
+                    sync()
+                    t0 = time.perf_counter()
+                    for i in range(K):
+                        nd, tl, st = ctxs[i % len(ctxs)]
+                        nd.render_part_device(lvl0, cam0, win0, W, H, 0, 1, tl.data_ptr(), stream=st.cuda_stream)
+                    sync()
+                    return (time.perf_counter() - t0) / K * 1e3
+                one = [(node, head["tile"], streams[0])]
+                two = [(node, head["tile"], streams[0]), (p2.node, tile2, streams[1])]
+                run_async(one); run_async(two)
+                extras["frames_in_flight"] = {"frames": K, "one_context_async_ms_per_frame": round(min(run_async(one) for _ in range(3)), 3),
+                                              "two_contexts_alternating_ms_per_frame": round(min(run_async(two) for _ in range(3)), 3),
+                                              "note": "not part of `value` (synchronous frames): what starting the next frame before this one's tail has drained would buy"}
+                p2.close()
+                for _ in range(3):
+                    step()
+            except Exception as e:   # noqa: BLE001  (a measurement beside the contract line must never take it down)
+                extras["frames_in_flight"] = {"error": str(e)[:200]}
     cfg4 = None
     if not args.no_extras and world > 1:
         # config 2's longest pixel chains take ~5 ms whatever N is; BASELINE.json's own
