@@ -79,6 +79,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc pass (N = 1 only)")
     ap.add_argument("--no-extras", action="store_true", help="skip first-frame / reseeded / moving-camera / config-4 measurements")
     ap.add_argument("--no-configs", action="store_true", help="skip the config 3 / config 5 blocks (N = 1)")
+    ap.add_argument("--sync-steps", action="store_true", help="timed steps through the synchronous form of brt_render_part_device (a host round "
+                                                              "trip per frame) instead of enqueueing them on the stream")
     return ap.parse_args(argv)
 
 
@@ -230,25 +232,54 @@ def main():
             # lane-level iterations of the rejection sampler = active lanes summed over the executions of its section
             counted["ball_iterations"] = plugin.debug_profile()["ball"][1]
         for _ in range(warmup):
-            step()
+            st_w = step()[0]
+        async_steps = dev.type == "cuda" and stub is None and not args.sync_steps and warmup >= 2
         barrier()
         t0 = time.perf_counter()
         kernel_ms, rays, variants, measuring = [], 0, [], 0
-        for _ in range(steps):
-            st, frame = step(timed=True)
-            kernel_ms.append(st["kernel_ms"])
-            rays += st["rays"]
-            variants.append(st.get("kernel_variant", 0))
-            measuring += st.get("measured_tile_costs", 0)
-        barrier()
-        elapsed = all_max(time.perf_counter() - t0)
+        if async_steps:
+            # The K timed frames are ENQUEUED on torch's current stream (the caller-stream form of brt_render_part_device: no host round
+            # trip per frame; the dispatch order and the kernel instantiation are the steady state the synchronous warm-up frames
+            # left), each followed by its gather / de-interleave on the same stream; ONE synchronisation, at the barrier behind them.
+            # Kernel time: HIP events on that stream around each launch.  Every frame has the same inputs, hence the same ray count
+            # as the last warm-up frame, which the library counted.
+            cur = torch.cuda.current_stream().cuda_stream
+            evs = []
+            for _ in range(steps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                st = node.render_part_device(lvl, cam, win, W, H, rank, world, tile.data_ptr(), stream=cur)
+                e1.record()
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record()
+                frame = gather_frame(tile, H, rank, world, node=node, rccl=rccl)
+                g1.record()
+                gather_events.append((g0, g1))
+                evs.append((e0, e1))
+                variants.append(st.get("kernel_variant", 0))
+                measuring += st.get("measured_tile_costs", 0)
+            barrier()
+            elapsed = all_max(time.perf_counter() - t0)
+            kernel_ms = [a.elapsed_time(b) for a, b in evs]
+            rays = st_w["rays"] * steps
+            st = dict(st_w, **{k: st[k] for k in ("kernel_variant", "measured_tile_costs") if k in st})
+        else:
+            for _ in range(steps):
+                st, frame = step(timed=True)
+                kernel_ms.append(st["kernel_ms"])
+                rays += st["rays"]
+                variants.append(st.get("kernel_variant", 0))
+                measuring += st.get("measured_tile_costs", 0)
+            barrier()
+            elapsed = all_max(time.perf_counter() - t0)
         total_rays = all_sum(rays)
         res = {"W": W, "H": H, "spp": spp, "bounces": bounces, "buffers": buffers, "scene": scene, "upload": upload, "lvl": lvl, "cam": cam, "win": win,
                "frame": frame, "counted": counted, "elapsed": elapsed, "total_rays": total_rays, "steps": steps,
                "kernel_ms": float(np.mean(kernel_ms)), "kernel_ms_per_rank": all_list(float(np.mean(kernel_ms))),
                "rays_per_rank": all_list(rays / steps),
                "gather_ms": float(np.mean([a.elapsed_time(b) for a, b in gather_events])) if gather_events else 0.0,
-               "step": step, "tile": tile, "last_stats": st, "variants": sorted(set(variants)), "measuring_frames": measuring}
+               "step": step, "tile": tile, "last_stats": st, "variants": sorted(set(variants)), "measuring_frames": measuring,
+               "async_steps": async_steps}
         return res
 
     # every rank is there and rank r renders on device ordinal r (one process per GPU: a launcher that put two ranks on one card, or
@@ -345,9 +376,9 @@ def main():
             node.write_buffers(head["upload"])
             for _ in range(3):
                 step()
-        # (g) what a following frame started before this one has ended would buy (lever (b)) -- measured, not
-        #     part of `value`: the contract line times synchronous frames.  K frames asynchronously on ONE context and stream (no host
-        #     round trip between frames), then alternating between TWO contexts on two streams (the second frame's workgroups start
+        # (g) what a following frame started before this one has ended would buy (lever (b)) -- measured beside
+        #     `value`, whose timed frames run one after the other on one stream.  K frames asynchronously on ONE context and stream (no
+        #     host round trip between frames: what the timed region does), then alternating between TWO contexts on two streams (the second frame's workgroups start
         #     on the CUs the first one's tail frees; each context has its own control block, order and pixel-state buffers)
         if world == 1:
             try:
@@ -373,7 +404,7 @@ def main():
                 run_async(one); run_async(two)
                 extras["frames_in_flight"] = {"frames": K, "one_context_async_ms_per_frame": round(min(run_async(one) for _ in range(3)), 3),
                                               "two_contexts_alternating_ms_per_frame": round(min(run_async(two) for _ in range(3)), 3),
-                                              "note": "not part of `value` (synchronous frames): what starting the next frame before this one's tail has drained would buy"}
+                                              "note": "beside `value` (frames enqueued on one stream, one after the other): what a following frame of a SECOND context, started before this one's tail has drained, would add -- nothing"}
                 p2.close()
                 for _ in range(3):
                     step()
@@ -428,7 +459,10 @@ def main():
             # camera and scene stand still never measures again (round 4), so the timed window IS the amortised steady state; a moving
             # camera measures every frame: `moving_camera_ms`
             "steady_state": {"kernel_variants_timed": head["variants"], "measuring_frames_timed": head["measuring_frames"],
-                             "amortised_ms_per_frame": head["elapsed"] / args.steps * 1e3},
+                             "amortised_ms_per_frame": head["elapsed"] / args.steps * 1e3,
+                             "submission": ("the K timed frames are enqueued on one stream (caller-stream form of brt_render_part_device, each followed by its "
+                                            "gather / de-interleave), one synchronisation at the closing barrier; frames run one after the other, none overlaps "
+                                            "(`frames_in_flight`)") if head["async_steps"] else "one synchronous call per frame (a host round trip each)"},
             "roofline": roof,
             "kernel": {"lds_bytes": counted["lds_bytes"], "scene_in_lds": counted["scene_in_lds"],
                        "workgroups": counted["n_workgroups"], "threads": counted["threads_per_workgroup"]},
