@@ -538,6 +538,56 @@ int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const fl
 // descriptors and the root re-written, the records re-sent -- 1.1 MB and a host sort of 10 003 counts per pre-pass and device.
 // The spheres are re-numbered with them (an internal numbering: nothing outside sees a sphere's index), see below.
 // Only the NUMBERING of the records changes: the walk visits the same nodes in the same order, pixels and all five counters stay.
+// the shape of the encoded tree: both child descriptors of every record, in the encoder's (breadth-first) numbering.  Two uploads with
+// the same hash have the same records in the same places holding the same spheres -- only boxes and centres may have moved
+uint64_t tree_shape_hash(const EncodedScene& e) {
+    uint64_t h = 1469598103934665603ull ^ ((uint64_t)e.n_pairs << 32) ^ e.n_models;
+    constexpr uint32_t kDescWord = PAIR_DESC / 4u;
+    for (uint32_t r = 0; r < e.n_pairs; r++)
+        for (uint32_t k = 0; k < 2u; k++) {
+            uint32_t d;
+            std::memcpy(&d, e.pairs.data() + (size_t)r * PAIR_WORDS + kDescWord + k, 4);
+            h = (h ^ d) * 1099511628211ull;
+        }
+    return h | 1ull;
+}
+
+// records and spheres of `e` in the numbering rank / srank (old index -> new index) into the four host arrays; the root's descriptor
+void permute_scene(const std::vector<float>& pairs, const std::vector<float>& spheres, const std::vector<uint32_t>& sphmat,
+                   const std::vector<float>& sphmats, uint32_t root, const std::vector<uint32_t>& rank, const std::vector<uint32_t>& srank,
+                   std::vector<float>* out_pairs, std::vector<float>* out_spheres, std::vector<uint32_t>* out_sphmat,
+                   std::vector<float>* out_sphmats, uint32_t* out_root) {
+    using D = Desc<true>;
+    constexpr uint32_t kDescWord = PAIR_DESC / 4u;
+    const uint32_t n = (uint32_t)rank.size(), m = (uint32_t)srank.size();
+    auto remap = [&](uint32_t d) {
+        if ((int32_t)d >= 0 && d < n) return rank[d];                                                  // interior (16-bit form: the record's index)
+        if ((int32_t)d < -1 && (d & D::LEAF1) && (d & D::INDEX_MASK) < m) return (d & ~D::INDEX_MASK) | srank[d & D::INDEX_MASK];   // single-sphere leaf
+        return d;
+    };
+    out_pairs->resize(pairs.size());
+    for (uint32_t i = 0; i < n; i++) {
+        const float* src = pairs.data() + (size_t)i * PAIR_WORDS;
+        float* dst = out_pairs->data() + (size_t)rank[i] * PAIR_WORDS;
+        std::memcpy(dst, src, PAIR_BYTES);
+        for (uint32_t k = 0; k < 2u; k++) {
+            uint32_t d;
+            std::memcpy(&d, src + kDescWord + k, 4);
+            d = remap(d);
+            std::memcpy(dst + kDescWord + k, &d, 4);
+        }
+    }
+    out_spheres->resize(spheres.size());
+    out_sphmats->resize(sphmats.size());
+    out_sphmat->resize(m);
+    for (uint32_t i = 0; i < m; i++) {
+        std::memcpy(out_spheres->data() + (size_t)srank[i] * 4, spheres.data() + (size_t)i * 4, 16);
+        std::memcpy(out_sphmats->data() + (size_t)srank[i] * 8, sphmats.data() + (size_t)i * 8, 32);
+        (*out_sphmat)[srank[i]] = sphmat[i];
+    }
+    *out_root = remap(root);
+}
+
 int32_t apply_hot_order(brt_ctx* ctx, DeviceCtx& dc, hipStream_t stream) {
     const uint32_t n = dc.view.n_pairs, m = dc.view.n_models;
     const EncodedScene& e = ctx->enc;
@@ -578,41 +628,30 @@ int32_t apply_hot_order(brt_ctx* ctx, DeviceCtx& dc, hipStream_t stream) {
     for (uint32_t i = 0; i < m; i++) sorder[i] = i;
     std::stable_sort(sorder.begin(), sorder.end(), [&](uint32_t a, uint32_t b) { return score[a] > score[b]; });
     for (uint32_t i = 0; i < m; i++) srank[sorder[i]] = i;
-    auto remap = [&](uint32_t d) {
-        uint32_t id;
-        if ((int32_t)d >= 0 && d < n) return rank[d];                             // interior (16-bit form: the record's index)
-        if (leaf_sphere(d, &id)) return (d & ~D::INDEX_MASK) | srank[id];       // single-sphere leaf
-        return d;
-    };
-    dc.h_pairs_hot.resize(cur.size());
-    for (uint32_t i = 0; i < n; i++) {
-        const float* src = cur.data() + (size_t)order[i] * PAIR_WORDS;
-        float* dst = dc.h_pairs_hot.data() + (size_t)i * PAIR_WORDS;
-        std::memcpy(dst, src, PAIR_BYTES);
-        for (uint32_t k = 0; k < 2u; k++) {
-            uint32_t d;
-            std::memcpy(&d, src + kDescWord + k, 4);
-            d = remap(d);
-            std::memcpy(dst + kDescWord + k, &d, 4);
-        }
-    }
-    std::vector<float> sph(dc.h_spheres_cur.size()), mats(dc.h_sphmats_cur.size());
-    std::vector<uint32_t> mat(m);
-    for (uint32_t i = 0; i < m; i++) {
-        std::memcpy(sph.data() + (size_t)i * 4, dc.h_spheres_cur.data() + (size_t)sorder[i] * 4, 16);
-        std::memcpy(mats.data() + (size_t)i * 8, dc.h_sphmats_cur.data() + (size_t)sorder[i] * 8, 32);
-        mat[i] = dc.h_sphmat_cur[sorder[i]];
-    }
+    std::vector<float> sph, mats;
+    std::vector<uint32_t> mat;
+    uint32_t new_root = 0;
+    permute_scene(cur, dc.h_spheres_cur, dc.h_sphmat_cur, dc.h_sphmats_cur, cur_root, rank, srank, &dc.h_pairs_hot, &sph, &mat, &mats, &new_root);
     HIP_TRY(ctx, hipMemcpyAsync(const_cast<float*>(dc.view.pairs), dc.h_pairs_hot.data(), dc.h_pairs_hot.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(ctx, hipMemcpyAsync(const_cast<float*>(dc.view.spheres), sph.data(), sph.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(ctx, hipMemcpyAsync(const_cast<uint32_t*>(dc.view.sphere_material), mat.data(), mat.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(ctx, hipMemcpyAsync(const_cast<float*>(dc.view.sphere_mats), mats.data(), mats.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));       // (the vectors are reused by the next call)
+    // the numbering as a map from the ENCODER's numbering (what the next upload of a tree of the same shape starts from): composed with
+    // the one the counts were indexed by
+    if (dc.hot_tree == ctx->tree_epoch && dc.h_total_rank.size() == n && dc.h_total_srank.size() == m) {
+        for (uint32_t i = 0; i < n; i++) dc.h_total_rank[i] = rank[dc.h_total_rank[i]];
+        for (uint32_t i = 0; i < m; i++) dc.h_total_srank[i] = srank[dc.h_total_srank[i]];
+    } else {
+        dc.h_total_rank = rank;
+        dc.h_total_srank = srank;
+    }
+    dc.hot_shape = tree_shape_hash(e);
     dc.h_pairs_cur.swap(dc.h_pairs_hot);
     dc.h_spheres_cur.swap(sph);
     dc.h_sphmat_cur.swap(mat);
     dc.h_sphmats_cur.swap(mats);
-    dc.view.root_desc = remap(cur_root);
+    dc.view.root_desc = new_root;
     dc.hot_tree = ctx->tree_epoch;
     dc.hot_records = visited;
     return BRT_OK;
@@ -1033,12 +1072,28 @@ int32_t upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, const 
     size_t total = 0;
     for (auto& s : secs) { s.off = total; total += align256(s.bytes ? s.bytes : 16); }
 
+    // A tree of the same shape as the one a device last counted the record visits of (an animated scene: the reference re-extracts
+    // and re-uploads every frame, extract.rs:299-336, and the spheres move a little) goes up in THAT numbering straight away: the
+    // records the view uses stay the ones the LDS tile holds (apply_hot_order), without a pre-pass per upload
+    const uint64_t shape = (ctx->knobs[K_HOT_RECORDS] != 0u && !rebuild && e.desc16 && e.simple_tree && e.n_pairs > 64u) ? tree_shape_hash(e) : 0ull;
+    ctx->tree_epoch++;          // (the numbering on the devices is the encoder's again unless a device re-applies its own below)
     for (auto& dc : ctx->devs) {
         HIP_TRY(ctx, hipSetDevice(dc.device));
         int32_t r2 = ensure(ctx, &dc.d_scene, &dc.scene_cap, total);
         if (r2 != BRT_OK) return r2;
-        for (auto& s : secs)
+        const bool reuse = shape != 0ull && dc.hot_shape == shape && dc.hot_records != 0u && dc.h_total_rank.size() == e.n_pairs &&
+                           dc.h_total_srank.size() == e.n_models;
+        uint32_t root = e.root_desc;
+        Sec mine[6];
+        for (int q = 0; q < 6; q++) mine[q] = secs[q];
+        if (reuse) {
+            permute_scene(e.pairs, e.spheres, e.sphere_material, e.sphere_mats, e.root_desc, dc.h_total_rank, dc.h_total_srank, &dc.h_pairs_cur,
+                          &dc.h_spheres_cur, &dc.h_sphmat_cur, &dc.h_sphmats_cur, &root);
+            mine[0].src = dc.h_pairs_cur.data(); mine[1].src = dc.h_spheres_cur.data(); mine[2].src = dc.h_sphmat_cur.data(); mine[5].src = dc.h_sphmats_cur.data();
+        }
+        for (auto& s : mine)
             if (s.bytes) HIP_TRY(ctx, hipMemcpyAsync(dc.d_scene + s.off, s.src, s.bytes, hipMemcpyHostToDevice, dc.stream));
+        const uint32_t kept_hot = reuse ? dc.hot_records : 0u;
         DeviceSceneView v{};
         v.pairs = reinterpret_cast<const float*>(dc.d_scene + secs[0].off);
         v.spheres = reinterpret_cast<const float*>(dc.d_scene + secs[1].off);
@@ -1050,16 +1105,16 @@ int32_t upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, const 
         v.n_models = e.n_models;
         v.n_materials = e.n_materials;
         v.n_leaf_table = (uint32_t)(e.leaf_table.size() / 2);
-        v.root_desc = e.root_desc;
+        v.root_desc = root;
         v.stack_entries = e.stack_entries;
         v.desc16 = e.desc16 ? 1u : 0u;
         v.simple_tree = e.simple_tree ? 1u : 0u;
         v.boxes_ordered = e.boxes_ordered ? 1u : 0u;
         dc.view = v;
-        dc.hot_records = 0u;
+        dc.hot_records = kept_hot;
+        if (reuse) dc.hot_tree = ctx->tree_epoch;
         dc.frames_since_upload = 0u;
     }
-    ctx->tree_epoch++;          // (the records on the devices are in breadth-first order again: DeviceCtx::hot_tree no longer matches)
     for (auto& dc : ctx->devs) {
         HIP_TRY(ctx, hipSetDevice(dc.device));
         HIP_TRY(ctx, hipStreamSynchronize(dc.stream));  // the caller's vectors are no longer referenced

@@ -82,6 +82,8 @@ struct DeviceCtx {
     float hot_cam_pos[3] = {0, 0, 0}, hot_cam_dir[3] = {0, 0, 1};   // the camera they were counted with
     uint32_t frames_since_upload = 0;                    // frames this device has rendered since the last scene upload / tree rebuild
     std::vector<uint32_t> h_hits, h_rank;
+    std::vector<uint32_t> h_total_rank, h_total_srank;   // the numbering of the records / spheres on this device as a map from the encoder's numbering
+    uint64_t hot_shape = 0;                              // tree_shape_hash of the tree that numbering was counted on (0: none)
     std::vector<float> h_spheres_cur, h_sphmats_cur;
     std::vector<uint32_t> h_sphmat_cur;
     std::vector<float> h_pairs_hot, h_pairs_cur;          // scratch / the records as they are on the device (when hot_tree matches)

@@ -746,6 +746,26 @@ def test_records_numbered_by_visits_same_pixels_and_counters(oracle):
                 got = p.node.run(lvl, cam, win, w, h, flags=brt.FLAG_COUNTERS)
                 assert_frames_equal(got, want)
                 assert {q: p.node.last_stats[q] for q in COUNTER_KEYS} == cnt
+    # an animated scene (the reference re-uploads every frame, extract.rs:299-336): a tree of the same shape goes up in the numbering
+    # the device last counted -- no pre-pass per upload, the frames are the oracle's on each new scene
+    with brt.RaytracePlugin([0]) as p:
+        lvl, cam, win = views[0]
+        for frame in range(3):
+            p.node.run(lvl, cam, win, w, h, buffers=nb if frame == 0 else None)
+        assert p.node.last_stats["hot_records"] > 1000
+        moving = b.models.copy()
+        kept = 0
+        for step in range(4):
+            moving["position"][7 + step, 0] += np.float32(0.002)
+            got = p.node.run(lvl, cam, win, w, h, buffers=brt.Buffers(moving, b.materials, None))
+            st = dict(p.node.last_stats)
+            want, cnt = oracle.render(brt.Buffers(moving, b.materials, brt.build_bvh_sah(moving)), lvl, cam, win, w, h)
+            assert_frames_equal(got, want)
+            assert st["rays"] == cnt["rays"] and st["prepass_ms"] == 0.0
+            kept += 1 if st["hot_records"] > 1000 else 0
+        assert kept >= 2, kept            # (a sphere that crosses a bin border of the SAH build changes the tree's shape: breadth first then)
+        got = p.node.run(lvl, cam, win, w, h, flags=brt.FLAG_COUNTERS)
+        assert {q: p.node.last_stats[q] for q in COUNTER_KEYS} == cnt
     # a camera that keeps moving: the numbering is counted again once the picture has moved a quarter of the frame's height since
     # (a pre-pass; frames stay the oracle's)
     with brt.RaytracePlugin([0]) as p:
