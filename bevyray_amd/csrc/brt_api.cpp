@@ -277,21 +277,7 @@ double camera_motion_px(const brt_ctx* ctx, const float* pos0, const float* dir0
     return px == px ? px : 1e30;
 }
 uint32_t dilation_tiles(const brt_ctx* ctx, const DeviceCtx& dc, const FrameParams& fp) {
-    const float* a = dc.cost_cam_dir;
-    const float* b = fp.cam_dir;
-    const double la = std::sqrt((double)a[0] * a[0] + (double)a[1] * a[1] + (double)a[2] * a[2]);
-    const double lb = std::sqrt((double)b[0] * b[0] + (double)b[1] * b[1] + (double)b[2] * b[2]);
-    double c = ((double)a[0] * b[0] + (double)a[1] * b[1] + (double)a[2] * b[2]) / (la * lb);
-    if (!(c == c)) return kMaxDilate + 1u;
-    c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
-    const double px_per_rad = 0.5 * (double)fp.height / (double)fp.tan_half_fov;
-    double dp = 0.0, dist = 0.0;
-    for (int k = 0; k < 3; k++) {
-        dp += ((double)fp.cam_pos[k] - dc.cost_cam_pos[k]) * ((double)fp.cam_pos[k] - dc.cost_cam_pos[k]);
-        dist += ((double)fp.cam_pos[k] - ctx->scene_centre[k]) * ((double)fp.cam_pos[k] - ctx->scene_centre[k]);
-    }
-    const double rot_px = std::acos(c) * px_per_rad, trans_px = std::sqrt(dp) / std::max(std::sqrt(dist), 1e-3) * px_per_rad;
-    const double px = std::max(rot_px, trans_px);
+    const double px = camera_motion_px(ctx, dc.cost_cam_pos, dc.cost_cam_dir, fp);
     if (!(px < 8.0 * kMaxDilate)) return kMaxDilate + 1u;
     return (uint32_t)std::ceil(px / 8.0) + 1u;
 }

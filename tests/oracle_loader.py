@@ -86,6 +86,10 @@ class Oracle:
         models = np.ascontiguousarray(buffers.models)
         materials = np.ascontiguousarray(buffers.materials)
         bvh = np.ascontiguousarray(buffers.bvh)
+        # (numpy re-packs a padded record dtype in concatenate & co.: 20-byte "models" would be walked as 32-byte ones)
+        if (models.dtype.itemsize, materials.dtype.itemsize, bvh.dtype.itemsize) != (32, 32, 48):
+            raise ValueError(f"oracle.render: buffers are not in the wire layout (record sizes {models.dtype.itemsize}, "
+                             f"{materials.dtype.itemsize}, {bvh.dtype.itemsize}; expected 32, 32, 48)")
         out = np.zeros((height, width, 4), np.float32)
         cnt = (C.c_uint64 * 5)()
         r0, r1 = (0, height) if rows is None else rows
