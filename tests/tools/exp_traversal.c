@@ -176,12 +176,31 @@ void exp_get_far(uint64_t* out8) { memcpy(out8, g_far, sizeof g_far); }
 static inline int is_far(int c) { return g_tile_k > 0 && c >= 0 && g_rank[c] >= g_tile_k; }
 
 typedef struct {
-    int active, in_flight;
+    int active, in_flight, pend;
     uint32_t rng, sample, bounce;
     float uvx, uvy, first_depth;
     vec3 tput;
     Walk w;
 } Lane;
+
+/* ---- study of a leaf step in two parts.  Part A (cheap: the discriminant) for the lanes at a leaf: a lane whose ray misses the
+ * sphere (discriminant < 0 or NaN) or has it behind its origin (h <= 0: then h - sqrt(..) <= 0 whatever the root, and t > 0.001
+ * fails) pops and walks on; the others WAIT (pending) for part B (sqrt, divide, accept), which runs when g_vote_b of them have
+ * gathered, when nobody else can move, or before the wave leaves the loop.  A pending lane does not walk (its `closest` is not
+ * known yet: walking on with the old one would visit boxes the reference culls).  g_ab = 0: the kernel's single leaf step. ---- */
+static int g_ab = 0, g_vote_a = 12, g_vote_b = 24;
+static uint64_t g_abc[4];   /* A executions, A lanes, B executions, B lanes */
+void exp_set_ab(int on, int vote_a, int vote_b) { g_ab = on; g_vote_a = vote_a; g_vote_b = vote_b; }
+void exp_get_ab(uint64_t* out4) { memcpy(out4, g_abc, sizeof g_abc); }
+static int part_a_passes(const Scene* s, const Walk* w, int idx) {
+    const Model* m = &s->models[idx];
+    vec3 oc = vsub(V(m->px, m->py, m->pz), w->ray.origin);
+    float a = dot(w->ray.direction, w->ray.direction);
+    float h = dot(w->ray.direction, oc);
+    float c = dot(oc, oc) - m->radius * m->radius;
+    float disc = h * h - a * c;
+    return disc >= 0.0f && h > 0.0f;
+}
 
 /* one tile = one wave; runs until the wave has thinned to `stop_live` live lanes (the real kernel hands the rest over) */
 static void sim_tile(const Scene* s, const WTree* t, const Variant* v, uint32_t tx, uint32_t ty, uint32_t W, uint32_t H,
@@ -216,6 +235,40 @@ static void sim_tile(const Scene* s, const WTree* t, const Variant* v, uint32_t 
             n_walking++;
         }
         int exit_at = n_walking >> 1; if (exit_at > v->exit_lanes) exit_at = v->exit_lanes;
+        if (g_ab) {
+            for (;;) {
+                int ni = 0, nl = 0, np = 0;
+                for (;;) {
+                    ni = 0;
+                    for (int l = 0; l < 64; l++) if (L[l].active && !L[l].pend && is_int(L[l].w.cur)) ni++;
+                    if (!ni) break;
+                    c->int_exec++; c->int_lanes += (uint64_t)ni;
+                    for (int l = 0; l < 64; l++) if (L[l].active && !L[l].pend && is_int(L[l].w.cur)) step_interior(s, t, &L[l].w, v, c);
+                    nl = 0; np = 0;
+                    for (int l = 0; l < 64; l++) if (L[l].active) { if (L[l].pend) np++; else if (is_leaf(L[l].w.cur)) nl++; }
+                    if (nl >= g_vote_a || np >= g_vote_b) break;
+                }
+                ni = nl = np = 0;
+                for (int l = 0; l < 64; l++) if (L[l].active) { if (L[l].pend) np++; else if (is_leaf(L[l].w.cur)) nl++; else if (is_int(L[l].w.cur)) ni++; }
+                if (nl && (nl >= g_vote_a || !ni)) {
+                    g_abc[0]++; g_abc[1] += (uint64_t)nl;
+                    for (int l = 0; l < 64; l++) if (L[l].active && !L[l].pend && is_leaf(L[l].w.cur)) {
+                        if (part_a_passes(s, &L[l].w, -L[l].w.cur - 2)) { L[l].pend = 1; np++; }
+                        else { c->sphere_tests++; pop(&L[l].w, v, c); }
+                    }
+                }
+                int nw = 0, movers = 0;
+                for (int l = 0; l < 64; l++) if (L[l].active && L[l].w.cur != DONE) { nw++; if (!L[l].pend) movers++; }
+                if (np && (np >= g_vote_b || !movers || nw <= exit_at)) {
+                    g_abc[2]++; g_abc[3] += (uint64_t)np;
+                    c->leaf_exec++; c->leaf_lanes += (uint64_t)np;
+                    for (int l = 0; l < 64; l++) if (L[l].active && L[l].pend) { L[l].pend = 0; step_leaf(s, &L[l].w, v, c); }
+                    nw = 0;
+                    for (int l = 0; l < 64; l++) if (L[l].active && L[l].w.cur != DONE) nw++;
+                }
+                if (nw <= exit_at) break;
+            }
+        } else
         for (;;) {
             for (;;) {
                 int ni = 0, nf = 0;
@@ -427,6 +480,7 @@ int exp_run(const void* models, uint32_t n_models, const void* materials, uint32
         free(q);
     }
     memset(g_far, 0, sizeof g_far);
+    memset(g_abc, 0, sizeof g_abc);
     Variant v = {width, near_first, pop_cull, leaf_in_parent, vote, exit_lanes};
     SimCnt c; memset(&c, 0, sizeof c);
     for (uint32_t i = 0; i < n_tiles; i++) {

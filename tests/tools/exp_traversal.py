@@ -58,6 +58,43 @@ def far_study(n=40):
     lib.exp_set_far(0, 0, 64)
 
 
+def leaf_split_study(n=60, scene=None):
+    """Would a leaf step in two parts pay?  Part A (the discriminant, ~55 cycles of a SIMD) for the lanes at a leaf; the lanes whose
+    ray can still hit (discriminant >= 0, sphere ahead: 48 % of the tests on the cover frame) wait for part B (sqrt, divide, accept:
+    ~150 cycles) until `vote_b` of them have gathered.  Costs: interior step 134 cycles, the kernel's single leaf step 200."""
+    W, H, spp, bounces = 1920, 1080, 64, 8
+    b = brt.generate_scene(brt.SCENE_COVER if scene is None else scene, 1)
+    b = brt.Buffers(b.models, b.materials, brt.build_bvh_sah(b.models))      # the callee's tree, as the product walks it
+    lvl, cam, win = brt.cover_camera(W, H, spp, bounces)
+    rng = np.random.default_rng(5)
+    tiles = np.stack([rng.integers(0, W // 8, n), rng.integers(0, H // 8, n)], 1)
+    lib.exp_set_ab.argtypes = [I, I, I]
+    lib.exp_get_ab.argtypes = [VP]
+    ab = np.zeros(4, np.uint64)
+    C_INT, C_LEAF, C_A, C_B = 134, 200, 55, 150
+    print(f"{'policy':34s} {'int/rnd':>8s} {'lanes':>6s} {'leaf|A/rnd':>10s} {'lanes':>6s} {'B/rnd':>7s} {'lanes':>6s} {'rounds':>8s} {'walk cycles/ray':>15s}")
+    base = None
+    for name, on, va, vb in [("kernel: one leaf step, vote 12", 0, 12, 0), ("A vote 12, B vote 16", 1, 12, 16), ("A vote 12, B vote 24", 1, 12, 24),
+                             ("A vote 12, B vote 32", 1, 12, 32), ("A vote 8, B vote 24", 1, 8, 24), ("A vote 4, B vote 24", 1, 4, 24),
+                             ("A vote 4, B vote 32", 1, 4, 32), ("A vote 1, B vote 24", 1, 1, 24), ("A vote 8, B vote 40", 1, 8, 40),
+                             ("A vote 12, B vote 1 (A then B at once)", 1, 12, 1)]:
+        lib.exp_set_ab(on, va, vb)
+        r = run(b, cam, win, W, H, tiles)
+        lib.exp_get_ab(ab.ctypes.data)
+        a = [int(x) for x in ab]
+        R = r["rounds"]
+        if on:
+            cyc = r["int_exec"] * C_INT + a[0] * C_A + a[2] * C_B
+            le, ll = a[0], a[1]
+        else:
+            cyc = r["int_exec"] * C_INT + r["leaf_exec"] * C_LEAF
+            le, ll = r["leaf_exec"], r["leaf_lanes"]
+        base = base or cyc / r["rays"]
+        print(f"{name:34s} {r['int_exec']/R:8.2f} {r['int_lanes']/max(1,r['int_exec']):6.1f} {le/R:10.2f} {ll/max(1,le):6.1f} {a[2]/R:7.2f} {a[3]/max(1,a[2]):6.1f} "
+              f"{R:8d} {cyc/r['rays']:15.1f}  ({100.0 * (cyc / r['rays'] / base - 1.0):+.1f} %)", flush=True)
+    lib.exp_set_ab(0, 12, 24)
+
+
 def policy_grid(n=60):
     """Leaf-vote x walk-exit thresholds of the width-2 walk: total wave instructions per ray (1060 non-walk per round)."""
     W, H, spp, bounces = 1920, 1080, 64, 8
@@ -79,6 +116,8 @@ def policy_grid(n=60):
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--far-study":
         return far_study(int(sys.argv[2]) if len(sys.argv) > 2 else 40)
+    if len(sys.argv) > 1 and sys.argv[1] == "--leaf-split":
+        return leaf_split_study(int(sys.argv[2]) if len(sys.argv) > 2 else 60, int(sys.argv[3]) if len(sys.argv) > 3 else None)
     if len(sys.argv) > 1 and sys.argv[1] == "--policy-grid":
         return policy_grid(int(sys.argv[2]) if len(sys.argv) > 2 else 60)
     scene = int(sys.argv[1]) if len(sys.argv) > 1 else brt.SCENE_COVER
