@@ -25,7 +25,10 @@
 
 namespace brt {
 
-constexpr int kSahBins = 16;
+#ifndef BRT_SAH_BINS
+#define BRT_SAH_BINS 16   // (the CPU twin takes any count; measured on the oracle: 24 / 32 / 64 bins walk 3 % fewer interior nodes per ray -- docs/experiments.md)
+#endif
+constexpr int kSahBins = BRT_SAH_BINS;
 constexpr uint32_t kSahMaxDepth = 28;     // leaves at depth <= 28: stack_entries <= 29 < 31 (simple tree, brt_host.cpp)
 constexpr double kSahDblMax = 1.7976931348623157e308;
 

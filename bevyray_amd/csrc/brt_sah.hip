@@ -40,6 +40,7 @@ constexpr uint32_t SB = 1024, SW = SB / 64;
 constexpr uint32_t kSubMax = 1024;      // subtrees of at most this many spheres are built by one workgroup each
 constexpr uint32_t kListCap = kSubMax / 2;   // nodes of >= 2 spheres in one level of a subtree
 constexpr uint32_t kNBins = 3 * kSahBins;
+static_assert(kNBins <= 64, "one lane per split candidate (step 3 of split_range): more bins need a loop there");
 constexpr uint32_t kTopCounters = 32;
 
 struct SahTask {
