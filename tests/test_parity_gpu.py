@@ -1744,3 +1744,45 @@ def test_lean_steady_state_kernel_renders_the_same_pixels(oracle, monkeypatch):
             for frame in range(3):
                 got = p.node.run(lvl, cam, win, w, h, buffers=b, raster_rgba=raster, raster_depth=depth)
                 assert_frames_equal(got, want)
+
+
+def test_two_contexts_driven_from_two_host_threads(oracle):
+    """The library keeps its state in the context (brt_ctx.h) -- nothing process-wide but the RCCL loader (std::call_once) and a
+    thread-local error string -- so two host threads, each with a context of its own on the same GPU, may upload and render at the
+    same time (ctypes releases the GIL for the duration of a call).  Each thread: its own scene, frames at two sizes, a far camera
+    (tree rebuilt), an animated upload -- every frame the oracle's."""
+    import threading
+    jobs = []
+    for kind, cam_fn, (w, h) in ((brt.SCENE_COVER, brt.cover_camera, (160, 90)), (brt.SCENE_RTIOW_FINAL, brt.rtiow_camera, (128, 72))):
+        b = brt.generate_scene(kind, 1)
+        steps = []
+        for spp, scale in ((8, 1.0), (33, 1.0), (8, 40.0)):
+            lvl, cam, win = cam_fn(w, h, spp, 6)
+            if scale != 1.0:
+                cam = cam.copy()
+                cam["position"] *= np.float32(scale)
+                cam["fov"] /= np.float32(scale)
+            tree = brt.build_bvh_sah(b.models, brt.tree_reach(b.models, cam)[2])
+            steps.append((lvl, cam, win, oracle.render(brt.Buffers(b.models, b.materials, tree), lvl, cam, win, w, h)))
+        jobs.append((b, w, h, steps))
+    errors = []
+
+    def worker(b, w, h, steps):
+        try:
+            with brt.RaytracePlugin([0]) as p:
+                for rep in range(6):
+                    for i, (lvl, cam, win, (want, cnt)) in enumerate(steps):
+                        got = p.node.run(lvl, cam, win, w, h, buffers=brt.Buffers(b.models, b.materials, None) if (rep + i) % 3 == 0 else None)
+                        st = p.node.last_stats
+                        if not np.array_equal(got.view(np.uint32), want.view(np.uint32)) or st["rays"] != cnt["rays"]:
+                            errors.append(f"{w}x{h} rep {rep} step {i}: frame or ray count differs")
+        except Exception as e:      # noqa: BLE001 -- reported by the asserting thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a render thread did not finish"
+    assert not errors, errors
