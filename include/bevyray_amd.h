@@ -137,7 +137,9 @@ const char* brt_last_error(const brt_ctx* ctx);
 
 /* Replaces: RaytracingPipeline::from_world (pipeline.rs:233-331) -- one-time GPU setup.
  * device_ids[n_devices] are HIP ordinals; the frame is row-tiled over them in strips of
- * BRT_STRIP_ROWS rows (strip s -> device s % n_devices).  An ordinal may repeat. */
+ * BRT_STRIP_ROWS rows (strip s -> device s % n_devices).  An ordinal may repeat.
+ * Threads: all state lives in the context; calls on ONE context must not overlap, different contexts may be driven from different
+ * host threads at the same time (tests/test_parity_gpu.py::test_two_contexts_driven_from_two_host_threads). */
 int32_t brt_create(const int32_t* device_ids, int32_t n_devices, brt_ctx** out_ctx);
 int32_t brt_destroy(brt_ctx* ctx);
 
