@@ -310,7 +310,7 @@ int32_t build_bvh_sah(const Model* models, uint32_t n_models, float reach, std::
                     sah_keybox_merge(bb[b], box[idx[i]]);
                     bc[b]++;
                 }
-                // cost of splitting after bin s = area(left) * n_left + area(right) * n_right
+                // cost of splitting after bin s = area(left) * w(n_left) + area(right) * w(n_right), w = sah_side_weight
                 for (int s = 0; s + 1 < kSahBins; s++) {
                     SahKeyBox L = sah_keybox_empty(), R = sah_keybox_empty();
                     uint32_t nl = 0, nr = 0;
@@ -319,7 +319,7 @@ int32_t build_bvh_sah(const Model* models, uint32_t n_models, float reach, std::
                         else { sah_keybox_merge(R, bb[b]); nr += bc[b]; }
                     }
                     if (nl == 0 || nr == 0) continue;
-                    const double cost = sah_half_area(L) * (double)nl + sah_half_area(R) * (double)nr;
+                    const double cost = sah_half_area(L) * sah_side_weight(nl, count) + sah_half_area(R) * sah_side_weight(nr, count);
                     if (cost < best_cost) { best_cost = cost; best_axis = k; best_bin = s; }   // strict <: first axis / bin wins ties
                 }
             }

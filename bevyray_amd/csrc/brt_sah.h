@@ -14,8 +14,11 @@
 //     slots per interior node in preorder hands out); left child: rank r + 1, right child: rank r + (left count);
 //   * split position `mid`: halves of the current order, unless a binned-SAH split applies: count > 2, the depth budget is
 //     not exhausted (d + ceil_log2(count) < kSahMaxDepth), and some axis has a finite, positive centroid extent.  16 bins
-//     per axis over the centroid extent of the range; cost of splitting after bin b = area(left) * n_left + area(right) *
-//     n_right in f64; the first (axis, bin) in axis-major order with the smallest cost < DBL_MAX wins; the range is
+//     per axis over the centroid extent of the range; cost of splitting after bin b = area(left) * w(n_left) + area(right) *
+//     w(n_right) in f64, w = sah_side_weight below: the count itself (the textbook surface area heuristic) in a node of up to
+//     kSahDepthWeightMin spheres, a piecewise-linear log2 of it in the larger nodes at the top of the tree (both sides of such a node
+//     are split on many more times, and what a side costs a ray that enters it grows with its DEPTH, not with its count);
+//     the first (axis, bin) in axis-major order with the smallest cost < DBL_MAX wins; the range is
 //     STABLY partitioned by "bin <= b" -- also when the split is then refused because the larger side would not fit the
 //     depth budget (d + 1 + ceil_log2(larger) > kSahMaxDepth), in which case `mid` stays at the halves of the new order.
 #pragma once
@@ -145,6 +148,19 @@ BRT_HD double sah_centroid(const PlocBox& b, int k) {
 BRT_HD int sah_bin(double c, double cmin, double scale) {
     int b = (int)((c - cmin) * scale);
     return b < 0 ? 0 : (b >= kSahBins ? kSahBins - 1 : b);
+}
+// weight of a side of n >= 1 spheres in the split cost of a node of `node_count` spheres.  Large nodes: log2(n) + 2 with log2
+// interpolated linearly between the powers of two -- e + (n / 2^e - 1), every step exact in f64 (integers, a division by a power of
+// two), so the CPU and the GPU builder agree to the bit.  Measured on the GPU over six seeds of the cover and RTIOW scenes and two of
+// the 10 004-sphere grid (1080p, 64 spp, 8 bounces; scripts/exp_tree_cost_seeds.py, profiles/r05/tree_cost_seeds.txt): kernel time
+// -1.3 % / -2.0 % / -2.0 % against the count everywhere; the depth weight in EVERY node -0.5 % / -0.9 % / -1.6 % and config 3 (one
+// 11 064-ray pixel long, in a leaf that ends up one level deeper) +7 %; with the threshold at 256 config 3 +2 %.
+constexpr uint32_t kSahDepthWeightMin = 256;
+BRT_HD double sah_side_weight(uint32_t n, uint32_t node_count) {
+    if (node_count <= kSahDepthWeightMin) return (double)n;
+    uint32_t e = 0;
+    while ((n >> (e + 1u)) != 0u) e++;
+    return (double)e + ((double)n / (double)(1u << e) - 1.0) + 2.0;
 }
 BRT_HD bool sah_axis_usable(double cmin, double cmax) {
     const double ext = cmax - cmin;

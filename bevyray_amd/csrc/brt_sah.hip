@@ -236,7 +236,7 @@ __device__ SplitResult sah_split(const Store& st, BVHNode* out, const SahTask& t
                         else { sah_keybox_merge(R, bb); nr += bins->count[w]; }
                     }
                     if (nl != 0u && nr != 0u) {
-                        const double c = sah_half_area(L) * (double)nl + sah_half_area(R) * (double)nr;
+                        const double c = sah_half_area(L) * sah_side_weight(nl, count) + sah_half_area(R) * sah_side_weight(nr, count);
                         if (c < kSahDblMax) cost = c;          // the winner must beat DBL_MAX (strict), as in the CPU loop
                     }
                 }
@@ -366,7 +366,7 @@ __device__ SplitResult sah_split_lane(const Store& st, BVHNode* out, const SahTa
                     }
                 }
                 if (nl == 0u || nr == 0u) continue;
-                const double cost = sah_half_area(L) * (double)nl + sah_half_area(R) * (double)nr;
+                const double cost = sah_half_area(L) * sah_side_weight(nl, count) + sah_half_area(R) * sah_side_weight(nr, count);
                 // the CPU loop's order is (axis, bin) ascending with a strict <: the axes come in that order here, the bins do not
                 if (cost < best_cost || (cost == best_cost && k == best_axis && s < best_bin)) {
                     best_cost = cost; best_axis = k; best_bin = s; best_nl = nl; best_packed = packed;
