@@ -27,8 +27,12 @@ for scene, seeds, camf in ((brt.SCENE_COVER, range(1, 7), brt.cover_camera), (br
 print("  ".join(out), flush=True)
 '''
 lib = sys.argv[1]
-for kc in sys.argv[2:]:
-    k, c = kc.split()
-    env = dict(os.environ, BRT_LIB_PATH=os.path.abspath(lib), BRT_EXP_KIND=k, BRT_EXP_C=c)
+for spec in sys.argv[2:]:          # "NAME=value NAME=value" (environment of the CPU-twin variant), or the older "kind C"
+    if "=" in spec:
+        extra = dict(kv.split("=", 1) for kv in spec.split())
+    else:
+        k, c = spec.split()
+        extra = {"BRT_EXP_KIND": k, "BRT_EXP_C": c}
+    env = dict(os.environ, BRT_LIB_PATH=os.path.abspath(lib), **extra)
     r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
-    print(f"kind {k} C {c:5s}: cover / rtiow / grid mean ms  {r.stdout.strip() or r.stderr.strip()[-300:]}", flush=True)
+    print(f"{spec:36s}: cover / rtiow / grid mean ms  {r.stdout.strip() or r.stderr.strip()[-300:]}", flush=True)
