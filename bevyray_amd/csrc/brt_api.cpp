@@ -813,6 +813,7 @@ int32_t build_bvh_on_device(brt_ctx* ctx, const Model* models, uint32_t n, bool 
         out->clear();
         return ctx_fail(ctx, BRT_ERR_HIP, "GPU BVH build made no progress after " + std::to_string(info[1]) + " rounds");
     }
+    if (sah) sah_giant_leaves_first(out->data(), (uint32_t)out->size(), models, n);      // (the rule's last step: brt_sah.h)
     float ms = 0.0f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, dc.ev0, dc.ev1));
     if (build_ms) *build_ms = ms;

@@ -346,7 +346,20 @@ int32_t build_bvh_sah(const Model* models, uint32_t n_models, float reach, std::
         todo.push_back({child + 1, mid, j.end, j.depth + 1, j.rank + (mid - j.begin)});
         todo.push_back({child, j.begin, mid, j.depth + 1, j.rank + 1u});
     }
+    sah_giant_leaves_first(out->data(), (uint32_t)out->size(), models, n_models);
     return BRT_OK;
+}
+
+void sah_giant_leaves_first(BVHNode* nodes, uint32_t n_nodes, const Model* models, uint32_t n_models) {
+    auto giant_leaf = [&](const BVHNode& nd) {
+        return nd.model_count == 1u && nd.index < n_models && models[nd.index].radius > 100.0f && std::isfinite(models[nd.index].radius);
+    };
+    for (uint32_t i = 0; i < n_nodes; i++) {
+        if (nodes[i].model_count != 0u) continue;
+        const uint32_t a = nodes[i].index;
+        if (a + 1u >= n_nodes || a + 1u == 0u) continue;
+        if (giant_leaf(nodes[a]) && !giant_leaf(nodes[a + 1u])) std::swap(nodes[a], nodes[a + 1u]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------

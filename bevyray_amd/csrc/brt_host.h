@@ -33,6 +33,9 @@ int32_t validate_and_encode(const Model* models, uint32_t n_models, const Materi
                             const BVHNode* nodes, uint32_t n_nodes, EncodedScene* out, std::string* err);
 int32_t build_bvh_ploc(const Model* models, uint32_t n_models, std::vector<BVHNode>* out);
 int32_t build_bvh_sah(const Model* models, uint32_t n_models, float reach, std::vector<BVHNode>* out);   // binned SAH, same node contract; reach: brt_sah.h
+// last step of the SAH rule (brt_sah.h "giant spheres first"), on the host for both builders: the CPU one calls it itself, the GPU
+// build (brt_api.cpp build_bvh_on_device) on the nodes it has read back
+void sah_giant_leaves_first(BVHNode* nodes, uint32_t n_nodes, const Model* models, uint32_t n_models);
 // the reach a camera needs of the callee-built SAH tree (rule: brt_sah.h "leaf boxes"; used by brt_api.cpp ensure_tree_reach)
 constexpr uint32_t kTreeLevelMax = 80;      // 2 S * 2^20: every pad has long been the reference's 0.1
 struct TreeScene {
