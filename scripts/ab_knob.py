@@ -15,18 +15,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("knob"); ap.add_argument("values", type=int, nargs="+")
     ap.add_argument("--configs", nargs="*", default=["2", "3"]); ap.add_argument("--reps", type=int, default=4)
+    ap.add_argument("--callee-tree", action="store_true", help="upload without a BVH (the callee's SAH tree) instead of the scene's PLOC tree")
+    ap.add_argument("--tunable", action="store_true", help="every value in the knobs-live instantiation (else the default value runs the folded one)")
     a = ap.parse_args()
     with brt.RaytracePlugin([0]) as p:
         for c in a.configs:
             kind, w, h, spp, bounces, cam = CFG[c]
             b = brt.generate_scene(kind, 1)
             lvl, camx, win = (brt.rtiow_camera if cam == "rtiow" else brt.cover_camera)(w, h, spp, bounces)
-            p.node.write_buffers(b)
+            p.node.write_buffers(brt.Buffers(b.models, b.materials, None) if a.callee_tree else b)
             out = p.alloc_frame(w, h)
             ref = None
             for rnd in range(2):
                 for v in a.values:
-                    with p.tuning(**{a.knob: v}):
+                    with p.tuning(**({a.knob: v, "BRT_TUNABLE": 1} if a.tunable else {a.knob: v})):
                         ks = []
                         for _ in range(a.reps + 2):
                             p.node.run(lvl, camx, win, w, h, out=out)
