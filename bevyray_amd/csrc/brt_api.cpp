@@ -32,6 +32,7 @@ uint32_t env_u32(const char* name, uint32_t dflt) {
 // Frame-uniform values with the reference's own expressions (raytrace.wgsl:95,141-153,177-182).
 int32_t make_frame_params(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level, uint32_t width,
                           uint32_t height, uint32_t part, uint32_t n_parts, FrameParams* out) {
+    if (const uint32_t k = ctx->knobs[K_TEST_THROW]) { ctx->knobs.v[K_TEST_THROW] = 0u; throw_for_test(k); }   // (tests: the exception barrier; every brt_render* comes through here)
     if (!camera80 || !window16) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "camera/window is null");
     if (width == 0 || height == 0 || width > 32768u || height > 32768u)
         return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "width/height must be in [1, 32768]");
@@ -861,6 +862,7 @@ uint32_t brt_abi_version(void) { return BRT_ABI_VERSION; }
 const char* brt_last_error(const brt_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
 
 int32_t brt_create(const int32_t* device_ids, int32_t n_devices, brt_ctx** out_ctx) {
+    return guard(nullptr, [&]() -> int32_t {
     if (!out_ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "out_ctx is null");
     *out_ctx = nullptr;
     if (!device_ids || n_devices < 1 || n_devices > 64) return fail(BRT_ERR_INVALID_ARGUMENT, "need 1..64 device ids");
@@ -869,7 +871,13 @@ int32_t brt_create(const int32_t* device_ids, int32_t n_devices, brt_ctx** out_c
     if (e != hipSuccess || count < 1)
         return fail(BRT_ERR_NO_DEVICE, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count 0") +
                                            " (this library has no CPU path)");
-    brt_ctx* ctx = new brt_ctx();
+    brt_ctx* ctx = new (std::nothrow) brt_ctx();
+    if (!ctx) return guard_fail(nullptr, BRT_ERR_OUT_OF_MEMORY, "out of memory");
+    // (anything below that throws -- the vector, a std::string of an error text -- must not leak the context and its device objects)
+    struct Cleanup {
+        brt_ctx* c;
+        ~Cleanup() { if (c) { for (auto& d : c->devs) free_device(d); delete c; } }
+    } cleanup{ctx};
     ctx->devs.resize((size_t)n_devices);
     for (int i = 0; i < n_devices; i++) {
         DeviceCtx& dc = ctx->devs[(size_t)i];
@@ -907,26 +915,29 @@ int32_t brt_create(const int32_t* device_ids, int32_t n_devices, brt_ctx** out_c
         rc = body();
         if (rc != BRT_OK) {
             g_last_error = ctx->last_error;
-            for (auto& d : ctx->devs) free_device(d);
-            delete ctx;
-            return rc;
+            return rc;          // (cleanup frees the devices and the context)
         }
     }
     // tuning knobs from the environment: once, here, and only on request (BRT_ENABLE_TUNING=1)
     if (env_u32("BRT_ENABLE_TUNING", 0) != 0u)
         for (int k = 0; k < K_COUNT; k++) ctx->knobs.v[k] = env_u32(kKnobs[k].name, kKnobs[k].dflt);
+    cleanup.c = nullptr;
     *out_ctx = ctx;
     return BRT_OK;
+    });
 }
 
 int32_t brt_set_policy(brt_ctx* ctx, uint32_t flags) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (flags & ~kPolicyMask) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "unknown policy flag");
     ctx->policy_flags = flags;
     return BRT_OK;
+    });
 }
 
 int32_t brt_set_tuning(brt_ctx* ctx, const char* name, uint32_t value) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!ctx || !name) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
     for (int k = 0; k < K_COUNT; k++)
         if (std::strcmp(name, kKnobs[k].name) == 0) {
@@ -939,9 +950,11 @@ int32_t brt_set_tuning(brt_ctx* ctx, const char* name, uint32_t value) {
             return BRT_OK;
         }
     return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, std::string("unknown tuning knob ") + name);
+    });
 }
 
 int32_t brt_get_tuning(const brt_ctx* ctx, const char* name, uint32_t* out_value, uint32_t* out_default) {
+    return guard(nullptr, [&]() -> int32_t {
     if (!ctx || !name) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
     for (int k = 0; k < K_COUNT; k++)
         if (std::strcmp(name, kKnobs[k].name) == 0) {
@@ -950,9 +963,11 @@ int32_t brt_get_tuning(const brt_ctx* ctx, const char* name, uint32_t* out_value
             return BRT_OK;
         }
     return fail(BRT_ERR_INVALID_ARGUMENT, std::string("unknown tuning knob ") + name);
+    });
 }
 
 int32_t brt_host_alloc(brt_ctx* ctx, uint64_t bytes, void** out_ptr) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!ctx || !out_ptr || bytes == 0) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer / zero size");
     *out_ptr = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->devs[0].device));
@@ -961,9 +976,11 @@ int32_t brt_host_alloc(brt_ctx* ctx, uint64_t bytes, void** out_ptr) {
     ctx->pinned.emplace_back(static_cast<char*>(p), (size_t)bytes);
     *out_ptr = p;
     return BRT_OK;
+    });
 }
 
 int32_t brt_host_free(brt_ctx* ctx, void* ptr) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     for (size_t i = 0; i < ctx->pinned.size(); i++)
         if (ctx->pinned[i].first == ptr) {
@@ -972,21 +989,26 @@ int32_t brt_host_free(brt_ctx* ctx, void* ptr) {
             return BRT_OK;
         }
     return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "pointer was not allocated by brt_host_alloc");
+    });
 }
 
 int32_t brt_destroy(brt_ctx* ctx) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!ctx) return BRT_OK;
     release_external_frames(ctx);
     for (auto& b : ctx->pinned) (void)hipHostFree(b.first);
     for (auto& d : ctx->devs) free_device(d);
     delete ctx;
     return BRT_OK;
+    });
 }
 
 int32_t brt_upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, const void* materials, uint32_t n_materials,
                          const void* bvh_nodes, uint32_t n_nodes) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     return upload_scene(ctx, models, n_models, materials, n_materials, bvh_nodes, n_nodes, 0u, false);
+    });
 }
 
 }  // extern "C"
@@ -997,6 +1019,7 @@ namespace {
 // leaf pads cover a longer reach (ensure_tree_reach): the dispatch-order history and the dirty-tracking state stay as they are.
 int32_t upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, const void* materials, uint32_t n_materials,
                      const void* bvh_nodes, uint32_t n_nodes, uint32_t level, bool rebuild) {
+    if (const uint32_t k = ctx->knobs[K_TEST_THROW]) { ctx->knobs.v[K_TEST_THROW] = 0u; throw_for_test(k); }   // (tests: the exception barrier)
     // Dirty tracking (the reference re-uploads everything every frame, README.md:17 lists that as
     // future work): identical bytes as the last successful upload -> nothing to do, and the tile-cost
     // history stays valid.  BRT_NO_DIRTY_TRACKING=1 disables.
@@ -1541,6 +1564,7 @@ extern "C" {
 
 int32_t brt_render(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level, uint32_t width, uint32_t height,
                    const float* raster_rgba, const float* raster_depth, float* out_rgba, uint32_t flags, brt_stats* stats) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (!out_rgba) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "out_rgba is null");
     if (!ctx->has_scene && level != 0u) return ctx_fail(ctx, BRT_ERR_NO_SCENE, "brt_upload_scene has not succeeded yet");
@@ -1551,12 +1575,14 @@ int32_t brt_render(brt_ctx* ctx, const void* camera80, const void* window16, uin
     if (rc != BRT_OK) drain_all_streams(ctx);
     else tree_stats(ctx, rebuilt, stats);
     return rc;
+    });
 }
 
 int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level, uint32_t width,
                                uint32_t height, uint32_t part, uint32_t n_parts, const float* d_raster_rgba,
                                const float* d_raster_depth, float* d_out_tile, void* hip_stream, uint32_t flags,
                                brt_stats* stats) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (!d_out_tile) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "d_out_tile is null");
     if (!ctx->has_scene && level != 0u) return ctx_fail(ctx, BRT_ERR_NO_SCENE, "brt_upload_scene has not succeeded yet");
@@ -1569,11 +1595,13 @@ int32_t brt_render_part_device(brt_ctx* ctx, const void* camera80, const void* w
     if (rc != BRT_OK) drain_all_streams(ctx);
     else tree_stats(ctx, rebuilt, stats);
     return rc;
+    });
 }
 
 int32_t brt_render_device(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level, uint32_t width, uint32_t height,
                           const float* d_raster_rgba, const float* d_raster_depth, void* d_frame, void* hip_stream, uint32_t flags,
                           brt_stats* stats) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (!d_frame) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "d_frame is null");
     if (!ctx->has_scene && level != 0u) return ctx_fail(ctx, BRT_ERR_NO_SCENE, "brt_upload_scene has not succeeded yet");
@@ -1585,10 +1613,12 @@ int32_t brt_render_device(brt_ctx* ctx, const void* camera80, const void* window
     if (rc != BRT_OK) drain_all_streams(ctx);
     else tree_stats(ctx, rebuilt, stats);
     return rc;
+    });
 }
 
 int32_t brt_deinterleave_device(brt_ctx* ctx, const float* d_tiles, uint32_t n_parts, uint32_t width, uint32_t height,
                                 void* d_frame, void* hip_stream, uint32_t flags) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (!d_tiles || !d_frame || n_parts == 0) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "null buffer / n_parts == 0");
     DeviceCtx& dc = ctx->devs[0];
@@ -1598,10 +1628,12 @@ int32_t brt_deinterleave_device(brt_ctx* ctx, const float* d_tiles, uint32_t n_p
     HIP_TRY(ctx, launch_deinterleave(d_tiles, d_frame, width, height, n_parts, brt_tile_rows(height, n_parts), flags & BRT_FLAG_OUT_MASK, stream));
     if (own_stream) HIP_TRY(ctx, hipStreamSynchronize(stream));
     return BRT_OK;
+    });
 }
 
 int32_t brt_build_bvh_device(brt_ctx* ctx, const void* models, uint32_t n_models, void* out_nodes, uint32_t capacity,
                              uint32_t* out_n_nodes, double* out_build_ms) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (!out_n_nodes) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "out_n_nodes is null");
     *out_n_nodes = 0;
@@ -1615,10 +1647,12 @@ int32_t brt_build_bvh_device(brt_ctx* ctx, const void* models, uint32_t n_models
         return ctx_fail(ctx, BRT_ERR_CAPACITY, "BVH needs " + std::to_string(nodes.size()) + " nodes, capacity " + std::to_string(capacity));
     std::memcpy(out_nodes, nodes.data(), nodes.size() * sizeof(BVHNode));
     return BRT_OK;
+    });
 }
 
 int32_t brt_build_bvh_sah_device(brt_ctx* ctx, const void* models, uint32_t n_models, float reach, void* out_nodes, uint32_t capacity,
                                  uint32_t* out_n_nodes, double* out_build_ms) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (!out_n_nodes) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "out_n_nodes is null");
     *out_n_nodes = 0;
@@ -1632,9 +1666,11 @@ int32_t brt_build_bvh_sah_device(brt_ctx* ctx, const void* models, uint32_t n_mo
         return ctx_fail(ctx, BRT_ERR_CAPACITY, "BVH needs " + std::to_string(nodes.size()) + " nodes, capacity " + std::to_string(capacity));
     std::memcpy(out_nodes, nodes.data(), nodes.size() * sizeof(BVHNode));
     return BRT_OK;
+    });
 }
 
 int32_t brt_debug_profile(brt_ctx* ctx, uint64_t* out64) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!ctx || !out64) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
     DeviceCtx& dc = ctx->devs[0];
     HIP_TRY(ctx, hipSetDevice(dc.device));
@@ -1651,11 +1687,13 @@ int32_t brt_debug_profile(brt_ctx* ctx, uint64_t* out64) {
         out64[42] = meta[3];
     }
     return BRT_OK;
+    });
 }
 
 int32_t brt_debug_tile_order(brt_ctx* ctx, const uint32_t* ray_sum, const uint32_t* longest_pixel, uint32_t n_tiles,
                              uint32_t sample_count, uint64_t grid_lanes, uint32_t tiles_x, uint32_t dilate, uint32_t split_tail,
                              uint32_t* out_order, uint32_t* out_info4) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (!ray_sum || !longest_pixel || !out_order || !out_info4 || n_tiles == 0) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "null buffer / no tiles");
     if (dilate != 0u && (tiles_x == 0u || n_tiles % tiles_x != 0u)) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "dilate needs a tiles_x that divides n_tiles");
@@ -1685,9 +1723,11 @@ int32_t brt_debug_tile_order(brt_ctx* ctx, const uint32_t* ray_sum, const uint32
     if (d_meta) (void)hipFree(d_meta);
     if (d_scratch) (void)hipFree(d_scratch);
     return rc;
+    });
 }
 
 int32_t brt_debug_eval(brt_ctx* ctx, uint32_t op, const float* in16, float* out8, uint32_t n) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (!in16 || !out8) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "null buffer");
     if (n == 0) return BRT_OK;
@@ -1710,6 +1750,7 @@ int32_t brt_debug_eval(brt_ctx* ctx, uint32_t op, const float* in16, float* out8
     (void)hipFree(d_in);
     (void)hipFree(d_out);
     return rc;
+    });
 }
 
 }  // extern "C"

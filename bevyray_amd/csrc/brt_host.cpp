@@ -24,6 +24,26 @@ int32_t fail(int32_t code, const std::string& msg) {
     return code;
 }
 
+int32_t guard_fail(std::string* ctx_error, int32_t code, const char* what) noexcept {
+    // (an assignment that fits the string's capacity -- at least the in-place buffer of 15 characters -- does not allocate)
+    auto put = [&](std::string& dst) noexcept {
+        try {
+            dst.assign(what ? what : "?");
+        } catch (...) {
+            try { dst.assign(code == BRT_ERR_OUT_OF_MEMORY ? "out of memory" : "internal error"); } catch (...) {}
+        }
+    };
+    put(g_last_error);
+    if (ctx_error) put(*ctx_error);
+    return code;
+}
+
+void throw_for_test(uint32_t kind) {
+    if (kind == 1u) throw std::bad_alloc();
+    if (kind == 2u) throw std::logic_error("BRT_TEST_THROW: logic_error");
+    throw 42;
+}
+
 // ---------------------------------------------------------------------------------------
 // Validation + encoding
 // ---------------------------------------------------------------------------------------
@@ -653,6 +673,7 @@ using namespace brt;
 extern "C" {
 
 int32_t brt_build_bvh(const void* models, uint32_t n_models, void* out_nodes, uint32_t capacity, uint32_t* out_n_nodes) {
+    return guard(nullptr, [&]() -> int32_t {
     if (!out_n_nodes) return fail(BRT_ERR_INVALID_ARGUMENT, "out_n_nodes is null");
     *out_n_nodes = 0;
     if (n_models == 0) return BRT_OK;
@@ -665,9 +686,11 @@ int32_t brt_build_bvh(const void* models, uint32_t n_models, void* out_nodes, ui
         return fail(BRT_ERR_CAPACITY, "BVH needs " + std::to_string(nodes.size()) + " nodes, capacity " + std::to_string(capacity));
     std::memcpy(out_nodes, nodes.data(), nodes.size() * sizeof(BVHNode));
     return BRT_OK;
+    });
 }
 
 int32_t brt_build_bvh_sah(const void* models, uint32_t n_models, float reach, void* out_nodes, uint32_t capacity, uint32_t* out_n_nodes) {
+    return guard(nullptr, [&]() -> int32_t {
     if (!out_n_nodes) return fail(BRT_ERR_INVALID_ARGUMENT, "out_n_nodes is null");
     *out_n_nodes = 0;
     if (n_models == 0) return BRT_OK;
@@ -680,16 +703,20 @@ int32_t brt_build_bvh_sah(const void* models, uint32_t n_models, float reach, vo
         return fail(BRT_ERR_CAPACITY, "BVH needs " + std::to_string(nodes.size()) + " nodes, capacity " + std::to_string(capacity));
     std::memcpy(out_nodes, nodes.data(), nodes.size() * sizeof(BVHNode));
     return BRT_OK;
+    });
 }
 
 int32_t brt_host_srgb_thresholds(float* out255) {
+    return guard(nullptr, [&]() -> int32_t {
     if (!out255) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
     std::memcpy(out255, kSrgbThreshold, sizeof kSrgbThreshold);
     return BRT_OK;
+    });
 }
 
 int32_t brt_host_tree_reach(const void* models, uint32_t n_models, const void* camera80, float* out_scene_scale, uint32_t* out_level,
                             float* out_reach) {
+    return guard(nullptr, [&]() -> int32_t {
     if ((!models && n_models != 0u) || !camera80) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
     const TreeScene t = tree_scene_of((const Model*)models, n_models);
     Camera cam;
@@ -700,10 +727,12 @@ int32_t brt_host_tree_reach(const void* models, uint32_t n_models, const void* c
     if (out_level) *out_level = level;
     if (out_reach) *out_reach = tree_reach_of(t.scale, level);
     return BRT_OK;
+    });
 }
 
 int32_t brt_validate_scene(const void* models, uint32_t n_models, const void* materials, uint32_t n_materials,
                            const void* bvh_nodes, uint32_t n_nodes, uint32_t* out_max_depth) {
+    return guard(nullptr, [&]() -> int32_t {
     EncodedScene e;
     std::string err;
     int32_t rc = validate_and_encode((const Model*)models, n_models, (const Material*)materials, n_materials,
@@ -711,10 +740,12 @@ int32_t brt_validate_scene(const void* models, uint32_t n_models, const void* ma
     if (rc != BRT_OK) return fail(rc, err);
     if (out_max_depth) *out_max_depth = e.max_leaf_depth;
     return BRT_OK;
+    });
 }
 
 int32_t brt_scene_generate(uint32_t kind, uint64_t seed, void* out_models, void* out_materials, uint32_t capacity,
                            uint32_t* out_n_models) {
+    return guard(nullptr, [&]() -> int32_t {
     if (!out_n_models) return fail(BRT_ERR_INVALID_ARGUMENT, "out_n_models is null");
     std::vector<Model> models;
     std::vector<Material> materials;
@@ -726,12 +757,14 @@ int32_t brt_scene_generate(uint32_t kind, uint64_t seed, void* out_models, void*
     std::memcpy(out_models, models.data(), models.size() * sizeof(Model));
     std::memcpy(out_materials, materials.data(), materials.size() * sizeof(Material));
     return BRT_OK;
+    });
 }
 
 // CameraExtract::extract_component (extract.rs:118-157) for
 // Transform::from_translation(t).looking_at(target, up): direction = forward(), up = up().
 int32_t brt_host_camera_extract(const float* t, const float* target, const float* up, float fov, float aspect_ratio,
                                 float near_, float far_, uint32_t sample_count, uint32_t bounces, void* out_camera80) {
+    return guard(nullptr, [&]() -> int32_t {
     if (!t || !target || !up || !out_camera80) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
     auto norm = [](float* v) { float l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); v[0] /= l; v[1] /= l; v[2] /= l; };
     float back[3] = {t[0] - target[0], t[1] - target[1], t[2] - target[2]};
@@ -748,9 +781,11 @@ int32_t brt_host_camera_extract(const float* t, const float* target, const float
     for (int k = 0; k < 3; k++) { c.position[k] = t[k]; c.direction[k] = -back[k]; c.up[k] = up2[k]; }
     std::memcpy(out_camera80, &c, sizeof c);
     return BRT_OK;
+    });
 }
 
 int32_t brt_host_window_extract(float random_seed, uint32_t physical_height, void* out_window16) {
+    return guard(nullptr, [&]() -> int32_t {
     if (!out_window16) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
     Window w;
     std::memset(&w, 0, sizeof w);
@@ -758,10 +793,12 @@ int32_t brt_host_window_extract(float random_seed, uint32_t physical_height, voi
     w.height = physical_height;
     std::memcpy(out_window16, &w, sizeof w);
     return BRT_OK;
+    });
 }
 
 int32_t brt_host_material(const float* base_color_srgb3, float metallic, float perceptual_roughness, float reflectance,
                           float ior, float specular_transmission, void* out_material32) {
+    return guard(nullptr, [&]() -> int32_t {
     if (!base_color_srgb3 || !out_material32) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
     StdMat m;
     for (int k = 0; k < 3; k++) m.base[k] = base_color_srgb3[k];
@@ -770,11 +807,13 @@ int32_t brt_host_material(const float* base_color_srgb3, float metallic, float p
     Material r = prepare_asset(m);
     std::memcpy(out_material32, &r, sizeof r);
     return BRT_OK;
+    });
 }
 
 int32_t brt_host_tile_order(const uint32_t* ray_sum, const uint32_t* longest_pixel, uint32_t n_tiles, uint32_t sample_count,
                             uint64_t grid_lanes, uint32_t sorted, uint32_t lane_permille, uint32_t tiles_x, uint32_t dilate,
                             uint32_t split_tail, uint32_t* out_order, uint32_t* out_info5) {
+    return guard(nullptr, [&]() -> int32_t {
     if (!ray_sum || !longest_pixel || !out_order || !out_info5) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
     if (dilate != 0u && (tiles_x == 0u || n_tiles % tiles_x != 0u)) return fail(BRT_ERR_INVALID_ARGUMENT, "dilate needs a tiles_x that divides n_tiles");
     TileOrderParams tp{};
@@ -787,6 +826,7 @@ int32_t brt_host_tile_order(const uint32_t* ray_sum, const uint32_t* longest_pix
     out_info5[0] = to.n_lane; out_info5[1] = to.n_critical; out_info5[2] = to.longest_pixel;
     out_info5[3] = to.n_nonsky; out_info5[4] = to.n_split;
     return BRT_OK;
+    });
 }
 
 }  // extern "C"

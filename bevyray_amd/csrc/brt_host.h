@@ -1,6 +1,8 @@
 // brt_host.h -- internal interface of the host-side (CPU) parts; see brt_host.cpp.
 #pragma once
 #include <cstdint>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -11,6 +13,29 @@ namespace brt {
 
 extern thread_local std::string g_last_error;
 int32_t fail(int32_t code, const std::string& msg);
+
+// Exception barrier of the C ABI (include/bevyray_amd.h: "none throws or aborts across the boundary"; the reference's node returns
+// Ok(()) and skips the pass on every failure, pipeline.rs:82-85).  Every extern "C" body runs inside guard(): an exception -- in
+// practice std::bad_alloc from a std::vector / std::string of the host side -- becomes an error code and a brt_last_error text
+// instead of unwinding into the (Rust) caller, which would be undefined behaviour.  guard_fail itself cannot throw: the texts
+// it stores fit std::string's in-place buffer or are truncated to it when even that assignment fails.
+int32_t guard_fail(std::string* ctx_error, int32_t code, const char* what) noexcept;
+template <class F>
+inline int32_t guard(std::string* ctx_error, F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return guard_fail(ctx_error, BRT_ERR_OUT_OF_MEMORY, "out of memory");
+    } catch (const std::exception& e) {
+        return guard_fail(ctx_error, BRT_ERR_INTERNAL, e.what());
+    } catch (...) {
+        return guard_fail(ctx_error, BRT_ERR_INTERNAL, "unknown error");
+    }
+}
+// test hook: throws what `kind` names (1 std::bad_alloc, 2 std::logic_error, 3 a non-standard type); brt_api.cpp calls it from
+// brt_upload_scene / brt_render* when the tuning knob BRT_TEST_THROW is set (and clears the knob), so that the GPU suite can
+// force an exception through the barrier of exports that own a context
+[[noreturn]] void throw_for_test(uint32_t kind);
 
 // Scene in the device encoding (brt_layout.h), still in host vectors.
 struct EncodedScene {

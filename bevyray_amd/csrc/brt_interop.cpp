@@ -137,6 +137,7 @@ void release_external_frames(brt_ctx* ctx) {
 extern "C" {
 
 int32_t brt_rccl_unique_id(void* out_id128) {
+    return guard(nullptr, [&]() -> int32_t {
     if (!out_id128) return fail(BRT_ERR_INVALID_ARGUMENT, "out_id128 is null");
     Rccl& r = rccl();
     if (!r.lib) return fail(BRT_ERR_RCCL, r.why);
@@ -145,9 +146,11 @@ int32_t brt_rccl_unique_id(void* out_id128) {
     if (rc != 0) return nccl_fail(nullptr, "ncclGetUniqueId", rc);
     std::memcpy(out_id128, &id, sizeof id);
     return BRT_OK;
+    });
 }
 
 int32_t brt_rccl_comm_create(brt_ctx* ctx, const void* id128, int32_t rank, int32_t world, void** out_comm) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!ctx || !id128 || !out_comm) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
     *out_comm = nullptr;
     if (world < 1 || rank < 0 || rank >= world) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "rank / world out of range");
@@ -161,19 +164,23 @@ int32_t brt_rccl_comm_create(brt_ctx* ctx, const void* id128, int32_t rank, int3
     if (rc != 0) return nccl_fail(ctx, "ncclCommInitRank", rc);
     *out_comm = comm;
     return BRT_OK;
+    });
 }
 
 int32_t brt_rccl_comm_destroy(brt_ctx* ctx, void* comm) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!comm) return BRT_OK;
     Rccl& r = rccl();
     if (!r.lib) return ctx_fail(ctx, BRT_ERR_RCCL, r.why);
     if (ctx) HIP_TRY(ctx, hipSetDevice(ctx->devs[0].device));
     const int rc = r.comm_destroy(comm);
     return rc == 0 ? BRT_OK : nccl_fail(ctx, "ncclCommDestroy", rc);
+    });
 }
 
 int32_t brt_gather_rccl(brt_ctx* ctx, void* nccl_comm, int32_t rank, int32_t world, const float* d_tile, float* d_tiles_on_root,
                         uint32_t width, uint32_t height, void* d_frame_on_root, void* hip_stream, uint32_t flags) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (!nccl_comm || !d_tile) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "null communicator / tile");
     if (world < 1 || rank < 0 || rank >= world) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "rank / world out of range");
@@ -193,9 +200,11 @@ int32_t brt_gather_rccl(brt_ctx* ctx, void* nccl_comm, int32_t rank, int32_t wor
         HIP_TRY(ctx, launch_deinterleave(d_tiles_on_root, d_frame_on_root, width, height, (uint32_t)world, tile_rows, flags & BRT_FLAG_OUT_MASK, stream));
     if (own_stream) HIP_TRY(ctx, hipStreamSynchronize(stream));
     return BRT_OK;
+    });
 }
 
 int32_t brt_import_frame_fd(brt_ctx* ctx, int32_t fd, uint64_t bytes, uint32_t handle_type, void** out_d_frame) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!ctx || !out_d_frame) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
     *out_d_frame = nullptr;
     if (fd < 0 || bytes == 0) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "bad file descriptor / zero size");
@@ -252,9 +261,11 @@ int32_t brt_import_frame_fd(brt_ctx* ctx, int32_t fd, uint64_t bytes, uint32_t h
     ctx->external.push_back(f);
     *out_d_frame = f.ptr;
     return BRT_OK;
+    });
 }
 
 int32_t brt_release_frame(brt_ctx* ctx, void* d_frame) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
     for (size_t i = 0; i < ctx->external.size(); i++)
         if (ctx->external[i].ptr == d_frame) {
@@ -268,9 +279,11 @@ int32_t brt_release_frame(brt_ctx* ctx, void* d_frame) {
             return BRT_OK;
         }
     return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "pointer was not returned by brt_import_frame_fd / brt_debug_export_frame_fd");
+    });
 }
 
 int32_t brt_debug_export_frame_fd(brt_ctx* ctx, uint64_t bytes, int32_t* out_fd, void** out_d_ptr) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!ctx || !out_fd || !out_d_ptr || bytes == 0) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer / zero size");
     *out_fd = -1;
     *out_d_ptr = nullptr;
@@ -299,13 +312,16 @@ int32_t brt_debug_export_frame_fd(brt_ctx* ctx, uint64_t bytes, int32_t* out_fd,
     *out_fd = fd;
     *out_d_ptr = f.ptr;
     return BRT_OK;
+    });
 }
 
 int32_t brt_debug_copy_to_host(brt_ctx* ctx, const void* d_src, void* h_dst, uint64_t bytes) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
     if (!ctx || !d_src || !h_dst) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer");
     HIP_TRY(ctx, hipSetDevice(ctx->devs[0].device));
     HIP_TRY(ctx, hipMemcpy(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost));
     return BRT_OK;
+    });
 }
 
 }  // extern "C"

@@ -12,7 +12,9 @@
  *
  * Conventions
  *   - Every function returns int32: BRT_OK (0) or a negative BRT_ERR_* code; none
- *     throws or aborts across the boundary.  brt_last_error() gives the text.
+ *     throws or aborts across the boundary (every export body runs inside an exception
+ *     barrier: a failed host allocation is BRT_ERR_OUT_OF_MEMORY, anything else
+ *     BRT_ERR_INTERNAL).  brt_last_error() gives the text.
  *     (Reference: every "not ready" condition returns Ok(()) and skips the pass,
  *     pipeline.rs:82-85,89-102,113-115,141-151; the Rust side maps non-zero to a
  *     logged warning + Ok(()).)
@@ -59,7 +61,9 @@ enum {
     BRT_ERR_NO_SCENE = -7,         /* render before upload */
     BRT_ERR_UNSUPPORTED = -8,      /* e.g. orthographic projection (extract.rs:148) */
     BRT_ERR_CAPACITY = -9,         /* caller buffer too small */
-    BRT_ERR_RCCL = -10             /* librccl could not be loaded, or an RCCL call failed; text in brt_last_error */
+    BRT_ERR_RCCL = -10,            /* librccl could not be loaded, or an RCCL call failed; text in brt_last_error */
+    BRT_ERR_OUT_OF_MEMORY = -11,   /* a host allocation failed (std::bad_alloc caught at the boundary); the context stays usable */
+    BRT_ERR_INTERNAL = -12         /* any other exception caught at the boundary; text in brt_last_error */
 };
 
 /* Raytracing level, reference src/raytracing/mod.rs:94-101 (#[repr(u32)]). */

@@ -494,3 +494,45 @@ def test_srgb_store_thresholds_and_the_oracle_formula_agree_at_every_decision_po
     before = open(header).read()
     subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_srgb_table.py")], check=True, capture_output=True)
     assert open(header).read() == before
+
+
+_OOM_CHILD = r'''
+import ctypes as C, resource, sys
+import numpy as np
+from bevyray_amd import _lib
+lib = _lib.load()
+n = int(sys.argv[1])
+rng = np.random.default_rng(7)
+models = np.zeros((n, 8), np.float32)
+models[:, 0:3] = rng.uniform(-100, 100, (n, 3)).astype(np.float32)
+models[:, 3] = 0.2
+vm = 0
+for ln in open("/proc/self/status"):
+    if ln.startswith("VmSize:"):
+        vm = int(ln.split()[1]) * 1024
+# the builders need (2 n - 1) x 48 bytes for the nodes alone: leave them 32 MB of address space
+resource.setrlimit(resource.RLIMIT_AS, (vm + (32 << 20), resource.RLIM_INFINITY))
+n_nodes = C.c_uint32(123)
+for name, args in (("brt_build_bvh_sah", (C.c_float(0.0),)), ("brt_build_bvh", ())):
+    rc = getattr(lib, name)(models.ctypes.data, n, *args, None, 0, C.byref(n_nodes))
+    print(name, rc, lib.brt_last_error(None).decode(), n_nodes.value, flush=True)
+# the library is still usable afterwards
+resource.setrlimit(resource.RLIMIT_AS, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
+out = np.zeros((19, 12), np.uint32)
+rc = lib.brt_build_bvh_sah(models.ctypes.data, 10, C.c_float(0.0), out.ctypes.data, 19, C.byref(n_nodes))
+print("after", rc, n_nodes.value, flush=True)
+'''
+
+
+def test_exception_barrier_turns_a_failed_host_allocation_into_an_error_code():
+    """include/bevyray_amd.h: no export throws across the boundary (pipeline.rs:82-85: the node skips the pass).  A child process whose
+    address space is capped lets the two host builders run out of memory on 3 M spheres: BRT_ERR_OUT_OF_MEMORY + text, no abort."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", _OOM_CHILD, "3000000"], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert lines[0].split()[:2] == ["brt_build_bvh_sah", "-11"] and "out of memory" in lines[0], r.stdout
+    assert lines[1].split()[:2] == ["brt_build_bvh", "-11"] and "out of memory" in lines[1], r.stdout
+    assert lines[0].split()[-1] == "0" and lines[1].split()[-1] == "0"        # out_n_nodes was reset before the failure
+    assert lines[2] == "after 0 19", r.stdout

@@ -364,6 +364,28 @@ def test_error_behaviour(plugin):
         plugin.node.run(lvl, cam, win, 0, 18)
 
 
+def test_exception_barrier_on_exports_that_own_a_context(plugin, oracle):
+    """include/bevyray_amd.h: no export throws across the boundary.  The knob BRT_TEST_THROW makes the next brt_upload_scene / brt_render*
+    throw std::bad_alloc (1), std::logic_error (2) or a non-standard type (3) from inside the call: an error code and a text come back,
+    the context stays usable and the next frame is the oracle's."""
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    w, h = 64, 40
+    lvl, cam, win = brt.cover_camera(w, h, 2, 3)
+    plugin.node.write_buffers(b)
+    for kind, code, text in ((1, -11, "out of memory"), (2, -12, "logic_error"), (3, -12, "unknown error")):
+        plugin.set_tuning("BRT_TEST_THROW", kind)
+        with pytest.raises(brt.BrtError) as e:
+            plugin.node.run(lvl, cam, win, w, h)
+        assert e.value.code == code and text in str(e.value), (kind, e.value.code, str(e.value))
+        assert plugin.get_tuning("BRT_TEST_THROW")[0] == 0
+    plugin.set_tuning("BRT_TEST_THROW", 1)
+    changed = b.models.copy(); changed["radius"][5] *= 1.5
+    with pytest.raises(brt.BrtError) as e:                      # through brt_upload_scene (the bytes differ: no dirty-tracking shortcut)
+        plugin.node.write_buffers(brt.Buffers(changed, b.materials, None))
+    assert e.value.code == -11 and "out of memory" in str(e.value)
+    render_both(plugin, oracle, b, lvl, cam, win, w, h)
+
+
 # ---- strips / devices ---------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("n_parts", [2, 3, 8])
@@ -471,6 +493,22 @@ def test_render_device_over_two_gpus(oracle):
 
 # ---- BASELINE.json full size: size-independent properties + sampled rows --------------------------------------
 
+def _timed_combination(plugin, b, lvl, cam, win, w, h, want, rays):
+    """The exact combination bench.py times, against the oracle frame the caller already has: the tree the CALLEE builds (bvh = None),
+    no flags, and the steady state of the view -- after the frames that measure (first frame of a view, a few frames after an upload)
+    the dispatch order is the learned one, the tail runs as half-sample jobs and the production LEAN instantiation (hand-written walk
+    loops and sampler) renders.  EVERY one of the six frames: whole frame + ray count."""
+    bb = brt.Buffers(b.models, b.materials, None)
+    st = None
+    for i in range(6):
+        f = plugin.node.run(lvl, cam, win, w, h, buffers=bb if i == 0 else None)
+        st = dict(plugin.node.last_stats)
+        assert st["rays"] == rays, (i, st["rays"], rays)
+        assert_frames_equal(f, want)
+    assert st["kernel_variant"] in (1, 2) and st["measured_tile_costs"] == 0, st       # LEAN instantiation, nothing measured: the timed state
+    return st
+
+
 def test_config2_full_size_properties(plugin, oracle):
     b = brt.generate_scene(brt.SCENE_COVER, 1)
     w, h, spp, bounces = 1920, 1080, 64, 8
@@ -491,6 +529,8 @@ def test_config2_full_size_properties(plugin, oracle):
     assert_frames_equal(f3, want)
     _, cnt3 = oracle.render(brt.Buffers(b.models, b.materials, brt.build_bvh_sah(b.models)), lvl, cam, win, w, h)
     assert {k: s3[k] for k in COUNTER_KEYS} == cnt3
+    st = _timed_combination(plugin, b, lvl, cam, win, w, h, want, cnt["rays"])
+    assert st["kernel_variant"] == 2 and st["scene_in_lds"] == 1
 
 
 def _frame_properties(f, stats, w, h, spp, bounces, n_px=None):
@@ -514,6 +554,7 @@ def test_config3_rtiow_full_size(plugin, oracle):
     want, cnt = oracle.render(b, lvl, cam, win, w, h)
     assert s1["rays"] == cnt["rays"]
     assert_frames_equal(f1, want)
+    _timed_combination(plugin, b, lvl, cam, win, w, h, want, cnt["rays"])
 
 
 @pytest.mark.parametrize("part", [0, 7])
@@ -568,6 +609,8 @@ def test_config5_10k_spheres_full_size(plugin, oracle):
     assert_frames_equal(want3, want)
     assert {k: s3[k] for k in COUNTER_KEYS} == cnt3
     assert cnt3["interior_visits"] < 0.85 * cnt["interior_visits"]
+    st = _timed_combination(plugin, b, lvl, cam, win, w, h, want, cnt["rays"])
+    assert st["scene_in_lds"] == 2 and st["hot_records"] != 0      # the top of the tree in the LDS tile, records numbered by use
 
 
 # ---- GPU BVH build --------------------------------------------------------------------
