@@ -241,6 +241,11 @@ BRT_DEV void ball_loop_asm(uint32_t& rng, f3& acc, float rough, uint64_t m2, uin
     "v_xor_b32_e32 %[rng], %[t], %[rng]\n"                                                                                  \
     "v_cvt_f32_u32_e32 " dst ", %[rng]\n"                                                                                  \
     "v_fma_f32 " dst ", " dst ", %[c_2m31], -1.0\n"       /* rng_ball_coord: 2 * (state * 2^-32) - 1, rounded once */
+#ifdef BRT_EXP_BALL_FREE       /* experiment (wrong pixels): every candidate is accepted -- what a rejection sampler that costs nothing would buy */
+#define BRT_BALL_ACCEPT "v_cmp_ge_f32_e32 vcc, 1.0, %[q]\n s_mov_b64 vcc, exec\n"
+#else
+#define BRT_BALL_ACCEPT "v_cmp_ge_f32_e32 vcc, 1.0, %[q]\n"                 /* accepted (inactive lanes: 0) */
+#endif
 #define BRT_BALL_ITERATION                                                                                                  \
         BRT_RNG_DRAW("%[x]")                                                                                                \
         BRT_RNG_DRAW("%[y]")                                                                                                \
@@ -250,7 +255,7 @@ BRT_DEV void ball_loop_asm(uint32_t& rng, f3& acc, float rough, uint64_t m2, uin
         "v_add_f32_e32 %[q], %[q], %[r]\n"                                                                                  \
         "v_mul_f32_e32 %[r], %[z], %[z]\n"                                                                                  \
         "v_add_f32_e32 %[q], %[q], %[r]\n"                                                                                  \
-        "v_cmp_ge_f32_e32 vcc, 1.0, %[q]\n"                 /* accepted (inactive lanes: 0) */                             \
+        BRT_BALL_ACCEPT                                                                                                     \
         "s_and_b64 %[s_up], %[m2], vcc\n"                   /* two needed -> one */                                        \
         "s_andn2_b64 %[m1], %[m1], vcc\n"                   /* one needed -> none */                                       \
         "s_andn2_b64 %[m2], %[m2], vcc\n"                                                                                   \
@@ -299,6 +304,7 @@ BRT_DEV void ball_loop_asm(uint32_t& rng, f3& acc, float rough, uint64_t m2, uin
 #endif
 #undef BRT_COUNT_BALL
 #undef BRT_BALL_ITERATION
+#undef BRT_BALL_ACCEPT
 #undef BRT_RNG_DRAW
 #endif
 }

@@ -554,7 +554,13 @@ def test_config3_rtiow_full_size(plugin, oracle):
     want, cnt = oracle.render(b, lvl, cam, win, w, h)
     assert s1["rays"] == cnt["rays"]
     assert_frames_equal(f1, want)
-    _timed_combination(plugin, b, lvl, cam, win, w, h, want, cnt["rays"])
+    # what bench.py times -- the callee-built tree, no flags, steady state -- against the oracle ON THAT TREE (a second pass of the
+    # oracle).  The two trees' frames differ in ONE pixel here, (704, 396): its 205th ray meets spheres 166 and 482 at the same f32
+    # distance 16.89793, an exact tie that the strict `<` of raytrace.wgsl:353 gives to whichever sphere the walk reaches first --
+    # topology dependent in the reference too (brute force in model order sides with the caller's tree).
+    want_sah, cnt_sah = oracle.render(brt.Buffers(b.models, b.materials, brt.build_bvh_sah(b.models)), lvl, cam, win, w, h)
+    assert int((want_sah.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum()) <= 1
+    _timed_combination(plugin, b, lvl, cam, win, w, h, want_sah, cnt_sah["rays"])
 
 
 @pytest.mark.parametrize("part", [0, 7])
