@@ -38,7 +38,7 @@ namespace brt {
 #ifndef BRT_ASM_COUNT
 #define BRT_ASM_COUNT 0
 #endif
-struct AsmCounts { uint32_t int_exec, int_lanes, leaf_exec, leaf_lanes, ball_exec, ball_lanes, fix_int_lanes, fix_leaf_lanes; };
+struct AsmCounts { uint32_t int_exec, int_lanes, leaf_exec, leaf_lanes, ball_exec, ball_lanes, fix_int_lanes, fix_leaf_lanes, rows_int_exec, rows_calls, rows_cycles, wide_cycles; };
 // (a call's counts are wave-uniform scalars; they are booked by the first lane that is active at the call, like prof_section, and
 //  summed over the lanes at the end of the kernel)
 __device__ __forceinline__ bool first_active_lane() {
@@ -363,6 +363,7 @@ struct ScenePtrs {
     uint32_t near_bytes;
     uint32_t near_base;      // LDS byte address of the tile (SCENE_LDS: of the pair records)
     uint32_t sph_base;       // SCENE_LDS: LDS byte address of the spheres
+    uint32_t rows_scratch;   // SCENE_LDS: LDS byte address of THIS WAVE's scratch for the row-mode walk (walk_rows_asm), 0: none
     bool boxes_ordered;      // every child box finite with min <= max (decided at upload)
     const float4* spheres;
     const uint32_t* sphere_material;
@@ -1042,6 +1043,321 @@ BRT_DEV void walk_wave_top_asm(uint32_t& cur, uint32_t& spa, float& closest, uin
 #endif
 }
 
+// ---- thin waves: ONE RAY PER ROW OF 16 LANES ("row mode", walk_rows_asm) -----------------------------------------------------
+// A wave that walks at most four rays -- the tail of a pixel chain: config 3 ends in ONE 11 064-ray pixel, a rank's share of a
+// frame split over 8 GPUs ends in its longest pixel -- is bound by its own instruction issue: a lone wave issues one instruction
+// every ~5 cycles whatever the instruction does (tests/tools/issue_bench.hip), and an interior step of walk_wave_lds_asm is ~66 of
+// them for a single useful lane.  Here a ray gets a row of 16 lanes and the step is spread over them:
+//     quad 0 = { near L x, y, z | clamp }   quad 1 = { far L x, y, z | clamp, child L's descriptor }
+//     quad 2 = { near R x, y, z | clamp }   quad 3 = { far R x, y, z | clamp, child R's descriptor }
+// every lane reads ONE word of the pair record (its plane, chosen by the ray's sign like the granule offsets of the wide loop),
+// computes (plane - o) * (1 / d) once -- the far quads multiply by -(1 / d): -(x y) is x (-y) exactly --, the fourth lane of a quad
+// holds the clamp (denorm_min for the near side, -below(closest) for the far side), two quad-permute max steps leave
+// max(near planes, denorm_min) resp. -min(far planes, below) in every lane of the quad (v_max_f32 is a total order on non-NaN values:
+// any association gives the same bits; rays that can produce a NaN never come here), four row broadcasts bring them to every lane
+// and each lane makes the reference's decision (raytrace.wgsl:331, :338-341) for itself: ~38 instructions per step instead of ~66.
+// The leaf step forms the two dot products of hit_sphere (raytrace.wgsl:371-383) across three lanes in the shader's order,
+// (x x' + y y') + z z', and then runs hipcc's sqrt and divide expansions exactly as walk_wave_lds_asm does.  Same nodes in the same
+// order, same ties, same t: pixels and counters do not change.  The rays' stacks stay where they are (the row reads and writes its
+// source lane's column of the wave's stack array), so a walk that was suspended by the wide loop is finished here as it stands.
+// Rays travel through 80 bytes of LDS scratch per row: { o, a | 1/d, closest | d, closest id | granule offsets, cur | stack top }.
+#ifndef BRT_WALK_ROWS
+#define BRT_WALK_ROWS BRT_HAND_ASM
+#endif
+constexpr uint32_t ROWS_SCRATCH_BYTES = 4u * 80u;      // per wave
+BRT_DEV void walk_rows_asm(uint32_t& cur, uint32_t spa, float& closest, uint32_t& closest_idx, uint32_t gofs_x, uint32_t gofs_y,
+                           uint32_t gofs_z, f3 o, f3 inv, f3 d, float a, uint32_t sph, uint32_t scratch, AsmCounts* ac = nullptr) {
+#if BRT_HAND_ASM
+#if BRT_ASM_COUNT
+    uint32_t c_ie, c_il, c_le, c_ll, c_tmp;
+#define BRT_COUNT_INT "s_bcnt1_i32_b64 %[c_tmp], %[s_take]\n s_lshr_b32 %[c_tmp], %[c_tmp], 4\n s_add_u32 %[c_il], %[c_il], %[c_tmp]\n s_add_u32 %[c_ie], %[c_ie], 1\n"
+#define BRT_COUNT_LEAF "s_bcnt1_i32_b64 %[c_tmp], %[s_take]\n s_lshr_b32 %[c_tmp], %[c_tmp], 4\n s_add_u32 %[c_ll], %[c_ll], %[c_tmp]\n s_add_u32 %[c_le], %[c_le], 1\n"
+#define BRT_COUNT_INT1 "s_add_u32 %[c_il], %[c_il], 1\n s_add_u32 %[c_ie], %[c_ie], 1\n"
+#else
+#define BRT_COUNT_INT
+#define BRT_COUNT_LEAF
+#define BRT_COUNT_INT1
+#endif
+    uint32_t wa, rowb, ofs, sphk, rcur, rspa, rcidx, below, lane;
+    float oj, mj, dj, cj, ra, rclosest, mj1, cj1;
+    uint32_t n4, ofs1;
+    uint64_t s_all, s_walk, s_rows, s_take, s_p2, s_any, s_both, s_pad, s_farpad;
+    const uint32_t rec_bytes = PAIR_BYTES, c_tiny = 0x0f800000u /* 2^-96 */, c_eps = 0x3a83126fu /* 0.001f */, c_cls = 0x260u /* +-0, +inf */,
+                   c80 = 80u;
+    // (the leaf step of a row: sphere test across three lanes, hipcc's sqrt / divide expansions, accept, pop; EXEC = the rows of %[s_take])
+#define BRT_ROWS_LEAF_STEP \
+        "v_and_b32_e32 v112, 0x3fff, %[rcur]\n" \
+        "v_lshl_add_u32 v111, v112, 4, %[sphk]\n" \
+        "ds_read_b32 v100, v111\n" \
+        "ds_read_i16 %[rcur], %[rspa]\n" \
+        "s_waitcnt lgkmcnt(1)\n" \
+        "v_sub_f32_e32 v101, v100, %[oj]\n" \
+        "v_add_u32_e32 %[rspa], 0xffffff80, %[rspa]\n" \
+        "v_mul_f32_e32 v102, %[dj], v101\n" \
+        "v_mul_f32_e32 v103, v101, v101\n" \
+        "s_nop 1\n" \
+        "v_add_f32_dpp v106, v102, v102 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n" \
+        "v_add_f32_dpp v108, v103, v103 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n" \
+        "s_nop 1\n" \
+        "v_add_f32_dpp v107, v102, v106 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n" \
+        "v_add_f32_dpp v104, v103, v108 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n" \
+        "s_nop 1\n" \
+        "v_subrev_f32_dpp v104, v100, v104 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n" \
+        "v_mul_f32_e32 v105, v107, v107\n" \
+        "v_mul_f32_e32 v104, %[ra], v104\n" \
+        "v_sub_f32_e32 v104, v105, v104\n" \
+        "v_cmp_gt_f32_e32 vcc, %[c_tiny], v104\n" \
+        "v_mul_f32_e32 v105, 0x4f800000, v104\n" \
+        "s_nop 0\n" \
+        "v_cndmask_b32_e32 v104, v104, v105, vcc\n" \
+        "v_sqrt_f32_e32 v105, v104\n" \
+        "v_cmp_class_f32_e64 %[s_both], v104, %[c_cls]\n" \
+        "v_add_u32_e32 v106, -1, v105\n" \
+        "v_add_u32_e32 v109, 1, v105\n" \
+        "v_fma_f32 v108, -v106, v105, v104\n" \
+        "v_fma_f32 v110, -v109, v105, v104\n" \
+        "v_cmp_ge_f32_e64 %[s_p2], 0, v108\n" \
+        "v_cmp_lt_f32_e64 %[s_any], 0, v110\n" \
+        "s_nop 0\n" \
+        "v_cndmask_b32_e64 v106, v105, v106, %[s_p2]\n" \
+        "v_cndmask_b32_e64 v105, v106, v109, %[s_any]\n" \
+        "v_mul_f32_e32 v106, 0x37800000, v105\n" \
+        "v_cndmask_b32_e32 v105, v105, v106, vcc\n" \
+        "v_cndmask_b32_e64 v104, v105, v104, %[s_both]\n" \
+        "v_sub_f32_e32 v104, v107, v104\n" \
+        "v_div_scale_f32 v105, %[s_p2], %[ra], %[ra], v104\n" \
+        "v_rcp_f32_e32 v106, v105\n" \
+        "v_div_scale_f32 v107, vcc, v104, %[ra], v104\n" \
+        "v_fma_f32 v109, -v105, v106, 1.0\n" \
+        "v_fmac_f32_e32 v106, v109, v106\n" \
+        "v_mul_f32_e32 v108, v107, v106\n" \
+        "v_fma_f32 v109, -v105, v108, v107\n" \
+        "v_fmac_f32_e32 v108, v109, v106\n" \
+        "v_fma_f32 v105, -v105, v108, v107\n" \
+        "v_div_fmas_f32 v105, v105, v106, v108\n" \
+        "v_div_fixup_f32 v104, v105, %[ra], v104\n" \
+        "s_nop 1\n" \
+        "v_mov_b32_dpp v105, v104 row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_cmp_lt_f32_e32 vcc, %[c_eps], v105\n" \
+        "v_cmp_lt_f32_e64 %[s_p2], v105, %[rclosest]\n" \
+        "s_and_b64 exec, vcc, %[s_p2]\n" \
+        "v_mov_b32_e32 %[rclosest], v105\n" \
+        "v_mov_b32_e32 %[rcidx], v112\n" \
+        "v_add_u32_e32 %[below], -1, v105\n" \
+        "v_xor_b32_e32 v106, 0x80000000, %[below]\n" \
+        "v_cndmask_b32_e64 %[cj], %[cj], v106, %[s_farpad]\n" \
+        "s_mov_b64 exec, %[s_rows]\n" \
+        "s_waitcnt lgkmcnt(0)\n"
+    asm volatile(
+#if BRT_ASM_COUNT
+        "s_mov_b32 %[c_ie], 0\n s_mov_b32 %[c_il], 0\n s_mov_b32 %[c_le], 0\n s_mov_b32 %[c_ll], 0\n"
+#endif
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_mov_b64 %[s_all], exec\n"
+        // ---- the walking lanes publish their rays: lane of rank r among them -> scratch row r ----------------------------------
+        "v_cmp_ne_u32_e32 vcc, -1, %[cur]\n"
+        "s_mov_b64 %[s_walk], vcc\n"
+        "s_mov_b64 exec, vcc\n"
+        "v_mbcnt_lo_u32_b32 %[wa], exec_lo, 0\n"               // rank among the walking lanes (EXEC is their mask)
+        "v_mbcnt_hi_u32_b32 %[wa], exec_hi, %[wa]\n"
+        "v_mul_u32_u24_e32 %[wa], %[c80], %[wa]\n"
+        "v_add_u32_e32 %[wa], %[scratch], %[wa]\n"
+        "ds_write2_b32 %[wa], %[ox], %[oy] offset0:0 offset1:1\n"
+        "ds_write2_b32 %[wa], %[oz], %[a] offset0:2 offset1:3\n"
+        "ds_write2_b32 %[wa], %[ix], %[iy] offset0:4 offset1:5\n"
+        "ds_write2_b32 %[wa], %[iz], %[closest] offset0:6 offset1:7\n"
+        "ds_write2_b32 %[wa], %[dx], %[dy] offset0:8 offset1:9\n"
+        "ds_write2_b32 %[wa], %[dz], %[cidx] offset0:10 offset1:11\n"
+        "ds_write2_b32 %[wa], %[gofs_x], %[gofs_y] offset0:12 offset1:13\n"
+        "ds_write2_b32 %[wa], %[gofs_z], %[cur] offset0:14 offset1:15\n"
+        "ds_write_b32 %[wa], %[spa] offset:64\n"
+        // ---- rows [0, walking lanes): EXEC = their 16 n lanes ---------------------------------------------------------------------
+        "s_bcnt1_i32_b64 %[n4], %[s_walk]\n"
+        "s_lshl_b32 %[n4], %[n4], 4\n"
+        "s_bfm_b64 %[s_rows], %[n4], 0\n"                       // the low 16 n bits (n < 4)
+        "s_cmp_eq_u32 %[n4], 64\n"
+        "s_cselect_b64 %[s_rows], -1, %[s_rows]\n"
+        "s_mov_b64 exec, %[s_rows]\n"
+        "s_mov_b32 vcc_lo, 0x88888888\n s_mov_b32 vcc_hi, 0x88888888\n s_mov_b64 %[s_pad], vcc\n"        // fourth lane of every quad
+        "s_mov_b32 vcc_lo, 0x80808080\n s_mov_b32 vcc_hi, 0x80808080\n s_mov_b64 %[s_farpad], vcc\n"     // ... of the far quads (1, 3)
+        // lane roles: j = lane & 15, k = j & 3 (axis; 3 = the clamp lane), q = j >> 2 (near L, far L, near R, far R)
+        "v_mbcnt_lo_u32_b32 %[lane], -1, 0\n"
+        "v_mbcnt_hi_u32_b32 %[lane], -1, %[lane]\n"
+        "v_lshrrev_b32_e32 %[rowb], 4, %[lane]\n"
+        "v_mul_u32_u24_e32 %[rowb], %[c80], %[rowb]\n"
+        "v_add_u32_e32 %[rowb], %[scratch], %[rowb]\n"          // this row's scratch
+        "v_and_b32_e32 v100, 3, %[lane]\n"                      // k
+        "v_lshlrev_b32_e32 v101, 2, v100\n"                     // 4 k
+        "v_add_u32_e32 %[sphk], %[sph], v101\n"                 // leaf step: this lane's word of a sphere { centre, r^2 }
+        "v_cndmask_b32_e64 v101, v101, 0, %[s_pad]\n"           // (a clamp lane reads axis x: its products are never used)
+        "v_add_u32_e32 v101, %[rowb], v101\n"
+        "ds_read_b32 %[oj], v101\n"
+        "ds_read_b32 %[mj], v101 offset:16\n"
+        "ds_read_b32 %[dj], v101 offset:32\n"
+        "ds_read_b32 %[ofs], v101 offset:48\n"
+        "ds_read_b32 %[ra], %[rowb] offset:12\n"
+        "ds_read_b32 %[rclosest], %[rowb] offset:28\n"
+        "ds_read_b32 %[rcidx], %[rowb] offset:44\n"
+        "ds_read_b32 %[rcur], %[rowb] offset:60\n"
+        "ds_read_b32 %[rspa], %[rowb] offset:64\n"
+        "v_bfe_u32 v102, %[lane], 2, 2\n"                       // q
+        "v_and_b32_e32 v103, 1, v102\n"                         // far side?
+        "v_lshlrev_b32_e32 v104, 31, v103\n"                    // its sign bit
+        "v_lshlrev_b32_e32 v103, 3, v103\n"                     // word of the granule { near L, near R, far L, far R }: far + 8 bytes,
+        "v_lshrrev_b32_e32 v105, 1, v102\n"                     //                                                      R + 4 bytes
+        "v_lshl_add_u32 v103, v105, 2, v103\n"
+        "v_lshl_add_u32 v105, v105, 2, %[c96]\n"                // a clamp lane reads a descriptor instead: L (quads 0, 1), R (quads 2, 3)
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_xor_b32_e32 %[mj], v104, %[mj]\n"                    // far quads: -(1 / d)
+        "v_add_u32_e32 %[ofs], %[ofs], v103\n"
+        "v_cndmask_b32_e64 %[ofs], %[ofs], v105, %[s_pad]\n"
+        "v_add_u32_e32 %[below], -1, %[rclosest]\n"
+        "v_xor_b32_e32 v104, 0x80000000, %[below]\n"
+        "v_mov_b32_e32 %[cj], 1\n"                              // denorm_min
+        "v_cndmask_b32_e64 %[cj], %[cj], v104, %[s_farpad]\n"   // -below
+        "v_cndmask_b32_e64 %[mj1], %[mj], 0, %[s_pad]\n"        // the one-ray form below: a clamp lane reads the plane of the lane before it, ...
+        "v_mov_b32_e32 %[cj1], 0x80000000\n"
+        "v_cndmask_b32_e64 %[cj1], %[cj1], %[cj], %[s_pad]\n"   // ... multiplies by 0 and adds its clamp; a plane lane adds -0
+        "v_mov_b32_dpp %[ofs1], %[ofs] row_shr:1 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_cndmask_b32_e64 %[ofs1], %[ofs], %[ofs1], %[s_pad]\n"
+        // ---- ONE ray (the tail of a pixel chain): its steps are one dependent chain, not an issue budget -- a lone wave issues an instruction
+        //      every ~5 cycles but a step of the loop below takes ~450, most of it the hand-offs between the vector pipe, the scalar unit
+        //      and EXEC in its decision part.  This form keeps EXEC fixed (the row) and decides with selects: the three records the walk can
+        //      go to next (child L, child R, the stack top) have their LDS addresses ready before the slab test is done, the push rule picks
+        //      one and the next reads go out; the only scalar instruction of a step is its back edge.
+        "s_cmp_lg_u32 %[n4], 16\n"
+        "s_cbranch_scc1 3f\n"
+        "v_cmp_lt_i32_e32 vcc, -1, %[rcur]\n"
+        "s_cbranch_vccz 14f\n"
+        "10:\n"                                                  // ---- interior steps while the ray stays at interior nodes
+        "v_mul_u32_u24_e32 v113, %[rec_bytes], %[rcur]\n"       // byte address of the record (they start at LDS address 0)
+        "v_mov_b32_e32 v112, 0xffffffc0\n"                      // -64
+        "v_add_u32_e32 v111, v113, %[ofs1]\n"
+        "11:\n"
+        BRT_COUNT_INT1
+        "ds_read_b32 v100, v111\n"                              // this lane's plane (a clamp lane: any plane, times 0)
+        "ds_read_b64 v[108:109], v113 offset:96\n"              // children L, R
+        "ds_read_i16 v110, %[rspa]\n"                           // the would-be pop
+        "s_waitcnt lgkmcnt(2)\n"
+        "v_sub_f32_e32 v101, v100, %[oj]\n"                     // (b - o) * (1 / d), raytrace.wgsl:388-390; a plane lane adds -0 (exact), a clamp
+        "v_fma_f32 v101, v101, %[mj1], %[cj1]\n"                // lane multiplies a finite number by 0 and adds its clamp
+        "s_nop 1\n"
+        "v_max_f32_dpp v102, v101, v101 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_max_f32_dpp v103, v102, v102 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_f32_dpp v104, v103, v103 row_shr:4 row_mask:0xf bank_mask:0xf\n"   // quads 1, 3: max(t_near, denorm_min) - min(t_far, below)
+        "s_nop 1\n"
+        "v_mov_b32_dpp v105, v104 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+        "v_mov_b32_dpp v104, v104 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+        "v_cmp_ge_f32_e32 vcc, 0, v105\n"                       // p1: t_near <= t_far of child L (x - y <= 0 iff x <= y: no flushing, y finite)
+        "v_cmp_ge_f32_e64 %[s_p2], 0, v104\n"                   // p2
+        "s_waitcnt lgkmcnt(0)\n"
+        "ds_write_b16 %[rspa], v108 offset:128\n"               // child L above the top: dead unless both are pushed
+        "v_cndmask_b32_e32 %[rcur], v110, v108, vcc\n"          // neither: pop; only L: L
+        "v_cndmask_b32_e64 v105, v112, 64, vcc\n"               // stack top: + 64 + 64 (both), + 64 - 64 (one), - 64 - 64 (neither)
+        "v_cndmask_b32_e64 %[rcur], %[rcur], v109, %[s_p2]\n"   // R, if pushed, is popped first
+        "v_cndmask_b32_e64 v104, v112, 64, %[s_p2]\n"
+        "v_mul_u32_u24_e32 v113, %[rec_bytes], %[rcur]\n"
+        "v_add3_u32 %[rspa], %[rspa], v104, v105\n"
+        "v_add_u32_e32 v111, v113, %[ofs1]\n"                   // this lane's word of the next record
+        "v_cmp_lt_i32_e32 vcc, -1, %[rcur]\n"
+        "s_cbranch_vccnz 11b\n"
+        "14:\n"                                                  // ---- a leaf, or the end of the walk
+        "v_cmp_gt_i32_e32 vcc, -1, %[rcur]\n"
+        "s_cbranch_vccz 7f\n"
+        "s_mov_b64 %[s_take], exec\n"
+        BRT_COUNT_LEAF
+        BRT_ROWS_LEAF_STEP
+        "v_cndmask_b32_e64 %[cj1], %[cj1], %[cj], %[s_farpad]\n"   // (closest may have changed: the far clamp)
+        "v_cmp_lt_i32_e32 vcc, -1, %[rcur]\n"
+        "s_cbranch_vccnz 10b\n"
+        "s_branch 14b\n"
+        // ---- loop (two to four rays) ------------------------------------------------------------------------------------------------------
+        "3:\n"
+        "v_cmp_lt_i32_e32 vcc, -1, %[rcur]\n"                   // rows at an interior node
+        "s_and_b64 %[s_take], vcc, %[s_rows]\n"
+        "s_cbranch_scc0 4f\n"
+        "s_mov_b64 exec, %[s_take]\n"
+        BRT_COUNT_INT
+        "ds_read_i16 v110, %[rspa]\n"                           // the would-be pop
+        "v_mul_u32_u24_e32 v111, %[rec_bytes], %[rcur]\n"
+        "v_add_u32_e32 v111, v111, %[ofs]\n"
+        "ds_read_b32 v100, v111\n"                              // this lane's plane (clamp lanes: a child descriptor)
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_sub_f32_e32 v101, v100, %[oj]\n"                     // (b - o) * (1 / d), raytrace.wgsl:388-390
+        "v_mul_f32_e32 v101, v101, %[mj]\n"
+        "v_cndmask_b32_e64 v101, v101, %[cj], %[s_pad]\n"
+        "v_mov_b32_dpp v108, v100 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"      // child L
+        "v_mov_b32_dpp v109, v100 row_newbcast:15 row_mask:0xf bank_mask:0xf\n"     // child R
+        "v_max_f32_dpp v102, v101, v101 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "ds_write_b16 %[rspa], v108 offset:128\n"               // child L above the top: dead unless both are pushed
+        "s_nop 0\n"
+        "v_max_f32_dpp v103, v102, v102 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_mov_b32_dpp v104, v103 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"      // max(t_near L, denorm_min)
+        "v_mov_b32_dpp v105, v103 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"      // -min(t_far L, below)
+        "v_mov_b32_dpp v106, v103 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+        "v_mov_b32_dpp v107, v103 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+        "v_cmp_le_f32_e64 vcc, v104, -v105\n"                   // p1: child L is pushed (raytrace.wgsl:331)
+        "v_cmp_le_f32_e64 %[s_p2], v106, -v107\n"               // p2: child R is pushed (raytrace.wgsl:338)
+        "s_or_b64 %[s_any], vcc, %[s_p2]\n"
+        "s_and_b64 %[s_both], vcc, %[s_p2]\n"
+        "s_andn2_b64 exec, %[s_take], %[s_any]\n"               // no child pushed: pop
+        "v_mov_b32_e32 %[rcur], v110\n"
+        "v_add_u32_e32 %[rspa], 0xffffff80, %[rspa]\n"
+        "s_andn2_b64 exec, vcc, %[s_p2]\n"                      // only L
+        "v_mov_b32_e32 %[rcur], v108\n"
+        "s_mov_b64 exec, %[s_p2]\n"                             // R (pushed last, popped first)
+        "v_mov_b32_e32 %[rcur], v109\n"
+        "s_mov_b64 exec, %[s_both]\n"                           // both: L stays on the stack
+        "v_add_u32_e32 %[rspa], 0x80, %[rspa]\n"
+        "s_mov_b64 exec, %[s_rows]\n"
+        // ---- leaf step for the rows that wait at a leaf -----------------------------------------------------------------------------
+        "4:\n"
+        "v_cmp_gt_i32_e32 vcc, -1, %[rcur]\n"                   // leaf descriptors are < -1
+        "s_and_b64 %[s_take], vcc, %[s_rows]\n"
+        "s_cbranch_scc0 6f\n"
+        "s_mov_b64 exec, %[s_take]\n"
+        BRT_COUNT_LEAF
+        BRT_ROWS_LEAF_STEP
+        "6:\n"
+        "v_cmp_ne_u32_e32 vcc, -1, %[rcur]\n"
+        "s_cbranch_vccnz 3b\n"
+        "7:\n"
+        // ---- results back to the walking lanes -------------------------------------------------------------------------------------
+        "ds_write_b32 %[rowb], %[rclosest] offset:28\n"
+        "ds_write_b32 %[rowb], %[rcidx] offset:44\n"
+        "s_mov_b64 exec, %[s_walk]\n"
+        "ds_read_b32 %[closest], %[wa] offset:28\n"
+        "ds_read_b32 %[cidx], %[wa] offset:44\n"
+        "v_mov_b32_e32 %[cur], -1\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_mov_b64 exec, %[s_all]\n"
+        : [cur] "+v"(cur), [closest] "+v"(closest), [cidx] "+v"(closest_idx), [wa] "=&v"(wa), [rowb] "=&v"(rowb), [ofs] "=&v"(ofs),
+          [sphk] "=&v"(sphk), [rcur] "=&v"(rcur), [rspa] "=&v"(rspa), [rcidx] "=&v"(rcidx), [below] "=&v"(below), [lane] "=&v"(lane),
+          [oj] "=&v"(oj), [mj] "=&v"(mj), [dj] "=&v"(dj), [cj] "=&v"(cj), [ra] "=&v"(ra), [rclosest] "=&v"(rclosest), [mj1] "=&v"(mj1), [cj1] "=&v"(cj1), [ofs1] "=&v"(ofs1), [n4] "=&s"(n4),
+          [s_all] "=&s"(s_all), [s_walk] "=&s"(s_walk), [s_rows] "=&s"(s_rows), [s_take] "=&s"(s_take), [s_p2] "=&s"(s_p2),
+          [s_any] "=&s"(s_any), [s_both] "=&s"(s_both), [s_pad] "=&s"(s_pad), [s_farpad] "=&s"(s_farpad)
+#if BRT_ASM_COUNT
+          , [c_ie] "=&s"(c_ie), [c_il] "=&s"(c_il), [c_le] "=&s"(c_le), [c_ll] "=&s"(c_ll), [c_tmp] "=&s"(c_tmp)
+#endif
+        : [spa] "v"(spa), [gofs_x] "v"(gofs_x), [gofs_y] "v"(gofs_y), [gofs_z] "v"(gofs_z), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z),
+          [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z), [a] "v"(a), [sph] "s"(sph),
+          [scratch] "s"(scratch), [rec_bytes] "s"(rec_bytes), [c_tiny] "s"(c_tiny), [c_eps] "s"(c_eps), [c_cls] "s"(c_cls), [c80] "s"(c80),
+          [c96] "s"(96u)
+        : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112",
+          "v113");
+#if BRT_ASM_COUNT
+    if (first_active_lane()) { ac->int_exec += c_ie; ac->int_lanes += c_il; ac->leaf_exec += c_le; ac->leaf_lanes += c_ll; ac->rows_int_exec += c_ie; ac->rows_calls += 1u; }
+#endif
+#undef BRT_COUNT_INT
+#undef BRT_COUNT_LEAF
+#endif
+}
+
+
 template <bool D16, bool SIMPLE_TREE, typename StackT>
 BRT_DEV void walk_loop_wave_lds(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, uint32_t ox, uint32_t oy, uint32_t oz,
                                 float& closest, uint32_t& closest_idx, uint32_t& cur, StackT*& sp, uint32_t& n,
@@ -1053,8 +1369,31 @@ BRT_DEV void walk_loop_wave_lds(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv
     // (the leaf step runs when at least `vote` of the lanes that walked at the last leaf step wait at a leaf -- walk_loop_wave
     //  counts the leaf lanes instead; the rules differ only when a lane ends its walk inside a run of interior steps, and only
     //  in when the leaf step runs)
+#if BRT_ASM_COUNT
+    const unsigned long long t0 = __builtin_readcyclecounter();
+#endif
     walk_wave_lds_asm(cur, spa, closest, closest_idx, ox, oy, oz, o, inv, d, a, sph, exit_at, vote, &hc.asm_counts);
+#if BRT_ASM_COUNT
+    if (first_active_lane()) hc.asm_counts.wide_cycles += (uint32_t)(__builtin_readcyclecounter() - t0);
+#endif
     sp = (StackT*)reinterpret_cast<lds_stack*>((uintptr_t)spa);
+}
+// ... and of a wave that walks at most four rays: every walk to its end, a ray to a row of 16 lanes (walk_rows_asm)
+template <bool D16, bool SIMPLE_TREE, typename StackT>
+BRT_DEV void walk_rows_lds(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv, uint32_t ox, uint32_t oy, uint32_t oz,
+                           float& closest, uint32_t& closest_idx, uint32_t& cur, StackT* sp, HitCounters& hc) {
+    static_assert(D16 && SIMPLE_TREE && sizeof(StackT) == 2, "LDS-resident simple tree: 16-bit descriptors, no overflow rule, no leaf table");
+    typedef __attribute__((address_space(3))) StackT lds_stack;
+    const uint32_t spa = (uint32_t)(uintptr_t)(lds_stack*)sp;
+    const uint32_t sph = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.sph_base);
+    const uint32_t scratch = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.rows_scratch);
+#if BRT_ASM_COUNT
+    const unsigned long long t0 = __builtin_readcyclecounter();
+#endif
+    walk_rows_asm(cur, spa, closest, closest_idx, ox, oy, oz, o, inv, d, a, sph, scratch, &hc.asm_counts);
+#if BRT_ASM_COUNT
+    if (first_active_lane()) hc.asm_counts.rows_cycles += (uint32_t)(__builtin_readcyclecounter() - t0);
+#endif
 }
 
 // ... and of a scene walked from the tile / from global memory (walk_wave_top_asm)
@@ -1074,7 +1413,11 @@ BRT_DEV void walk_loop_wave_top(const ScenePtrs& sc, f3 o, f3 d, float a, f3 inv
 // HITS: the instantiation can count interior visits per record (sc.hits; the pre-pass of a SCENE_LDS_TOP scene): such a launch walks
 // in the compiler's loop, the repairing form (a superset of the plain one: the min / max it adds change nothing for safe rays).
 // POLICY: the instantiation can walk under the compare-select reading of min / max (sc.minmax_select): also in the compiler's loop.
-template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, int MODE, typename StackT, bool HITS = false, bool POLICY = false>
+// ROWS: a wave that walks at most four rays takes the row-mode loop (walk_rows_asm).  The kernel asks for it in the instantiations
+// that can hold a CRITICAL pixel chain (LEAN 0 / 1: config 3 ends in one 11 064-ray pixel); the steady-state instantiation of views
+// without such chains (LEAN 2: the headline frame) leaves it out -- there the thin phase of a wave is too short to pay for the second
+// loop's registers and dispatch (same box, headline frame: 8.885 ms without, 9.026 ms with; profiles/r06/thin_wave_rows.txt).
+template <int STRIDE, bool COUNTERS, bool D16, bool SIMPLE_TREE, int MODE, typename StackT, bool HITS = false, bool POLICY = false, bool ROWS = false>
 BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, f3 o, f3 d,
                       uint32_t exit_lanes, uint32_t leaf_vote, HitCounters& hc) {
     using DS = Desc<D16>;
@@ -1127,8 +1470,14 @@ BRT_DEV void walk_run(const ScenePtrs& sc, WalkState<StackT>& w, StackT* stk, f3
                 walk_loop_wave<COUNTERS, D16, SIMPLE_TREE, true, MODE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp,
                                                                        n, exit_at, vote, hc);
             constexpr bool kByHandTop = BRT_WALK_FAST && BRT_WALK_FAST_TOP && MODE != SCENE_LDS && !COUNTERS && SIMPLE_TREE && D16;
-            if constexpr (kByHand)
-                walk_loop_wave_lds<D16, SIMPLE_TREE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp, n, exit_at, vote, hc);
+            // a thin wave (the tail of a pixel chain): a ray to a row of 16 lanes, every walk to its end (walk_rows_asm)
+            constexpr bool kRows = kByHand && BRT_WALK_ROWS && ROWS;
+            bool rows = false;
+            if constexpr (kRows) rows = n_walking <= 4u && !any_unsafe && sc.rows_scratch != 0u;       // (wave-uniform)
+            if constexpr (kByHand) {
+                if (rows) walk_rows_lds<D16, SIMPLE_TREE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp, hc);
+                else walk_loop_wave_lds<D16, SIMPLE_TREE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp, n, exit_at, vote, hc);
+            }
             else if constexpr (kByHandTop)
                 walk_loop_wave_top<D16, SIMPLE_TREE, MODE>(sc, o, d, a, inv, ox, oy, oz, closest, closest_idx, cur, sp, n, exit_at, vote, hc);
             else if (!any_unsafe)

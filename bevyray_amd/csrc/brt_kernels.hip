@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void k_trace_simple(DeviceSceneView sv, FrameP
     sc.near_bytes = 0u;
     sc.near_base = 0u;
     sc.sph_base = 0u;
+    sc.rows_scratch = 0u;
     sc.hits = nullptr;
     sc.minmax_select = false;
     sc.boxes_ordered = sv.boxes_ordered != 0u;
@@ -288,6 +289,7 @@ size_t trace_lds_bytes(const DeviceSceneView& sv, int scene_mode, uint32_t block
     bytes += (size_t)(block / 64) * (sv.stack_entries + 2) * 64 * (sv.desc16 ? 2 : 4);   // + 2: DONE sentinel, one spare entry
     bytes = (bytes + 15) & ~(size_t)15;
     bytes += WGQ_BYTES;                                                                  // workgroup share of the pixel queue
+    if (scene_mode == SCENE_LDS && BRT_WALK_ROWS) bytes += (size_t)(block / 64) * ROWS_SCRATCH_BYTES;   // row-mode walk of thin waves
     if (pool_cap) bytes += 16 + (size_t)pool_cap * POOL_RECORD_BYTES;                    // drain pool: control words + records
     bytes += (size_t)hist_words * 4;                                                     // pre-pass: visits per pair record (FrameParams::record_hits)
     return bytes;

@@ -498,6 +498,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     sc.near_bytes = 0u;
     sc.near_base = 0u;
     sc.sph_base = 0u;
+    sc.rows_scratch = 0u;
     sc.hits = nullptr;
     sc.minmax_select = TUNABLE && (fp.policy_flags & 2u) != 0u;
     if (MODE == SCENE_LDS) {
@@ -555,6 +556,10 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     off = (off + 15u) & ~15u;
     uint32_t* const wgq = reinterpret_cast<uint32_t*>(lds + off);
     off += WGQ_BYTES;
+    if (MODE == SCENE_LDS && BRT_WALK_ROWS) {      // every wave's scratch for the row-mode walk of a thin wave (walk_rows_asm)
+        sc.rows_scratch = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + off) + wave * ROWS_SCRATCH_BYTES;
+        off += n_waves * ROWS_SCRATCH_BYTES;
+    }
     uint32_t* pool_ctl = nullptr;
     float4* pool = nullptr;
     if (fp.pool_cap != 0u) {
@@ -854,7 +859,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         if (fresh) walk_begin<D16>(walk, sc, sv.root_desc, stk, d);
         if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_pre += now - t_mark; t_mark = now; }
         if (kPhasePrio == 1 && !wave_crit) __builtin_amdgcn_s_setprio(1);
-        if (active) walk_run<64, COUNTERS, D16, SIMPLE, MODE, StackT, kHits, TUNABLE>(sc, walk, stk, o, d, finish_walks ? 0u : walk_exit_lanes, leaf_vote, hc);
+        if (active) walk_run<64, COUNTERS, D16, SIMPLE, MODE, StackT, kHits, TUNABLE, LEAN != 2>(sc, walk, stk, o, d, finish_walks ? 0u : walk_exit_lanes, leaf_vote, hc);
         in_flight = active && walk_pending<D16, SIMPLE>(walk);
         if (COUNTERS) { const unsigned long long now = wall_clock64(); ticks_walk += now - t_mark; t_mark = now; }
         const bool landed = active && !in_flight;      // walk finished: shade this segment now
@@ -896,12 +901,16 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
 #if BRT_ASM_COUNT
     if (!COUNTERS) {      // what the hand-written loops of this wave executed (each call booked by one lane: sum over the lanes)
         const AsmCounts& c = hc.asm_counts;
-        const uint32_t v[8] = {wave_sum(c.int_exec), wave_sum(c.int_lanes), wave_sum(c.leaf_exec), wave_sum(c.leaf_lanes), wave_sum(c.ball_exec), wave_sum(c.ball_lanes),
-                               wave_sum(c.fix_int_lanes), wave_sum(c.fix_leaf_lanes)};
+        const uint32_t v[12] = {wave_sum(c.int_exec), wave_sum(c.int_lanes), wave_sum(c.leaf_exec), wave_sum(c.leaf_lanes), wave_sum(c.ball_exec), wave_sum(c.ball_lanes),
+                                wave_sum(c.fix_int_lanes), wave_sum(c.fix_leaf_lanes), wave_sum(c.rows_int_exec), wave_sum(c.rows_calls), wave_sum(c.rows_cycles), wave_sum(c.wide_cycles)};
         if (lane == 0) {            // (word 32 is the tile queue's counter)
             for (int k = 0; k < 6; k++) atomicAdd(&counters[33 + k], (unsigned long long)v[k]);
             atomicAdd(&counters[39], (unsigned long long)v[6]);
             atomicAdd(&counters[43], (unsigned long long)v[7]);
+            atomicAdd(&counters[44], (unsigned long long)v[8]);       // of the interior executions: in the row-mode walk of thin waves (walk_rows_asm)
+            atomicAdd(&counters[5], (unsigned long long)v[9]);        // calls of that walk  (words 44 and 5 .. 7 are phase times in the COUNTERS build)
+            atomicAdd(&counters[6], (unsigned long long)v[10]);       // shader clocks in the row-mode walk ...
+            atomicAdd(&counters[7], (unsigned long long)v[11]);       // ... and in the wide hand-written walk (first active lane's view, summed over the waves)
         }
     }
 #endif

@@ -416,7 +416,8 @@ class RaytracePlugin:
         self.last_raw = [int(x) for x in raw]
         # -DBRT_ASM_COUNT builds: executions / active lanes of the hand-written loops of the last production launch (else zeros)
         self.last_asm_counts = {"interior": (int(raw[33]), int(raw[34])), "leaf": (int(raw[35]), int(raw[36])), "ball": (int(raw[37]), int(raw[38])),
-                                "repairing_loop_lanes": (int(raw[39]), int(raw[43]))}
+                                "repairing_loop_lanes": (int(raw[39]), int(raw[43])), "rows_interior_exec": int(raw[44]), "rows_calls": int(raw[5]),
+                                "rows_cycles": int(raw[6]), "wide_cycles": int(raw[7])}
         names = ["interior", "leaf", "camera", "scatter", "sky", "ball", "camera_top", "round"]
         prof = {n: (int(raw[8 + 2 * k]), int(raw[9 + 2 * k])) for k, n in enumerate(names)}
         # wave time stamps (100 MHz wall clock): first start, first / last "pixel queue empty", last end
