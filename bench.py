@@ -468,6 +468,13 @@ def main():
                        "workgroups": counted["n_workgroups"], "threads": counted["threads_per_workgroup"]},
         }
         out.update(extras)
+        # both trees side by side in the contract's config block: `value` is measured in the tree the callee
+        # builds; the same frame in the tree the reference's extract stage would hand over (PLOC, 0.1 pads):
+        if "caller_ploc_tree_ms" in extras and extras["caller_ploc_tree_ms"] > 0:
+            out["config"]["caller_tree_ms"] = extras["caller_ploc_tree_ms"]
+            out["config"]["caller_tree_value"] = round(head["total_rays"] / args.steps / (extras["caller_ploc_tree_ms"] * 1e-3) / 1e6, 1)
+            out["config"]["caller_tree_note"] = ("Mrays/s (kernel time, this rank's share) of the same frame in the caller's PLOC tree, 0.1 pads "
+                                                 "(extract.rs:220-227, 315-332); `value` is in the callee-built tree")
         if cfg4 is not None:
             cfg4["roofline"] = roofline_block(args, world, stub is not None, max(cfg4["kernel_ms_per_rank"]), None, PMC_WORKLOAD4_TAG)
             out["config4"] = cfg4

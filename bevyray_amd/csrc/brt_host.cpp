@@ -370,15 +370,34 @@ int32_t build_bvh_sah(const Model* models, uint32_t n_models, float reach, std::
     return BRT_OK;
 }
 
+#ifndef BRT_GIANT_RULE
+#define BRT_GIANT_RULE 1   // 1: by the boxes (below); 0: round 5's rule, a sphere of radius > 100 (A/B: scripts/exp_tree_rules.py)
+#endif
 void sah_giant_leaves_first(BVHNode* nodes, uint32_t n_nodes, const Model* models, uint32_t n_models) {
-    auto giant_leaf = [&](const BVHNode& nd) {
-        return nd.model_count == 1u && nd.index < n_models && models[nd.index].radius > 100.0f && std::isfinite(models[nd.index].radius);
+    // A LEAF whose box takes at least half of its parent's surface, beside a sibling that is a subtree: nearly every ray that enters
+    // the parent enters that leaf -- the ground under a scene, a big sphere beside a cluster of small ones.  Decided on the boxes the
+    // builder made (half areas in f64, as in the split cost), not on a radius: a ground of radius 50 or 80 is found like one of
+    // radius 1000, a scene without such a sphere is left alone.
+    auto half_area = [](const BVHNode& nd) {
+        const double dx = (double)nd.bounds_max[0] - (double)nd.bounds_min[0], dy = (double)nd.bounds_max[1] - (double)nd.bounds_min[1],
+                     dz = (double)nd.bounds_max[2] - (double)nd.bounds_min[2];
+        return (dx * dy + dy * dz) + dz * dx;
+    };
+    auto giant_leaf = [&](const BVHNode& parent, const BVHNode& nd, const BVHNode& sibling) {
+        if (nd.model_count != 1u || nd.index >= n_models) return false;
+#if BRT_GIANT_RULE == 0
+        (void)parent; (void)sibling;
+        return models[nd.index].radius > 100.0f && std::isfinite(models[nd.index].radius);
+#else
+        const double a = half_area(nd), ap = half_area(parent);
+        return sibling.model_count == 0u && std::isfinite(a) && std::isfinite(ap) && ap > 0.0 && a >= 0.5 * ap;
+#endif
     };
     for (uint32_t i = 0; i < n_nodes; i++) {
         if (nodes[i].model_count != 0u) continue;
         const uint32_t a = nodes[i].index;
         if (a + 1u >= n_nodes || a + 1u == 0u) continue;
-        if (giant_leaf(nodes[a]) && !giant_leaf(nodes[a + 1u])) std::swap(nodes[a], nodes[a + 1u]);
+        if (giant_leaf(nodes[i], nodes[a], nodes[a + 1u]) && !giant_leaf(nodes[i], nodes[a + 1u], nodes[a])) std::swap(nodes[a], nodes[a + 1u]);
     }
 }
 

@@ -21,9 +21,10 @@
 //     the first (axis, bin) in axis-major order with the smallest cost < DBL_MAX wins; the range is
 //     STABLY partitioned by "bin <= b" -- also when the split is then refused because the larger side would not fit the
 //     depth budget (d + 1 + ceil_log2(larger) > kSahMaxDepth), in which case `mid` stays at the halves of the new order.
-//   * giant spheres first (a last pass over the finished nodes, on the host for both builders: brt_host.cpp sah_giant_leaves_first):
-//     where one child of a node is the leaf of a sphere of radius > 100 -- the ground, a child of the root -- and the other is not,
-//     that leaf goes to slot `index + 1`, which the reference pops FIRST (raytrace.wgsl:329-341).  Every ray enters the ground's box;
+//   * giant leaves first (a last pass over the finished nodes, on the host for both builders: brt_host.cpp sah_giant_leaves_first):
+//     where one child of a node is a LEAF whose box takes at least half of the node's surface and the other child is a subtree -- the
+//     ground, a child of the root; a big sphere beside a cluster of small ones; decided on the boxes, not on a radius (round 5: "radius >
+//     100") -- that leaf goes to slot `index + 1`, which the reference pops FIRST (raytrace.wgsl:329-341).  Every ray enters the ground's box;
 //     popped last, its sphere test comes at the end of each lane's own walk, a few lanes at a time; popped first, all lanes of a wave
 //     make it together in one full-width leaf step right after the root (config 2 -0.9 %, config 3 -1.5 ... -4 %, config 5 -0 ... -1.7 %;
 //     same frames: profiles/r05/ground_first.txt).
