@@ -63,6 +63,21 @@ static int collapse(const BVHNode* b, uint32_t bn, int width, WTree* t) {
     return id;
 }
 
+/* ---- multi-sphere leaves (raytrace.wgsl:348-362 loops `model_count` spheres of a leaf) ----------------------
+ * g_leaf_max > 1: the SAH builder below may end a range of at most g_leaf_max spheres as ONE leaf -- always (g_leaf_rule 0), or when
+ * the surface area heuristic says so (g_leaf_rule 1: n * C_sphere * area <= best split cost * C_sphere + C_step * area, the wave costs
+ * of a sphere test and of an interior step).  A leaf is then a code >= LEAF_MULTI into the table {first, count} over g_leaf_ids.
+ * g_leaf_units counts, per leaf-step execution of a wave, the LARGEST count among the lanes at a leaf: the step loops that often. */
+#define LEAF_MULTI (1 << 24)
+static int g_leaf_max = 1, g_leaf_rule = 0, g_pad_mode = 0;
+static float g_c_sphere = 61.0f, g_c_step = 43.0f;
+static int *g_leaf_first = NULL, *g_leaf_cnt = NULL, *g_leaf_ids = NULL, g_n_leaves = 0, g_n_leaf_ids = 0;
+static uint64_t g_leaf_units = 0, g_leaf_hist[9];
+void exp_set_leaf(int leaf_max, int rule, int pad_mode, float c_sphere, float c_step) {
+    g_leaf_max = leaf_max; g_leaf_rule = rule; g_pad_mode = pad_mode; g_c_sphere = c_sphere; g_c_step = c_step;
+}
+void exp_get_leaf(uint64_t* out12) { out12[0] = g_leaf_units; out12[1] = (uint64_t)g_n_leaves; for (int i = 0; i < 9; i++) out12[2 + i] = g_leaf_hist[i]; }
+
 /* ---- binned SAH BVH2 over the padded sphere boxes (Model::aabb, extract.rs:220-227) -> BVHNode array ---- */
 typedef struct { float lo[3], hi[3]; uint32_t id; } Prim;
 static void grow(float* lo, float* hi, const float* plo, const float* phi) {
@@ -74,7 +89,15 @@ static void sah_build(Prim* p, int n, BVHNode* out, uint32_t slot, uint32_t* n_o
     BVHNode* nd = &out[slot];
     memset(nd, 0, sizeof *nd);
     nd->minx = lo[0]; nd->miny = lo[1]; nd->minz = lo[2]; nd->maxx = hi[0]; nd->maxy = hi[1]; nd->maxz = hi[2];
-    if (n == 1) { nd->index = p[0].id; nd->model_count = 1; return; }
+    if (n == 1) { nd->index = p[0].id; nd->model_count = 1; g_leaf_hist[1]++; return; }
+    if (n <= g_leaf_max && g_leaf_rule == 0) {
+multi_leaf:
+        nd->index = (uint32_t)(LEAF_MULTI + g_n_leaves); nd->model_count = (uint32_t)n;
+        g_leaf_first[g_n_leaves] = g_n_leaf_ids; g_leaf_cnt[g_n_leaves] = n; g_n_leaves++;
+        for (int i = 0; i < n; i++) g_leaf_ids[g_n_leaf_ids++] = (int)p[i].id;
+        g_leaf_hist[n < 8 ? n : 8]++;
+        return;
+    }
     /* full sweep SAH on each axis (n is small) */
     int best_axis = 0, best_split = n / 2; float best_cost = INF;
     float* right_area = (float*)malloc(sizeof(float) * (size_t)n);
@@ -94,6 +117,10 @@ static void sah_build(Prim* p, int n, BVHNode* out, uint32_t slot, uint32_t* n_o
         }
     }
     free(right_area);
+    if (n <= g_leaf_max && g_leaf_rule == 1) {
+        const float area = box_area(lo, hi);
+        if ((float)n * g_c_sphere * area <= best_cost * g_c_sphere + g_c_step * area) goto multi_leaf;
+    }
     for (int i = 1; i < n; i++) {
         Prim key = p[i]; float kc = key.lo[best_axis] + key.hi[best_axis]; int j = i - 1;
         while (j >= 0 && p[j].lo[best_axis] + p[j].hi[best_axis] > kc) { p[j + 1] = p[j]; j--; }
@@ -159,8 +186,13 @@ static void step_interior(const Scene* s, const WTree* t, Walk* w, const Variant
     for (int i = 0; i < nh; i++) if (!v->pop_cull || hit[i].tnear < w->closest) w->stack[w->sp++] = hit[i];
     pop(w, v, c);
 }
+static int leaf_count(int cur) { const int code = -cur - 2; return code >= LEAF_MULTI ? g_leaf_cnt[code - LEAF_MULTI] : 1; }
 static void step_leaf(const Scene* s, Walk* w, const Variant* v, SimCnt* c) {
-    sphere(s, w, -w->cur - 2, c);
+    const int code = -w->cur - 2;
+    if (code >= LEAF_MULTI) {
+        const int lf = code - LEAF_MULTI;
+        for (int i = 0; i < g_leaf_cnt[lf]; i++) sphere(s, w, g_leaf_ids[g_leaf_first[lf] + i], c);     /* raytrace.wgsl:348-362 */
+    } else sphere(s, w, code, c);
     pop(w, v, c);
 }
 
@@ -295,6 +327,9 @@ static void sim_tile(const Scene* s, const WTree* t, const Variant* v, uint32_t 
             for (int l = 0; l < 64; l++) if (L[l].active && is_leaf(L[l].w.cur)) nl++;
             if (nl) {
                 c->leaf_exec++; c->leaf_lanes += (uint64_t)nl;
+                int mx = 1;
+                for (int l = 0; l < 64; l++) if (L[l].active && is_leaf(L[l].w.cur)) { const int k = leaf_count(L[l].w.cur); if (k > mx) mx = k; }
+                g_leaf_units += (uint64_t)mx;
                 for (int l = 0; l < 64; l++) if (L[l].active && is_leaf(L[l].w.cur)) step_leaf(s, &L[l].w, v, c);
             }
             int nw = 0;
@@ -459,11 +494,16 @@ int exp_run(const void* models, uint32_t n_models, const void* materials, uint32
     if (use_sah & 1) {
         Prim* p = (Prim*)malloc(sizeof(Prim) * n_models);
         for (uint32_t i = 0; i < n_models; i++) {
-            const Model* m = &s.models[i]; float r = m->radius + 0.1f;
+            const Model* m = &s.models[i];
+            /* g_pad_mode 1: the callee's leaf pads (brt_sah.h sah_model_pad at the scenes' scale: the 0.01 floor) instead of the reference's 0.1 */
+            float r = m->radius + ((g_pad_mode == 1 && m->radius <= 100.0f) ? 0.01f : 0.1f);
             p[i].lo[0] = m->px - r; p[i].lo[1] = m->py - r; p[i].lo[2] = m->pz - r;
             p[i].hi[0] = m->px + r; p[i].hi[1] = m->py + r; p[i].hi[2] = m->pz + r; p[i].id = i;
         }
         own = (BVHNode*)calloc(2 * (size_t)n_models, sizeof(BVHNode));
+        free(g_leaf_first); free(g_leaf_cnt); free(g_leaf_ids);
+        g_leaf_first = (int*)calloc(n_models + 1, sizeof(int)); g_leaf_cnt = (int*)calloc(n_models + 1, sizeof(int)); g_leaf_ids = (int*)calloc(n_models + 1, sizeof(int));
+        g_n_leaves = 0; g_n_leaf_ids = 0; memset(g_leaf_hist, 0, sizeof g_leaf_hist);
         uint32_t n_out = 1;
         sah_build(p, (int)n_models, own, 0, &n_out);
         free(p);
@@ -481,6 +521,7 @@ int exp_run(const void* models, uint32_t n_models, const void* materials, uint32
     }
     memset(g_far, 0, sizeof g_far);
     memset(g_abc, 0, sizeof g_abc);
+    g_leaf_units = 0;
     Variant v = {width, near_first, pop_cull, leaf_in_parent, vote, exit_lanes};
     SimCnt c; memset(&c, 0, sizeof c);
     for (uint32_t i = 0; i < n_tiles; i++) {

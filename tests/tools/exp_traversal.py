@@ -95,6 +95,40 @@ def leaf_split_study(n=60, scene=None):
     lib.exp_set_ab(0, 12, 24)
 
 
+def leaf_size_study(n=60):
+    """multi-sphere leaves in the callee's tree (raytrace.wgsl:348-362 loops `model_count` spheres): SAH trees whose
+    leaves hold up to 1 / 2 / 4 spheres, forced or decided by the surface area heuristic with the wave costs of the two steps, on the
+    views of configs 2, 3 (at 64 spp) and 5; callee's leaf pads.  Wave-level cost of a round's walk in SIMD cycles: interior step 112,
+    leaf step 20 + 142 per sphere of the LARGEST leaf among the lanes of the step (measured issue costs)."""
+    W, H = 1920, 1080
+    lib.exp_set_leaf.argtypes = [I, I, I, C.c_float, C.c_float]
+    lib.exp_get_leaf.argtypes = [VP]
+    C_INT, C_LEAF0, C_SPH = 112.0, 20.0, 142.0
+    out = np.zeros(12, np.uint64)
+    for name, scene, camf, spp, bounces in (("config 2 (cover)", brt.SCENE_COVER, brt.cover_camera, 64, 8),
+                                            ("config 3 view (RTIOW, 64 spp, 50 bounces)", brt.SCENE_RTIOW_FINAL, brt.rtiow_camera, 64, 50),
+                                            ("config 5 (10 004-sphere grid)", brt.SCENE_STRESS_GRID, brt.cover_camera, 64, 8)):
+        b = brt.generate_scene(scene, 1)
+        lvl, cam, win = camf(W, H, spp, bounces)
+        rng = np.random.default_rng(5)
+        tiles = np.stack([rng.integers(0, W // 8, n), rng.integers(0, H // 8, n)], 1)
+        print(f"== {name}: {len(b.models)} spheres, {n} random tiles")
+        print(f"{'leaves':28s} {'leaves by size 1/2/3/4':>24s} {'int/ray':>8s} {'sph/ray':>8s} {'intX/rnd':>8s} {'lanes':>6s} {'leafX/rnd':>9s} {'lanes':>6s} {'units/rnd':>9s} {'walk cycles/round':>17s}")
+        base = None
+        for label, mx, rule in (("1 sphere (the product)", 1, 0), ("<= 2, forced", 2, 0), ("<= 2, by SAH", 2, 1), ("<= 4, forced", 4, 0), ("<= 4, by SAH", 4, 1)):
+            lib.exp_set_leaf(mx, rule, 1, C_SPH, C_INT)
+            r = run(b, cam, win, W, H, tiles, sah=1)
+            lib.exp_get_leaf(out.ctypes.data)
+            units = int(out[0]); hist = [int(x) for x in out[3:7]]
+            R = r["rounds"]
+            cyc = (r["int_exec"] * C_INT + r["leaf_exec"] * C_LEAF0 + units * C_SPH) / R
+            base = base or cyc
+            print(f"{label:28s} {'/'.join(map(str, hist)):>24s} {r['int_lanes']/r['rays']:8.2f} {r['sphere_tests']/r['rays']:8.2f} {r['int_exec']/R:8.2f} "
+                  f"{r['int_lanes']/max(1,r['int_exec']):6.1f} {r['leaf_exec']/R:9.2f} {r['leaf_lanes']/max(1,r['leaf_exec']):6.1f} {units/R:9.2f} "
+                  f"{cyc:12.0f} ({100.0 * (cyc / base - 1.0):+.1f} %)", flush=True)
+    lib.exp_set_leaf(1, 0, 0, C_SPH, C_INT)
+
+
 def policy_grid(n=60):
     """Leaf-vote x walk-exit thresholds of the width-2 walk: total wave instructions per ray (1060 non-walk per round)."""
     W, H, spp, bounces = 1920, 1080, 64, 8
@@ -118,6 +152,8 @@ def main():
         return far_study(int(sys.argv[2]) if len(sys.argv) > 2 else 40)
     if len(sys.argv) > 1 and sys.argv[1] == "--leaf-split":
         return leaf_split_study(int(sys.argv[2]) if len(sys.argv) > 2 else 60, int(sys.argv[3]) if len(sys.argv) > 3 else None)
+    if len(sys.argv) > 1 and sys.argv[1] == "--leaf-size":
+        return leaf_size_study(int(sys.argv[2]) if len(sys.argv) > 2 else 60)
     if len(sys.argv) > 1 and sys.argv[1] == "--policy-grid":
         return policy_grid(int(sys.argv[2]) if len(sys.argv) > 2 else 60)
     scene = int(sys.argv[1]) if len(sys.argv) > 1 else brt.SCENE_COVER
