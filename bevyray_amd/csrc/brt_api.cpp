@@ -488,6 +488,24 @@ int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const fl
                 lp.variant = (uint32_t)tl.lean | (tl.frame.tunable ? 16u : 0u);
                 lp.measured = fp.tile_cost != nullptr ? 1u : 0u;
             }
+            // sampler stage (knob BRT_BALL_SERVERS, brt_trace.h SRV): the steady-state instantiation of an LDS-resident scene with two of the
+            // workgroup's sixteen waves serving the rejection sampler of the other fourteen; its mailboxes come out of the drain pool's LDS
+            tl.srv = 0u;
+            if (ctx->knobs[K_BALL_SERVERS] != 0u && lp.scene_mode == SCENE_LDS && tl.lean == 2 && dc.view.simple_tree && lp.block == BRT_BLOCK &&
+                lp.wg_per_cu == 1u) {
+                const size_t pool_bytes = lp.pool_cap ? 16u + (size_t)lp.pool_cap * POOL_RECORD_BYTES : 0u, rest = lp.lds_bytes - pool_bytes;
+                const size_t need = srv_lds_bytes(lp.block);
+                if (rest + need <= dc.max_lds) {
+                    size_t room = dc.max_lds - rest - need;
+                    uint32_t pool = room > 16u ? (uint32_t)((room - 16u) / POOL_RECORD_BYTES) : 0u;
+                    if (pool > lp.pool_cap) pool = lp.pool_cap;
+                    if (lp.pool_cap != 0u && pool < 64u) pool = 0u;
+                    lp.pool_cap = pool;
+                    lp.lds_bytes = rest + (pool ? 16u + (size_t)pool * POOL_RECORD_BYTES : 0u) + need;
+                    tl.srv = SRV_WAVES;
+                    lp.variant |= 32u;
+                }
+            }
             tl.scene_mode = lp.scene_mode;
             tl.scene.lds_pairs = lp.lds_pairs;
             tl.grid = lp.grid;

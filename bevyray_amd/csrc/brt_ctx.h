@@ -103,7 +103,7 @@ struct DeviceCtx {
 enum Knob : int {
     K_BOTTOM_UP, K_REFILL_MIN, K_WALK_EXIT, K_LEAF_VOTE, K_DRAIN_DONATE, K_POOL_ADOPT, K_WGQ_BATCH, K_LPT_LANE_PERMILLE, K_TUNABLE,
     K_FORCE_GLOBAL_SCENE, K_FORCE_LDS_TOP, K_BLOCK_THREADS, K_WG_PER_CU, K_POOL_CAP, K_LPT, K_LPT_SORT, K_LPT_SKY_SLACK, K_CRIT,
-    K_ORDER_ON_HOST, K_NO_LEAN, K_PREPASS_SPP, K_NO_DIRTY_TRACKING, K_CPU_BVH, K_PLOC_ONE_BLOCK_MAX, K_BVH_QUALITY, K_POOL_FORCE, K_LPT_REFRESH_EVERY, K_LEAN_MEASURE, K_LPT_DILATE, K_SPLIT_TAIL, K_SPLIT_FORCE, K_HOT_RECORDS, K_TEST_THROW, K_COUNT
+    K_ORDER_ON_HOST, K_NO_LEAN, K_PREPASS_SPP, K_NO_DIRTY_TRACKING, K_CPU_BVH, K_PLOC_ONE_BLOCK_MAX, K_BVH_QUALITY, K_POOL_FORCE, K_LPT_REFRESH_EVERY, K_LEAN_MEASURE, K_LPT_DILATE, K_SPLIT_TAIL, K_SPLIT_FORCE, K_HOT_RECORDS, K_TEST_THROW, K_BALL_SERVERS, K_COUNT
 };
 struct KnobDef { const char* name; uint32_t dflt; };
 constexpr KnobDef kKnobs[K_COUNT] = {
@@ -112,7 +112,7 @@ constexpr KnobDef kKnobs[K_COUNT] = {
     {"BRT_TUNABLE", 0}, {"BRT_FORCE_GLOBAL_SCENE", 0}, {"BRT_FORCE_LDS_TOP", 0}, {"BRT_BLOCK_THREADS", 0}, {"BRT_WG_PER_CU", 0},
     {"BRT_POOL_CAP", 384}, {"BRT_LPT", 1}, {"BRT_LPT_SORT", 1}, {"BRT_LPT_SKY_SLACK", 20}, {"BRT_CRIT", 1}, {"BRT_ORDER_ON_HOST", 0},
     {"BRT_NO_LEAN", 0}, {"BRT_PREPASS_SPP", 4}, {"BRT_NO_DIRTY_TRACKING", 0}, {"BRT_CPU_BVH", 0},
-    {"BRT_PLOC_ONE_BLOCK_MAX", kPlocOneBlockMax}, {"BRT_BVH_QUALITY", 1}, {"BRT_POOL_FORCE", 0}, {"BRT_LPT_REFRESH_EVERY", 0}, {"BRT_LEAN_MEASURE", 1}, {"BRT_LPT_DILATE", 3}, {"BRT_SPLIT_TAIL", 16}, {"BRT_SPLIT_FORCE", 0}, {"BRT_HOT_RECORDS", 1}, {"BRT_TEST_THROW", 0}};
+    {"BRT_PLOC_ONE_BLOCK_MAX", kPlocOneBlockMax}, {"BRT_BVH_QUALITY", 1}, {"BRT_POOL_FORCE", 0}, {"BRT_LPT_REFRESH_EVERY", 0}, {"BRT_LEAN_MEASURE", 1}, {"BRT_LPT_DILATE", 3}, {"BRT_SPLIT_TAIL", 16}, {"BRT_SPLIT_FORCE", 0}, {"BRT_HOT_RECORDS", 1}, {"BRT_TEST_THROW", 0}, {"BRT_BALL_SERVERS", 0}};
 struct Knobs {
     uint32_t v[K_COUNT];
     Knobs() { for (int i = 0; i < K_COUNT; i++) v[i] = kKnobs[i].dflt; }

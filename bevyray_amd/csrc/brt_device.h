@@ -38,7 +38,7 @@ namespace brt {
 #ifndef BRT_ASM_COUNT
 #define BRT_ASM_COUNT 0
 #endif
-struct AsmCounts { uint32_t int_exec, int_lanes, leaf_exec, leaf_lanes, ball_exec, ball_lanes, fix_int_lanes, fix_leaf_lanes, rows_int_exec, rows_calls, rows_cycles, wide_cycles; };
+struct AsmCounts { uint32_t int_exec, int_lanes, leaf_exec, leaf_lanes, ball_exec, ball_lanes, fix_int_lanes, fix_leaf_lanes, rows_int_exec, rows_calls, rows_cycles, wide_cycles, srv_wait_polls; };
 // (a call's counts are wave-uniform scalars; they are booked by the first lane that is active at the call, like prof_section, and
 //  summed over the lanes at the end of the kernel)
 __device__ __forceinline__ bool first_active_lane() {
@@ -309,6 +309,198 @@ BRT_DEV void ball_loop_asm(uint32_t& rng, f3& acc, float rough, uint64_t m2, uin
 #endif
 }
 
+// ---- the rejection sampler as a STAGE of the workgroup (k_trace_persistent<.., SRV>) ------------------------------
+// In the wave-level loop above a round's ~35 hit lanes wait for the unluckiest of them: 7.7 iterations at 14.6 of 64 lanes, 13 % of the
+// headline frame (sampler made free: 8.90 -> 7.74 ms, profiles/r06/sampler_stage.txt).  The sampler's state is the smallest of all stages --
+// {rng, points needed} in, {rng, p1, p2} out -- so here it leaves the path's lane: of the workgroup's sixteen waves fourteen trace and
+// SRV_WAVES = 2 SERVE.  A trace wave posts its round's requests into its mailbox in LDS (32 bytes per lane: {rng, need | serial << 2}
+// compacted by mbcnt, then its door word {serial, count}), goes on with the part of the round's shading that does not need the points
+// (sky, sample ends, camera rays, the second normalize, the glass branch) and picks the results up behind it: {rng', p1} {p2, serial} in
+// the request's own entry, valid when the last word is the round's serial.  A server wave keeps 64 requests in flight: every iteration
+// draws a candidate for each of its lanes (the iteration of ball_loop_asm, on fixed registers), the lanes that are done write their
+// entry back and free lanes take the next requests of the server's current batch (a trace wave's door it has not served yet).  A lane's
+// draws are the same hash chain whichever wave runs them: pixels cannot change.  A server owns every other trace wave (static: no shared
+// queue, no atomics); it ends when the workgroup's last trace wave has ended (control word 0).  Nobody can wait for ever: the requests
+// of a posted batch are taken whenever a server lane is free, a request is done with probability 1, and both loops give up after a
+// bounded number of polls (a wrong frame instead of a hang; the give-ups are counted).
+//   mbox: LDS byte address of wave 0's mailbox (2 KB per trace wave); door: of door[0]; ctl: control words {alive trace waves, ..}
+//   first, stride, n_mine: this server serves trace waves first, first + stride, .. (n_mine of them)
+#ifndef BRT_SRV_LOW
+#define BRT_SRV_LOW 0
+#endif
+#ifndef BRT_SRV_PATIENCE
+#define BRT_SRV_PATIENCE 8
+#endif
+BRT_DEV void ball_server_asm(uint32_t mbox, uint32_t door, uint32_t ctl, uint32_t first, uint32_t stride, uint32_t n_mine, uint32_t* counts8) {
+    const uint32_t low = BRT_SRV_LOW, patience = BRT_SRV_PATIENCE;
+#if BRT_HAND_ASM
+    uint32_t pos, cnt, base, i0, d0, nfree, take, idle, c_iter, c_lanes, c_polls, c_tmp, polled, stall;
+    uint64_t m2, m1, busy, s_up, s_mine, s_tmp, s_take;
+    const uint32_t c_mul = 277803737u, c_2m31 = 0x30000000u /* 2^-31 */;
+#define BRT_SRV_DRAW(dst)                                                                                                   \
+    "v_add_u32_e32 v100, 0xd8e8c2ba, v100\n"              /* random.wgsl:9 */                                              \
+    "v_lshrrev_b32_e32 v108, 28, v100\n"                                                                                    \
+    "v_add_u32_e32 v108, 4, v108\n"                                                                                         \
+    "v_lshrrev_b32_e32 v108, v108, v100\n"                                                                                  \
+    "v_xor_b32_e32 v100, v108, v100\n"                                                                                      \
+    "v_mul_lo_u32 v100, v100, %[c_mul]\n"                                                                                   \
+    "v_lshrrev_b32_e32 v108, 22, v100\n"                                                                                    \
+    "v_xor_b32_e32 v100, v108, v100\n"                                                                                      \
+    "v_cvt_f32_u32_e32 " dst ", v100\n"                                                                                    \
+    "v_fma_f32 " dst ", " dst ", %[c_2m31], -1.0\n"
+    asm volatile(
+        "s_setprio 3\n"
+        "s_mov_b64 %[m2], 0\n s_mov_b64 %[m1], 0\n s_mov_b32 %[pos], 0\n s_mov_b32 %[cnt], 0\n s_mov_b32 %[idle], 0\n"
+        "s_mov_b32 %[c_iter], 0\n s_mov_b32 %[c_lanes], 0\n s_mov_b32 %[c_polls], 0\n s_mov_b32 %[base], 0\n s_mov_b32 %[stall], 0\n"
+        "v_mbcnt_lo_u32_b32 v112, -1, 0\n"
+        "v_mbcnt_hi_u32_b32 v112, -1, v112\n"                   // lane
+        "v_cmp_gt_u32_e32 vcc, %[n_mine], v112\n"               // lanes that watch a door
+        "s_mov_b64 %[s_mine], vcc\n"
+        "v_mul_lo_u32 v109, v112, %[stride]\n"
+        "v_add_u32_e32 v109, %[first], v109\n"                  // the trace wave this lane watches
+        "v_lshl_add_u32 v109, v109, 2, %[door]\n"               // ... its door word
+        "v_mov_b32_e32 v110, 0\n"                               // the door value this lane has served
+        "v_mov_b32_e32 v111, 0\n"
+        // ---- a pass: (A) the LDS reads of the refill go out -- the next requests of the current batch for the free lanes, or, with no batch
+        //      at hand, the doors --, (B) one candidate for every lane that needs one (ball_loop_asm's iteration) runs under their round trip,
+        //      lanes that are done write their entry back, (C) the reads are taken in: the takers start, or a new batch is opened.
+        "1:\n"
+        "s_or_b64 %[busy], %[m2], %[m1]\n"
+        "s_mov_b64 %[s_take], 0\n"
+        "s_mov_b32 %[polled], 0\n"
+        "s_cmp_lt_u32 %[pos], %[cnt]\n"
+        "s_cbranch_scc0 2f\n"
+        "s_not_b64 %[s_tmp], %[busy]\n"                         // (A) free lanes take requests pos .. of the batch
+        "s_bcnt1_i32_b64 %[nfree], %[s_tmp]\n"
+        "s_cbranch_scc0 4f\n"
+        "s_sub_u32 %[take], %[cnt], %[pos]\n"
+        "s_min_u32 %[take], %[take], %[nfree]\n"
+        "s_mov_b64 exec, %[s_tmp]\n"
+        "v_mbcnt_lo_u32_b32 v112, exec_lo, 0\n"
+        "v_mbcnt_hi_u32_b32 v112, exec_hi, v112\n"              // rank among the free lanes
+        "v_cmp_gt_u32_e32 vcc, %[take], v112\n"
+        "s_mov_b64 %[s_take], vcc\n"
+        "s_mov_b64 exec, vcc\n"
+        "v_add_u32_e32 v112, %[pos], v112\n"
+        "v_lshl_add_u32 v111, v112, 5, %[base]\n"               // the request's entry
+        "ds_read_b64 v[114:115], v111\n"                        // { rng, need | serial << 2 }
+        "s_add_u32 %[pos], %[pos], %[take]\n"
+        "s_branch 4f\n"
+        "2:\n"                                                  // (A) no batch at hand: the doors (only worth a look with room for a batch)
+        "s_not_b64 %[s_tmp], %[busy]\n"
+        "s_bcnt1_i32_b64 %[nfree], %[s_tmp]\n"
+        "s_cmp_lt_u32 %[nfree], 12\n"
+        "s_cbranch_scc1 4f\n"
+        "s_mov_b64 exec, %[s_mine]\n"
+        "ds_read_b32 v112, v109\n"
+        "s_mov_b32 %[polled], 1\n"
+        "s_add_u32 %[c_polls], %[c_polls], 1\n"
+        // ---- (B) ------------------------------------------------------------------------------------------------------------------------
+        "4:\n"
+        "s_mov_b64 exec, %[busy]\n"
+        "s_cbranch_execz 6f\n"
+        // (a server that iterates with a few lanes costs its SIMD what one with 64 does: below %[low] lanes it lets requests gather for up to
+        //  %[patience] passes -- each a look at the doors and a short sleep -- before it goes on with what it has)
+        "s_bcnt1_i32_b64 %[c_tmp], exec\n"
+        "s_cmp_ge_u32 %[c_tmp], %[low]\n"
+        "s_cbranch_scc1 5f\n"
+        "s_add_u32 %[stall], %[stall], 1\n"
+        "s_cmp_ge_u32 %[stall], %[patience]\n"
+        "s_cbranch_scc1 5f\n"
+        "s_sleep 1\n"
+        "s_branch 6f\n"
+        "5:\n"
+        "s_mov_b32 %[stall], 0\n"
+        "s_add_u32 %[c_lanes], %[c_lanes], %[c_tmp]\n s_add_u32 %[c_iter], %[c_iter], 1\n"
+        BRT_SRV_DRAW("v104")
+        BRT_SRV_DRAW("v105")
+        BRT_SRV_DRAW("v106")
+        "v_mul_f32_e32 v108, v104, v104\n"                      // dot3(p, p) = (x*x + y*y) + z*z
+        "v_mul_f32_e32 v113, v105, v105\n"
+        "v_add_f32_e32 v108, v108, v113\n"
+        "v_mul_f32_e32 v113, v106, v106\n"
+        "v_add_f32_e32 v108, v108, v113\n"
+        "v_cmp_ge_f32_e32 vcc, 1.0, v108\n"                     // accepted
+        "s_and_b64 %[s_up], %[m2], vcc\n"                       // two needed -> one
+        "s_andn2_b64 %[m1], %[m1], vcc\n"                       // one needed -> none
+        "s_andn2_b64 %[m2], %[m2], vcc\n"
+        "s_or_b64 %[m1], %[m1], %[s_up]\n"
+        "s_mov_b64 exec, %[s_up]\n"
+        "v_mov_b32_e32 v101, v104\n"                            // the first of two points
+        "v_mov_b32_e32 v102, v105\n"
+        "v_mov_b32_e32 v103, v106\n"
+        "s_or_b64 %[s_tmp], %[m2], %[m1]\n"
+        "s_andn2_b64 exec, %[busy], %[s_tmp]\n"                 // done: the entry goes back {rng', p1} {p2, serial}
+        "s_cbranch_execz 6f\n"
+        "ds_write_b128 v111, v[100:103]\n"
+        "ds_write_b128 v111, v[104:107] offset:16\n"
+        // ---- (C) ------------------------------------------------------------------------------------------------------------------------
+        "6:\n"
+        "s_mov_b64 exec, %[s_take]\n"
+        "s_cbranch_execz 7f\n"
+        "s_waitcnt lgkmcnt(0)\n"                                // (the takers' requests; any write-back above is behind them in the queue: waited for too)
+        "v_mov_b32_e32 v100, v114\n"
+        "v_and_b32_e32 v112, 3, v115\n"
+        "v_lshrrev_b32_e32 v107, 2, v115\n"                     // the serial goes back with the result
+        "v_cmp_eq_u32_e32 vcc, 2, v112\n"
+        "s_or_b64 %[m2], %[m2], vcc\n"
+        "v_cmp_eq_u32_e32 vcc, 1, v112\n"
+        "s_or_b64 %[m1], %[m1], vcc\n"
+        "s_mov_b64 exec, -1\n"
+        "s_branch 1b\n"
+        "7:\n"
+        "s_mov_b64 exec, -1\n"
+        "s_cmp_eq_u32 %[polled], 0\n"
+        "s_cbranch_scc1 1b\n"
+        "s_waitcnt lgkmcnt(0)\n"                                // the doors
+        "s_mov_b64 exec, %[s_mine]\n"
+        "v_cmp_ne_u32_e32 vcc, v112, v110\n"                    // a value this lane has not served
+        "s_mov_b64 exec, -1\n"
+        "s_cbranch_vccz 8f\n"
+        "s_ff1_i32_b64 %[i0], vcc\n"                            // the first door with a new batch
+        "s_lshl_b64 %[s_tmp], 1, %[i0]\n"
+        "s_mov_b64 exec, %[s_tmp]\n"
+        "v_mov_b32_e32 v110, v112\n"                            // served (from now on)
+        "s_mov_b64 exec, -1\n"
+        "v_readlane_b32 %[d0], v112, %[i0]\n"
+        "s_and_b32 %[cnt], %[d0], 0xff\n"                       // requests of the batch
+        "s_mov_b32 %[pos], 0\n"
+        "s_mul_i32 %[base], %[i0], %[stride]\n"
+        "s_add_u32 %[base], %[base], %[first]\n"
+        "s_lshl_b32 %[base], %[base], 11\n"                     // 2 KB per trace wave
+        "s_add_u32 %[base], %[base], %[mbox]\n"
+        "s_mov_b32 %[idle], 0\n"
+        "s_branch 1b\n"
+        "8:\n"                                                  // no new batch
+        "s_or_b64 %[busy], %[m2], %[m1]\n"
+        "s_cmp_lg_u64 %[busy], 0\n"
+        "s_cbranch_scc1 1b\n"
+        "v_mov_b32_e32 v112, %[ctl]\n"
+        "ds_read_b32 v112, v112\n"                              // nothing in flight: has the last trace wave ended?
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_readfirstlane_b32 %[d0], v112\n"
+        "s_cmp_eq_u32 %[d0], 0\n"
+        "s_cbranch_scc1 9f\n"
+        "s_sleep 1\n"
+        "s_add_u32 %[idle], %[idle], 1\n"
+        "s_cmp_gt_u32 %[idle], 0x1000000\n"                     // (a bound, not a protocol step)
+        "s_cbranch_scc1 9f\n"
+        "s_branch 1b\n"
+        "9:\n"
+        "s_mov_b64 exec, -1\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_setprio 0\n"
+        : [pos] "=&s"(pos), [cnt] "=&s"(cnt), [base] "=&s"(base), [i0] "=&s"(i0), [d0] "=&s"(d0), [nfree] "=&s"(nfree), [take] "=&s"(take),
+          [idle] "=&s"(idle), [c_iter] "=&s"(c_iter), [c_lanes] "=&s"(c_lanes), [c_polls] "=&s"(c_polls), [c_tmp] "=&s"(c_tmp), [m2] "=&s"(m2),
+          [m1] "=&s"(m1), [busy] "=&s"(busy), [s_up] "=&s"(s_up), [s_mine] "=&s"(s_mine), [s_tmp] "=&s"(s_tmp), [s_take] "=&s"(s_take), [polled] "=&s"(polled), [stall] "=&s"(stall)
+        : [low] "s"(low), [patience] "s"(patience), [mbox] "s"(mbox), [door] "s"(door), [ctl] "s"(ctl), [first] "s"(first), [stride] "s"(stride), [n_mine] "s"(n_mine), [c_mul] "s"(c_mul),
+          [c_2m31] "s"(c_2m31)
+        : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115");
+    counts8[0] = c_iter; counts8[1] = c_lanes; counts8[2] = c_polls; counts8[3] = idle;
+#undef BRT_SRV_DRAW
+#endif
+}
+
 // raytrace.wgsl:387-398 with 1/d hoisted per ray.  Returns whether the child is pushed
 // (raytrace.wgsl:331,338: dst != INF && dst < closest.distance).
 BRT_DEV bool slab_push(f3 o, f3 inv, f3 bmin, f3 bmax, float closest) {
@@ -364,6 +556,8 @@ struct ScenePtrs {
     uint32_t near_base;      // LDS byte address of the tile (SCENE_LDS: of the pair records)
     uint32_t sph_base;       // SCENE_LDS: LDS byte address of the spheres
     uint32_t rows_scratch;   // SCENE_LDS: LDS byte address of THIS WAVE's scratch for the row-mode walk (walk_rows_asm), 0: none
+    uint32_t srv_ctl;              // sampler stage (SRV): LDS byte address of its control words
+    uint32_t srv_mbox, srv_door;   // sampler stage (SRV): LDS byte addresses of THIS trace wave's mailbox (64 entries of 32 bytes) and door word
     bool boxes_ordered;      // every child box finite with min <= max (decided at upload)
     const float4* spheres;
     const uint32_t* sphere_material;

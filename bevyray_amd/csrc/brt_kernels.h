@@ -23,6 +23,7 @@ struct TraceLaunch {
     unsigned long long* counters;       // 5 x u64, zeroed by the caller
     int scene_mode;                     // SceneMode (brt_layout.h)
     bool counters_on;
+    uint32_t srv;                       // sampler stage (brt_trace.h, SRV): this many of a workgroup's waves serve the rejection sampler of the others (0: none)
     int lean;                           // LEAN instantiation (brt_trace.h): 0 general; 1 level 3 + no tile-cost measurement; 2 + no critical tile possible
     uint32_t grid, block;
     size_t lds_bytes;
@@ -31,6 +32,9 @@ struct TraceLaunch {
 
 size_t trace_lds_bytes(const DeviceSceneView& sv, int scene_mode, uint32_t block, uint32_t pool_cap, uint32_t hist_words = 0);
 constexpr uint32_t POOL_RECORD_BYTES = 96;   // one path in the drain pool (k_trace_persistent)
+// sampler stage (k_trace_persistent<.., SRV>): a 32-byte mailbox entry per lane of every trace wave + 16 control words + a door per wave
+constexpr uint32_t SRV_WAVES = 2;
+constexpr uint32_t srv_lds_bytes(uint32_t block) { return (block / 64u - SRV_WAVES) * 64u * 32u + 64u + (block / 64u) * 4u; }
 constexpr uint32_t WGQ_BYTES = 64;           // a workgroup's share of the pixel queue: 8 control words + 8 tile ids
 hipError_t launch_trace_persistent(const TraceLaunch& tl);
 hipError_t launch_trace_simple(const TraceLaunch& tl);

@@ -277,11 +277,18 @@ BRT_DEV bool shade_segment(const ScenePtrs& sc, const FrameParams& fp, f3& o, f3
 // :269 is made first) or LATE (metal absorbed or at the limit -- `absorbed` needs N2 -- and glass at the limit under the
 // or-short-circuit policy): early ones get their camera ray in N2, late ones are flagged need_cam and get it at the top
 // of the next round (1 in ~40 samples on the cover frame).
-template <bool COUNTERS, int LEAN, bool TUNABLE>
+// SRV: the rejection sampler is a stage of the workgroup (ball_server_asm, brt_device.h): the hit lanes POST {rng, points needed} behind the
+// material lottery, the round's shading that does not need the points runs, and they PICK the points UP behind the second normalize.
+// What changes per lane is nothing -- the same draws, operations and operands in the same order --; what changes in the wave: a diffuse
+// sample that ends here (absorbed, or at the bounce limit) is found out behind the pick-up, i.e. LATE (its camera ray is made at the top
+// of the next round), and a metal lane's `u + fuzz` moves behind the pick-up too.  srv_serial: the round's serial number (wave-uniform).
+typedef uint32_t lds_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t lds_u2 __attribute__((ext_vector_type(2)));
+template <bool COUNTERS, int LEAN, bool TUNABLE, bool SRV = false>
 BRT_DEV void shade_landed(const ScenePtrs& sc, const FrameParams& fp, bool landed, float t, uint32_t idx, PixelState& ps,
                           f3& o, f3& d, f3& tput, uint32_t& bounce, float& first_depth, bool& active, bool& need_cam,
                           uint32_t& n_rays, HitCounters& hc, float* out_tile, const float* raster_rgba,
-                          const float* raster_depth) {
+                          const float* raster_depth, uint32_t srv_serial = 0u) {
     const bool osc = TUNABLE && (fp.policy_flags & 1u);      // alternative reading of :269 (fixtures only)
     const bool sel = TUNABLE && (fp.policy_flags & 2u);      // ... of min / max (:263, :405): compare-select
     const bool pw5 = TUNABLE && (fp.policy_flags & 4u);      // ... of pow (:415): exp2(5 log2 x)
@@ -330,7 +337,7 @@ BRT_DEV void shade_landed(const ScenePtrs& sc, const FrameParams& fp, bool lande
     // (kind, att, acc, ior, draw: only ever read for hit lanes -- deliberately left undefined for the others)
     bool metal = false, glass = false, diffuse = false, absorbed = false;
     f3 att, acc;
-    float ior, draw;
+    float ior, draw, m1x_of_hit = 0.0f;
     if (hit) {
 #if BRT_MAT_BY_SPHERE
         const float4 m0 = sc.sphere_mats[2 * idx];      // base_color.rgb, metallic
@@ -345,13 +352,15 @@ BRT_DEV void shade_landed(const ScenePtrs& sc, const FrameParams& fp, bool lande
         diffuse = !metal && !glass;
         if (glass && !osc) draw = rng_float(ps.rng);                               // :269, default policy: always drawn
         ior = m1.z;
+        m1x_of_hit = m1.x;
         att = glass ? mk3(1.0f, 1.0f, 1.0f) : mk3(m0.x, m0.y, m0.z);
         uint32_t need = metal ? 1u : (diffuse ? 2u : 0u);
         acc = diffuse ? n1 : mk3(-0.0f, -0.0f, -0.0f);
         float scale = diffuse ? 1.0f : m1.x;
         unsigned long long t_ball = 0;
         if (COUNTERS) t_ball = wall_clock64();
-        if (BRT_BALL_ASM && !COUNTERS) {
+        if (SRV) need = 0u;                                                       // (the points come from the servers: below)
+        else if (BRT_BALL_ASM && !COUNTERS) {
             ball_loop_asm(ps.rng, acc, m1.x, __builtin_amdgcn_ballot_w64(diffuse), __builtin_amdgcn_ballot_w64(metal), &hc.asm_counts);
             need = 0u;
         }
@@ -371,15 +380,31 @@ BRT_DEV void shade_landed(const ScenePtrs& sc, const FrameParams& fp, bool lande
             const uint64_t m = __ballot(true);
             if (mbcnt64(m) == 0u) hc.ticks_ball += wall_clock64() - t_ball;
         }
-        if (diffuse) {                                                            // :281-297
+        if (!SRV && diffuse) {                                                    // :281-297
             const float eps = 1e-8f;
             if (__builtin_fabsf(acc.x) < eps && __builtin_fabsf(acc.y) < eps && __builtin_fabsf(acc.z) < eps) acc = n1;
             absorbed = dot3(acc, n1) < 0.0f;
         }
     }
+    // ---- sampler stage: post this round's requests (compacted: request k of the wave in entry k of its mailbox) ----
+    const bool srv_need = SRV && hit && (metal || diffuse);
+    uint32_t srv_slot = 0u;
+    if (SRV) {
+        const uint64_t nm = __ballot(srv_need);
+        if (nm != 0ull) {
+            srv_slot = sc.srv_mbox + 32u * mbcnt64(nm);
+            if (srv_need) {
+                const lds_u2 rq = {ps.rng, (metal ? 1u : 2u) | (srv_serial << 2)};
+                *reinterpret_cast<__attribute__((address_space(3))) lds_u2*>((uintptr_t)srv_slot) = rq;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // the entries before the door
+            if (mbcnt64(nm) == 0u && srv_need)                                // (the first posting lane rings)
+                *reinterpret_cast<volatile __attribute__((address_space(3))) uint32_t*>((uintptr_t)sc.srv_door) = (srv_serial << 8) | (uint32_t)__popcll(nm);
+        }
+    }
     // ---- early ends ----
     const bool limit = hit && bounce >= fp.bounce_count;        // :189: this was the last segment the loop allows
-    const bool early = sky || (diffuse && (absorbed || limit)) || (glass && limit && !osc);
+    const bool early = sky || (!SRV && diffuse && (absorbed || limit)) || (glass && limit && !osc);
     bool cam = false;
     f3 cdir;
     if (early) {
@@ -411,8 +436,8 @@ BRT_DEV void shade_landed(const ScenePtrs& sc, const FrameParams& fp, bool lande
             d = u;                      // (origin, throughput, first depth of the new sample: top of the next round)
             need_cam = false;
         } else if (metal) {                                                       // :234-245
-            d = u + acc;
-            absorbed = dot3(d, n1) < 0.0f;
+            if (SRV) d = u;                                                        // (+ the fuzz behind the pick-up)
+            else { d = u + acc; absorbed = dot3(d, n1) < 0.0f; }
         } else {                                                                  // glass, :249-280
             const float ri = dn < 0.0f ? (1.0f / ior) : ior;
             const float cos_theta = sel ? min_sel(dot3(neg3(u), n1), 1.0f) : min_f(dot3(neg3(u), n1), 1.0f);
@@ -426,6 +451,39 @@ BRT_DEV void shade_landed(const ScenePtrs& sc, const FrameParams& fp, bool lande
                 reflects = reflects || (refl > draw);
             }
             d = reflects ? reflect3(u, n1) : refract3(u, n1, ri, sel);
+        }
+    }
+    // ---- sampler stage: pick the points up (valid when the entry's last word is this round's serial) ----
+    if (SRV && __ballot(srv_need) != 0ull) {
+        bool waiting = srv_need;
+        for (uint32_t spin = 0u; ; spin++) {
+            if (waiting) {
+                const uint32_t flag = *reinterpret_cast<volatile __attribute__((address_space(3))) uint32_t*>((uintptr_t)(srv_slot + 28u));
+                waiting = flag != srv_serial;
+            }
+            if (__ballot(waiting) == 0ull) break;
+            // (a bound, not a protocol step: brt_device.h ball_server_asm.  Whoever runs into it poisons the workgroup -- control word 1 --
+            //  and nobody of it polls again: a wrong frame, counted, instead of a kernel that stands still)
+            volatile __attribute__((address_space(3))) uint32_t* poison = reinterpret_cast<volatile __attribute__((address_space(3))) uint32_t*>((uintptr_t)(sc.srv_ctl + 4u));
+            if (spin > (1u << 20) || ((spin & 255u) == 255u && *poison != 0u)) { *poison = 1u; hc.hits |= 0x80000000u; break; }
+            if (BRT_ASM_COUNT) hc.asm_counts.srv_wait_polls++;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (srv_need) {
+            const lds_u4 r0 = *reinterpret_cast<__attribute__((address_space(3))) lds_u4*>((uintptr_t)srv_slot);
+            const lds_u4 r1 = *reinterpret_cast<__attribute__((address_space(3))) lds_u4*>((uintptr_t)(srv_slot + 16u));
+            ps.rng = r0.x;
+            if (diffuse) acc = acc + mk3(__uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));      // normal + 1.0 * p1 (:285)
+            acc = acc + m1x_of_hit * mk3(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z));     // + roughness * p (:238, :285)
+            if (diffuse) {                                                        // :281-297
+                const float eps = 1e-8f;
+                if (__builtin_fabsf(acc.x) < eps && __builtin_fabsf(acc.y) < eps && __builtin_fabsf(acc.z) < eps) acc = n1;
+                absorbed = dot3(acc, n1) < 0.0f;
+            } else {                                                              // metal, :238-245
+                d = d + acc;
+                absorbed = dot3(d, n1) < 0.0f;
+            }
         }
     }
     // ---- the paths that go on: next segment from the hit point; late ends ----
@@ -478,7 +536,8 @@ BRT_DEV uint32_t pool_peek(const uint32_t* ctl, int i) { return __atomic_load_n(
 #ifndef BRT_PRIO_TOP
 #define BRT_PRIO_TOP 1   // the phase priorities also for scenes walked from the LDS tile + global memory (k_trace_persistent, kPhasePrio)
 #endif
-template <int MODE, bool D16, bool SIMPLE, bool COUNTERS, bool TUNABLE, int LEAN>
+// SRV: the rejection sampler as a stage of the workgroup (brt_device.h ball_server_asm): the last SRV_WAVES waves serve, the others trace.
+template <int MODE, bool D16, bool SIMPLE, bool COUNTERS, bool TUNABLE, int LEAN, bool SRV = false>
 __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView sv, FrameParams fp,
                                                                 uint32_t* __restrict__ queue_counter,
                                                                 float* __restrict__ out_tile,
@@ -487,6 +546,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
                                                                 unsigned long long* __restrict__ counters) {
     static_assert(MODE == SCENE_GLOBAL || D16, "a scene staged in LDS always uses 16-bit descriptors");
     static_assert(!LEAN || (!COUNTERS && !TUNABLE), "LEAN is a specialisation of the production timing kernel");
+    static_assert(!SRV || (LEAN == 2 && MODE == SCENE_LDS && BRT_HAND_ASM), "the sampler stage exists for the steady-state instantiation of an LDS-resident scene");
     using StackT = typename std::conditional<D16, int16_t, int32_t>::type;   // sign-extending loads: brt_layout.h
     extern __shared__ uint4 smem[];
     ScenePtrs sc;
@@ -544,6 +604,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t n_waves = blockDim.x >> 6;
+    const uint32_t n_trace = SRV ? n_waves - SRV_WAVES : n_waves;        // waves that trace (the rest serve the sampler)
     // This lane's column of the wave's [entry][64] stack array.  16-bit entries: lanes l and l + 32 share a dword (column 2 (l mod 32)
     // + l / 32) instead of lanes 2k and 2k + 1: the LDS serves a wave's access 32 lanes at a time, and two lanes of one half that sit at
     // different stack depths would hit the same bank at different addresses -- a 2-way conflict on every pop and push of the walk.
@@ -565,7 +626,18 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     if (fp.pool_cap != 0u) {
         pool_ctl = reinterpret_cast<uint32_t*>(lds + off);
         pool = reinterpret_cast<float4*>(lds + off + 16u);
-        if (threadIdx.x == 0) { pool_ctl[0] = 0u; pool_ctl[1] = 0u; pool_ctl[2] = n_waves; pool_ctl[3] = 0u; }
+        if (threadIdx.x == 0) { pool_ctl[0] = 0u; pool_ctl[1] = 0u; pool_ctl[2] = n_trace; pool_ctl[3] = 0u; }
+    }
+    // sampler stage: behind the pool {16 control words: [0] trace waves alive | a door word per wave | 2 KB of mailbox per trace wave}
+    uint32_t srv_ctl = 0u;
+    if (SRV) {
+        const uint32_t srv_off = off + (fp.pool_cap != 0u ? 16u + fp.pool_cap * POOL_RECORD_BYTES : 0u);
+        uint32_t* const sw = reinterpret_cast<uint32_t*>(lds + srv_off);
+        for (uint32_t i = threadIdx.x; i < srv_lds_bytes(blockDim.x) / 4u; i += blockDim.x) sw[i] = i == 0u ? n_trace : 0u;
+        srv_ctl = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + srv_off);
+        sc.srv_ctl = srv_ctl;
+        sc.srv_door = srv_ctl + 64u + 4u * wave;
+        sc.srv_mbox = srv_ctl + 64u + 4u * n_waves + 2048u * wave;
     }
     // pre-pass of a scene walked from the tile + global memory: this workgroup's histogram of interior visits per record, behind the pool
     constexpr bool kHits = TUNABLE && MODE == SCENE_LDS_TOP;
@@ -578,6 +650,20 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     }
     if (threadIdx.x < WGQ_BYTES / 4u) wgq[threadIdx.x] = 0u;
     __syncthreads();
+    if (SRV && wave >= n_trace) {
+        // a server: trace waves (wave - n_trace), (wave - n_trace) + SRV_WAVES, .. are its own
+        const uint32_t s_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave - n_trace));
+        uint32_t c8[8];
+        ball_server_asm((uint32_t)__builtin_amdgcn_readfirstlane((int)(srv_ctl + 64u + 4u * n_waves)), (uint32_t)__builtin_amdgcn_readfirstlane((int)(srv_ctl + 64u)),
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)srv_ctl), s_id, SRV_WAVES, (n_trace - s_id + SRV_WAVES - 1u) / SRV_WAVES, c8);
+        if (lane == 0) {      // what the stage executed (brt_debug_profile): iterations, lanes in them, door polls, idle polls at the end
+            atomicAdd(&counters[37], (unsigned long long)c8[0]);
+            atomicAdd(&counters[38], (unsigned long long)c8[1]);
+            atomicAdd(&counters[47], (unsigned long long)c8[2]);
+            atomicMax(&counters[48], (unsigned long long)c8[3]);
+        }
+        return;
+    }
     // slots a workgroup takes from the global queue at a time (chosen by the host, brt_api.cpp launch_part)
     const uint32_t wgq_batch = fp.wgq_batch >= 64u ? fp.wgq_batch : 64u;
     // tuning knobs: live in the TUNABLE instantiation, constants (brt_layout.h) in the production one
@@ -626,6 +712,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
 #endif
     if (COUNTERS) t_start = t_mark = wall_clock64();
 
+    uint32_t srv_serial = 0u;         // SRV: number of this wave's rounds so far (the serial of its sampler requests)
     bool tiles_done = false;          // the tile queue (slots FrameParams::queue_lane .. queue_size) is empty
     bool again_mark = false;          // COUNTERS: the round that starts follows another one directly (phase times)
     // lane takes queue slot q of `tile`
@@ -866,8 +953,9 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
         const float t = walk.closest;
         const uint32_t idx = walk.closest_idx;
         if (kPhasePrio != 0 && !wave_crit) __builtin_amdgcn_s_setprio(0);
-        shade_landed<COUNTERS, LEAN, TUNABLE>(sc, fp, landed, t, idx, ps, o, d, tput, bounce, first_depth, active, need_cam, n_rays, hc,
-                                              out_tile, raster_rgba, raster_depth);
+        if (SRV) srv_serial = (srv_serial + 1u) & 0xffffffu;
+        shade_landed<COUNTERS, LEAN, TUNABLE, SRV>(sc, fp, landed, t, idx, ps, o, d, tput, bounce, first_depth, active, need_cam, n_rays, hc,
+                                                   out_tile, raster_rgba, raster_depth, srv_serial);
         again_mark = true;
         {
             // another round at once unless the management code would do something: no live path (next tile / leave), a lane queue, other
@@ -895,6 +983,12 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             if (c != 0u) atomicAdd(&fp.record_hits[i], c);
         }
     }
+    if (SRV) {
+        // this trace wave has ended (no request of it is outstanding): the servers end behind the last one
+        if (lane == 0) __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) uint32_t*>((uintptr_t)srv_ctl), 0xffffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t gave_up = wave_sum(hc.hits >> 31);
+        if (lane == 0 && gave_up != 0u) atomicAdd(&counters[46], (unsigned long long)gave_up);      // (never: a pick-up that ran into its bound)
+    }
     // ---- counters: one atomic per wave ----
     const uint32_t r = wave_sum(n_rays);
     if (lane == 0) atomicAdd(&counters[0], (unsigned long long)r);
@@ -911,6 +1005,8 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
             atomicAdd(&counters[5], (unsigned long long)v[9]);        // calls of that walk  (words 44 and 5 .. 7 are phase times in the COUNTERS build)
             atomicAdd(&counters[6], (unsigned long long)v[10]);       // shader clocks in the row-mode walk ...
             atomicAdd(&counters[7], (unsigned long long)v[11]);       // ... and in the wide hand-written walk (first active lane's view, summed over the waves)
+            const uint32_t wp = wave_sum(c.srv_wait_polls);
+            atomicAdd(&counters[49], (unsigned long long)wp);         // sampler stage: lane-polls of the pick-up
         }
     }
 #endif
@@ -978,9 +1074,9 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
 }
 
 
-template <int MODE, bool D, bool S, bool C, bool T, int LEAN = 0>
+template <int MODE, bool D, bool S, bool C, bool T, int LEAN = 0, bool SRV = false>
 static hipError_t launch_persistent_t(const TraceLaunch& tl) {
-    auto kern = k_trace_persistent<MODE, D, S, C, T, LEAN>;
+    auto kern = k_trace_persistent<MODE, D, S, C, T, LEAN, SRV>;
     if (MODE == SCENE_LDS || MODE == SCENE_LDS_TOP) {
         // the hand-written walk loops (walk_wave_lds_asm, walk_wave_top_asm) address the pair records from LDS address 0: the dynamic LDS must start there
         static const size_t static_lds = [&] {
@@ -1000,6 +1096,8 @@ static hipError_t launch_persistent_t(const TraceLaunch& tl) {
 template <int MODE, bool D, bool T>
 static hipError_t launch_persistent_md(const TraceLaunch& tl) {
     // LEAN instantiations only where they matter: the production timing kernel on a simple (PLOC-shaped) tree staged in LDS
+    if (!T && MODE == SCENE_LDS && tl.lean == 2 && tl.srv != 0u && tl.scene.simple_tree && !tl.counters_on)
+        return launch_persistent_t<MODE, D, true, false, false, (!T && MODE == SCENE_LDS) ? 2 : 0, (!T && MODE == SCENE_LDS && BRT_HAND_ASM)>(tl);
     if (!T && MODE != SCENE_GLOBAL && tl.lean && tl.scene.simple_tree && !tl.counters_on)
         return tl.lean == 2 ? launch_persistent_t<MODE, D, true, false, false, (!T && MODE != SCENE_GLOBAL) ? 2 : 0>(tl)
                             : launch_persistent_t<MODE, D, true, false, false, (!T && MODE != SCENE_GLOBAL) ? 1 : 0>(tl);

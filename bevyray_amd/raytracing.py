@@ -418,6 +418,9 @@ class RaytracePlugin:
         self.last_asm_counts = {"interior": (int(raw[33]), int(raw[34])), "leaf": (int(raw[35]), int(raw[36])), "ball": (int(raw[37]), int(raw[38])),
                                 "repairing_loop_lanes": (int(raw[39]), int(raw[43])), "rows_interior_exec": int(raw[44]), "rows_calls": int(raw[5]),
                                 "rows_cycles": int(raw[6]), "wide_cycles": int(raw[7])}
+        # sampler stage (knob BRT_BALL_SERVERS): what the server waves executed, pick-ups that ran into their bound (must be 0)
+        self.last_sampler_stage = {"iterations": int(raw[37]), "lanes": int(raw[38]), "gave_up": int(raw[46]), "door_polls": int(raw[47]),
+                                   "idle_polls_at_end_max": int(raw[48]), "pickup_lane_polls": int(raw[49])}
         names = ["interior", "leaf", "camera", "scatter", "sky", "ball", "camera_top", "round"]
         prof = {n: (int(raw[8 + 2 * k]), int(raw[9 + 2 * k])) for k, n in enumerate(names)}
         # wave time stamps (100 MHz wall clock): first start, first / last "pixel queue empty", last end

@@ -364,6 +364,31 @@ def test_error_behaviour(plugin):
         plugin.node.run(lvl, cam, win, 0, 18)
 
 
+def test_sampler_stage_of_the_workgroup_renders_the_same_pixels(oracle):
+    """The rejection sampler as a STAGE of the workgroup (knob BRT_BALL_SERVERS; brt_trace.h SRV, brt_device.h ball_server_asm): fourteen
+    waves trace, two serve the other waves' samplers through mailboxes in LDS.  A lane's draws are the same hash chain whichever wave
+    runs them: whole frames and ray counts equal the oracle's, in the steady-state instantiation (kernel_variant 2 + 32) the stage exists
+    for; no pick-up runs into its bound."""
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    bb = brt.Buffers(b.models, b.materials, None)
+    for (w, h, spp, bounces) in ((1920, 1080, 4, 2), (1920, 1080, 8, 8)):
+        lvl, cam, win = brt.cover_camera(w, h, spp, bounces)
+        want, cnt = oracle.render(b, lvl, cam, win, w, h)
+        with brt.RaytracePlugin([0]) as p:
+            p.set_tuning("BRT_BALL_SERVERS", 1)
+            seen = set()
+            for i in range(6):
+                f = p.node.run(lvl, cam, win, w, h, buffers=bb if i == 0 else None)
+                st = dict(p.node.last_stats)
+                seen.add(st["kernel_variant"])
+                assert st["rays"] == cnt["rays"], (i, st["kernel_variant"])
+                assert_frames_equal(f, want)
+            assert st["kernel_variant"] == 2 + 32, seen                    # the last frames ran in the instantiation with the stage
+            p.debug_profile()
+            stage = p.last_sampler_stage
+            assert stage["gave_up"] == 0 and stage["iterations"] > 0 and stage["lanes"] > stage["iterations"], stage
+
+
 def test_exception_barrier_on_exports_that_own_a_context(plugin, oracle):
     """include/bevyray_amd.h: no export throws across the boundary.  The knob BRT_TEST_THROW makes the next brt_upload_scene / brt_render*
     throw std::bad_alloc (1), std::logic_error (2) or a non-standard type (3) from inside the call: an error code and a text come back,
