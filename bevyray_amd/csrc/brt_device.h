@@ -331,6 +331,9 @@ BRT_DEV void ball_loop_asm(uint32_t& rng, f3& acc, float rough, uint64_t m2, uin
 #ifndef BRT_SRV_PATIENCE
 #define BRT_SRV_PATIENCE 8
 #endif
+#ifndef BRT_SRV_PRIO
+#define BRT_SRV_PRIO "s_setprio 3\n"
+#endif
 BRT_DEV void ball_server_asm(uint32_t mbox, uint32_t door, uint32_t ctl, uint32_t first, uint32_t stride, uint32_t n_mine, uint32_t* counts8) {
     const uint32_t low = BRT_SRV_LOW, patience = BRT_SRV_PATIENCE;
 #if BRT_HAND_ASM
@@ -349,7 +352,7 @@ BRT_DEV void ball_server_asm(uint32_t mbox, uint32_t door, uint32_t ctl, uint32_
     "v_cvt_f32_u32_e32 " dst ", v100\n"                                                                                    \
     "v_fma_f32 " dst ", " dst ", %[c_2m31], -1.0\n"
     asm volatile(
-        "s_setprio 3\n"
+        BRT_SRV_PRIO
         "s_mov_b64 %[m2], 0\n s_mov_b64 %[m1], 0\n s_mov_b32 %[pos], 0\n s_mov_b32 %[cnt], 0\n s_mov_b32 %[idle], 0\n"
         "s_mov_b32 %[c_iter], 0\n s_mov_b32 %[c_lanes], 0\n s_mov_b32 %[c_polls], 0\n s_mov_b32 %[base], 0\n s_mov_b32 %[stall], 0\n"
         "v_mbcnt_lo_u32_b32 v112, -1, 0\n"
