@@ -131,7 +131,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.brt_abi_version() != 5:
+    if lib.brt_abi_version() != 6:
         raise RuntimeError("libbevyray_amd.so ABI version mismatch")
     _lib = lib
     return lib

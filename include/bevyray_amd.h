@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define BRT_ABI_VERSION 5u
+#define BRT_ABI_VERSION 6u
 
 /* Rows per strip of the interleaved row tiling. */
 #define BRT_STRIP_ROWS 8u

@@ -2,7 +2,7 @@
 # The library's HOST side (brt_api.cpp, brt_interop.cpp, brt_host.cpp: validation, encoders, both CPU BVH builders, tree reach rule,
 # store-format tables, RCCL loader) compiled by g++ with AddressSanitizer + UndefinedBehaviorSanitizer, linked with the hipcc-built
 # kernel objects, and the CPU test suite run against it (BRT_LIB_PATH).  CPU only: the GPU boxes run no sanitizers.
-#   bash scripts/asan_host.sh            -> "59 passed", 0 sanitizer reports expected
+#   bash scripts/asan_host.sh            -> all passed (the address-space-cap test skips itself), 0 sanitizer reports expected
 set -e
 root="$(cd "$(dirname "$0")/.." && pwd)"
 src="$root/bevyray_amd/csrc"

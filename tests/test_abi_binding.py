@@ -26,7 +26,7 @@ def test_rust_binding_declares_exactly_the_headers_exports():
 
 
 def test_rust_binding_constants_stats_layout_and_abi_version():
-    assert RUST["abi"] == HEADER["abi"] == 5
+    assert RUST["abi"] == HEADER["abi"] == 6
     for name, value in HEADER["constants"].items():
         assert RUST["constants"].get(name) == value, name
     assert not set(RUST["constants"]) - set(HEADER["constants"])
