@@ -246,9 +246,10 @@ uint64_t camera_hash(const FrameParams& fp) {
 // re-uploads every frame, extract.rs:299-336, and moves little between two frames) and is measured again soon after one
 // (brt_upload_scene ages it); it never affects pixels.  The ray count of a view (LEAN = 2: "no pixel chain can be
 // critical") additionally depends on sample and bounce counts; a wrong guess after a scene change only costs speed.
-void order_key_of(const brt_ctx*, const FrameParams& fp, uint32_t key[6]) {
+void order_key_of(const brt_ctx* ctx, const FrameParams& fp, uint32_t key[6]) {
     key[0] = fp.width; key[1] = fp.height; key[2] = fp.part; key[3] = fp.n_parts;
-    key[4] = 0u; key[5] = fp.local_strips * fp.tiles_x;
+    key[4] = fp.strip_of ? ctx->strip_epoch : 0u;      // (another strip table: other strips, other costs)
+    key[5] = fp.local_strips * fp.tiles_x;
 }
 void view_key_of(const brt_ctx* ctx, const FrameParams& fp, uint32_t key[8]) {
     order_key_of(ctx, fp, key);
@@ -763,6 +764,8 @@ int32_t read_counters(brt_ctx* ctx, DeviceCtx& dc, hipStream_t stream, brt_stats
 uint64_t part_pixels(const FrameParams& fp) {
     uint64_t rows = 0;
     const uint32_t strips = (fp.height + BRT_STRIP_ROWS - 1u) / BRT_STRIP_ROWS;
+    // (a part has one strip in every group of n_parts strips whatever the strip table says -- except in the last, partial group:
+    //  callers with a table correct that: strip_table_attach)
     for (uint32_t s = fp.part; s < strips; s += fp.n_parts) {
         const uint32_t r0 = s * BRT_STRIP_ROWS;
         rows += (r0 + BRT_STRIP_ROWS <= fp.height) ? BRT_STRIP_ROWS : (fp.height - r0);
@@ -774,6 +777,7 @@ void free_device(DeviceCtx& dc) {
     if (hipSetDevice(dc.device) != hipSuccess) return;
     if (dc.d_scene) (void)hipFree(dc.d_scene);
     if (dc.d_ctrl) (void)hipFree(dc.d_ctrl);
+    if (dc.d_strip_table) (void)hipFree(dc.d_strip_table);
     if (dc.d_tile) (void)hipFree(dc.d_tile);
     if (dc.d_gather) (void)hipFree(dc.d_gather);
     if (dc.d_pack) (void)hipFree(dc.d_pack);
@@ -1188,6 +1192,63 @@ int32_t upload_scene(brt_ctx* ctx, const void* models, uint32_t n_models, const 
 
 }  // namespace
 
+namespace brt {
+
+// ---- strip table (brt_set_strip_table) ------------------------------------------------------------------------------
+// Strips go to parts by `s mod N` unless the caller sets a table.  A table permutes the parts INSIDE every group of N consecutive strips,
+// so a part still has exactly one strip per group: its k-th local strip lies in group k, tiles keep their size and layout, the ONE gather
+// stays as it is, and only two lookups change -- the kernel's "local strip -> frame strip" (FrameParams::strip_of) and the assembly's
+// "frame strip -> part" (k_deinterleave).  Pixels cannot change: a pixel's seed depends on its frame coordinates (raytrace.wgsl:95).
+// brt_plan_strips makes such a table from measured costs: the frame is rendered once at a few samples per pixel on THIS device with the
+// per-tile ray counts switched on, and the strips of every group are dealt out, dearest strip to the part with the least so far.  Every
+// rank computes the same table from the same integers (the kernel is deterministic), so no second collective is needed.
+bool strip_table_valid(const uint32_t* t, uint32_t n_strips, uint32_t n_parts) {
+    if (n_parts == 0u || n_parts > 64u) return false;
+    for (uint32_t g = 0; g * n_parts < n_strips; g++) {
+        uint64_t seen = 0;
+        for (uint32_t s = g * n_parts; s < n_strips && s < (g + 1u) * n_parts; s++) {
+            if (t[s] >= n_parts || (seen >> t[s]) & 1ull) return false;
+            seen |= 1ull << t[s];
+        }
+    }
+    return true;
+}
+// the device copies for `part` on device dc (made once per table and part): *part_of_strip for the assembly, fp->strip_of for the kernel
+int32_t strip_table_attach(brt_ctx* ctx, DeviceCtx& dc, FrameParams* fp, const uint32_t** part_of_strip, hipStream_t stream) {
+    if (part_of_strip) *part_of_strip = nullptr;
+    const uint32_t strips = fp ? (fp->height + BRT_STRIP_ROWS - 1u) / BRT_STRIP_ROWS : (uint32_t)ctx->strip_part.size();
+    const uint32_t n_parts = fp ? fp->n_parts : ctx->strip_n_parts;
+    if (ctx->strip_part.empty() || ctx->strip_n_parts != n_parts || ctx->strip_part.size() != strips || n_parts < 2u) return BRT_OK;
+    const uint32_t part = fp ? fp->part : 0u, local = (strips + n_parts - 1u) / n_parts;
+    if (dc.strip_epoch != ctx->strip_epoch || dc.strip_part != part || !dc.d_strip_table) {
+        std::vector<uint32_t> h(ctx->strip_part);
+        h.resize((size_t)strips + local, 0xffffffu);                           // strip_of: a group without a strip of this part: padding
+        for (uint32_t s = 0; s < strips; s++)
+            if (ctx->strip_part[s] == part) h[(size_t)strips + s / n_parts] = s;
+        int32_t rc = ensure(ctx, &dc.d_strip_table, &dc.strip_table_cap, h.size() * 4u);
+        if (rc != BRT_OK) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(dc.d_strip_table, h.data(), h.size() * 4u, hipMemcpyHostToDevice, stream));
+        HIP_TRY(ctx, hipStreamSynchronize(stream));                            // (h is a local; once per table)
+        dc.strip_epoch = ctx->strip_epoch;
+        dc.strip_part = part;
+    }
+    const uint32_t* d = reinterpret_cast<const uint32_t*>(dc.d_strip_table);
+    if (part_of_strip) *part_of_strip = d;
+    if (fp) fp->strip_of = d + strips;
+    return BRT_OK;
+}
+uint64_t part_pixels_table(const brt_ctx* ctx, const FrameParams& fp) {
+    uint64_t rows = 0;
+    for (uint32_t s = 0; s < (uint32_t)ctx->strip_part.size(); s++)
+        if (ctx->strip_part[s] == fp.part) {
+            const uint32_t r0 = s * BRT_STRIP_ROWS;
+            rows += (r0 + BRT_STRIP_ROWS <= fp.height) ? BRT_STRIP_ROWS : (fp.height - r0);
+        }
+    return rows * fp.width;
+}
+
+}  // namespace brt
+
 extern "C" {
 
 uint32_t brt_tile_rows(uint32_t height, uint32_t n_parts) {
@@ -1227,6 +1288,8 @@ int32_t render_part_device(brt_ctx* ctx, const void* camera80, const void* windo
     HIP_TRY(ctx, hipSetDevice(dc.device));
     const bool own_stream = (hip_stream == nullptr) && !(flags & BRT_FLAG_CALLER_STREAM);
     hipStream_t stream = own_stream ? dc.stream : static_cast<hipStream_t>(hip_stream);
+    rc = strip_table_attach(ctx, dc, &fp, nullptr, stream);        // the context's strip table, if it is one for this frame and split
+    if (rc != BRT_OK) return rc;
     bool prepass_ran = false;
     if (own_stream) {
         rc = prepass_order(ctx, dc, fp, d_raster_rgba, d_raster_depth, d_out_tile, stream, flags, &prepass_ran);
@@ -1239,7 +1302,7 @@ int32_t render_part_device(brt_ctx* ctx, const void* camera80, const void* windo
     if (rc != BRT_OK) return rc;
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
-        stats->paths = part_pixels(fp) * (uint64_t)fp.sample_count;
+        stats->paths = (fp.strip_of ? part_pixels_table(ctx, fp) : part_pixels(fp)) * (uint64_t)fp.sample_count;
         stats->lds_bytes = (uint32_t)lp.lds_bytes;
         stats->scene_in_lds = lp.scene_mode == SCENE_LDS ? 1u : (lp.scene_mode == SCENE_LDS_TOP ? 2u : 0u);
         stats->n_workgroups = lp.grid;
@@ -1634,6 +1697,72 @@ int32_t brt_render_device(brt_ctx* ctx, const void* camera80, const void* window
     });
 }
 
+int32_t brt_set_strip_table(brt_ctx* ctx, uint32_t n_parts, uint32_t n_strips, const uint32_t* part_of_strip) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
+    if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
+    ctx->strip_epoch++;
+    if (!part_of_strip) { ctx->strip_part.clear(); ctx->strip_n_parts = 0u; return BRT_OK; }
+    if (n_parts < 1u || n_strips < 1u || n_strips > 4096u) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "n_parts / n_strips out of range");
+    if (!strip_table_valid(part_of_strip, n_strips, n_parts))
+        return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "strip table: every group of n_parts consecutive strips must hold each part at most once");
+    ctx->strip_part.assign(part_of_strip, part_of_strip + n_strips);
+    ctx->strip_n_parts = n_parts;
+    return BRT_OK;
+    });
+}
+
+int32_t brt_plan_strips(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level, uint32_t width, uint32_t height,
+                        uint32_t n_parts, uint32_t probe_spp, uint32_t* out_part_of_strip) {
+    return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
+    if (!ctx) return fail(BRT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (!ctx->has_scene) return ctx_fail(ctx, BRT_ERR_NO_SCENE, "no scene uploaded");
+    if (n_parts < 1u || n_parts > 64u || probe_spp < 1u) return ctx_fail(ctx, BRT_ERR_INVALID_ARGUMENT, "n_parts must be 1..64, probe_spp >= 1");
+    FrameParams fp;
+    int32_t rc = make_frame_params(ctx, camera80, window16, level == 0u ? 3u : level, width, height, 0u, 1u, &fp);
+    if (rc != BRT_OK) return rc;
+    fp.sample_count = probe_spp;
+    fp.spp_f = (float)probe_spp;
+    DeviceCtx& dc = ctx->devs[0];
+    HIP_TRY(ctx, hipSetDevice(dc.device));
+    const uint32_t n_tiles = fp.local_strips * fp.tiles_x, strips = fp.local_strips;
+    rc = ensure(ctx, &dc.d_tile, &dc.tile_cap, (size_t)strips * BRT_STRIP_ROWS * width * 16u);
+    if (rc != BRT_OK) return rc;
+    rc = ensure(ctx, &dc.d_tile_cost, &dc.tile_cost_cap, (size_t)n_tiles * 8u);
+    if (rc != BRT_OK) return rc;
+    HIP_TRY(ctx, hipStreamWaitEvent(dc.stream, dc.ev_last, 0));
+    HIP_TRY(ctx, hipMemsetAsync(dc.d_tile_cost, 0, (size_t)n_tiles * 8u, dc.stream));
+    fp.tile_cost = dc.d_tile_cost;                              // ray sums per tile (then maxima)
+    rc = launch_part(ctx, dc, fp, nullptr, nullptr, dc.d_tile, dc.stream, 0u, false, nullptr);
+    if (rc != BRT_OK) return rc;
+    std::vector<uint32_t> cost(n_tiles);
+    HIP_TRY(ctx, hipMemcpyAsync(cost.data(), dc.d_tile_cost, (size_t)n_tiles * 4u, hipMemcpyDeviceToHost, dc.stream));
+    HIP_TRY(ctx, hipStreamSynchronize(dc.stream));
+    dc.costs_valid = false;                                     // (the cost buffer no longer holds a view's measurement)
+    std::vector<uint64_t> strip_cost(strips, 0), load(n_parts, 0);
+    for (uint32_t t = 0; t < n_tiles; t++) strip_cost[t / fp.tiles_x] += cost[t];
+    // groups from the dearest down (their strips matter most for the balance), inside a group the dearest strip to the part with the
+    // least so far; ties by index: a function of the integers alone
+    std::vector<uint32_t> groups((strips + n_parts - 1u) / n_parts), table(strips, 0u);
+    std::vector<uint64_t> gcost(groups.size(), 0);
+    for (uint32_t s = 0; s < strips; s++) gcost[s / n_parts] += strip_cost[s];
+    for (uint32_t g = 0; g < groups.size(); g++) groups[g] = g;
+    std::stable_sort(groups.begin(), groups.end(), [&](uint32_t a, uint32_t b) { return gcost[a] > gcost[b]; });
+    for (uint32_t g : groups) {
+        std::vector<uint32_t> ss, ps(n_parts);
+        for (uint32_t s = g * n_parts; s < strips && s < (g + 1u) * n_parts; s++) ss.push_back(s);
+        for (uint32_t p = 0; p < n_parts; p++) ps[p] = p;
+        std::stable_sort(ss.begin(), ss.end(), [&](uint32_t a, uint32_t b) { return strip_cost[a] > strip_cost[b]; });
+        std::stable_sort(ps.begin(), ps.end(), [&](uint32_t a, uint32_t b) { return load[a] < load[b]; });
+        for (size_t i = 0; i < ss.size(); i++) { table[ss[i]] = ps[i]; load[ps[i]] += strip_cost[ss[i]]; }
+    }
+    if (out_part_of_strip) std::memcpy(out_part_of_strip, table.data(), (size_t)strips * 4u);
+    ctx->strip_epoch++;
+    ctx->strip_part = table;
+    ctx->strip_n_parts = n_parts;
+    return BRT_OK;
+    });
+}
+
 int32_t brt_deinterleave_device(brt_ctx* ctx, const float* d_tiles, uint32_t n_parts, uint32_t width, uint32_t height,
                                 void* d_frame, void* hip_stream, uint32_t flags) {
     return guard(ctx ? &ctx->last_error : nullptr, [&]() -> int32_t {
@@ -1643,7 +1772,14 @@ int32_t brt_deinterleave_device(brt_ctx* ctx, const float* d_tiles, uint32_t n_p
     HIP_TRY(ctx, hipSetDevice(dc.device));
     const bool own_stream = (hip_stream == nullptr) && !(flags & BRT_FLAG_CALLER_STREAM);
     hipStream_t stream = own_stream ? dc.stream : static_cast<hipStream_t>(hip_stream);
-    HIP_TRY(ctx, launch_deinterleave(d_tiles, d_frame, width, height, n_parts, brt_tile_rows(height, n_parts), flags & BRT_FLAG_OUT_MASK, stream));
+    const uint32_t* part_of_strip = nullptr;
+    {
+        FrameParams key{};                                        // (which frame and split: the table must be one for them)
+        key.height = height; key.n_parts = n_parts; key.part = 0u;
+        int32_t rc = strip_table_attach(ctx, ctx->devs[0], &key, &part_of_strip, stream);
+        if (rc != BRT_OK) return rc;
+    }
+    HIP_TRY(ctx, launch_deinterleave(d_tiles, d_frame, width, height, n_parts, brt_tile_rows(height, n_parts), flags & BRT_FLAG_OUT_MASK, stream, part_of_strip));
     if (own_stream) HIP_TRY(ctx, hipStreamSynchronize(stream));
     return BRT_OK;
     });

@@ -58,6 +58,10 @@ struct DeviceCtx {
     uint32_t order_crit = 0;                             // d_tile_order[0 .. crit) are the CRITICAL tiles
     size_t tile_order_cap = 0;
     uint32_t* d_order_meta = nullptr;                    // order built on the GPU: [0] critical tiles, [1] longest pixel
+    // strip table on this device (brt_set_strip_table): part_of_strip[n_strips], then strip_of[local_strips] of `strip_part`
+    char* d_strip_table = nullptr;
+    size_t strip_table_cap = 0;
+    uint32_t strip_epoch = 0, strip_part = 0xffffffffu;  // the ctx->strip_epoch / part the device copy was made for
     char* d_order_scratch = nullptr;
     size_t order_scratch_cap = 0;
     bool order_on_device = false;                        // d_tile_order / d_order_meta were written by brt_order.hip
@@ -138,6 +142,11 @@ struct brt_ctx {
     brt::EncodedScene enc;
     bool has_scene = false;
     uint32_t scene_epoch = 0;   // bumped by every upload
+    // Strip table (brt_set_strip_table): strip_part[s] = the part that renders frame strip s, a permutation of the parts inside every
+    // group of n_parts consecutive strips (so that a part's k-th local strip lies in group k: tile layout and gather stay as they are).
+    // Empty: strip s belongs to part s % n_parts.
+    std::vector<uint32_t> strip_part;
+    uint32_t strip_n_parts = 0, strip_epoch = 0;
     uint32_t tree_epoch = 0;    // bumped whenever the encoded tree on the devices is rewritten (uploads, rebuilds for the camera's reach)
     uint32_t last_n_models = 0; // spheres of the last successful upload
     std::vector<std::pair<char*, size_t>> pinned;   // brt_host_alloc blocks
@@ -186,4 +195,12 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 void release_external_frames(brt_ctx* ctx);   // brt_interop.cpp; called by brt_destroy
 
+}  // namespace brt
+
+namespace brt {
+// strip table (brt_api.cpp): the device copies for fp->part on dc; *part_of_strip (frame strip -> part) for the assembly, fp->strip_of
+// (this part's k-th local strip -> frame strip) for the kernel.  Nothing is attached when the context holds no table for fp's frame and split.
+bool strip_table_valid(const uint32_t* part_of_strip, uint32_t n_strips, uint32_t n_parts);
+int32_t strip_table_attach(brt_ctx* ctx, DeviceCtx& dc, FrameParams* fp, const uint32_t** part_of_strip, hipStream_t stream);
+uint64_t part_pixels_table(const brt_ctx* ctx, const FrameParams& fp);
 }  // namespace brt

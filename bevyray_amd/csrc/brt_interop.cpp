@@ -196,8 +196,14 @@ int32_t brt_gather_rccl(brt_ctx* ctx, void* nccl_comm, int32_t rank, int32_t wor
     const size_t count = (size_t)tile_rows * width * 4;                                           // floats per rank
     const int rc = r.gather(d_tile, d_tiles_on_root, count, kNcclFloat, 0, nccl_comm, stream);      // THE collective of the path
     if (rc != 0) return nccl_fail(ctx, "ncclGather", rc);
-    if (rank == 0 && d_frame_on_root)
-        HIP_TRY(ctx, launch_deinterleave(d_tiles_on_root, d_frame_on_root, width, height, (uint32_t)world, tile_rows, flags & BRT_FLAG_OUT_MASK, stream));
+    if (rank == 0 && d_frame_on_root) {
+        const uint32_t* part_of_strip = nullptr;                   // the context's strip table (brt_set_strip_table), if it is one for this frame and split
+        FrameParams key{};
+        key.height = height; key.n_parts = (uint32_t)world; key.part = 0u;
+        const int32_t rt = strip_table_attach(ctx, dc, &key, &part_of_strip, stream);
+        if (rt != BRT_OK) return rt;
+        HIP_TRY(ctx, launch_deinterleave(d_tiles_on_root, d_frame_on_root, width, height, (uint32_t)world, tile_rows, flags & BRT_FLAG_OUT_MASK, stream, part_of_strip));
+    }
     if (own_stream) HIP_TRY(ctx, hipStreamSynchronize(stream));
     return BRT_OK;
     });

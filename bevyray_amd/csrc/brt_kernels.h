@@ -40,8 +40,9 @@ hipError_t launch_trace_persistent(const TraceLaunch& tl);
 hipError_t launch_trace_simple(const TraceLaunch& tl);
 hipError_t launch_passthrough(const FrameParams& fp, float* out_tile, const float* raster_rgba, hipStream_t stream);
 // out_format: BRT_FLAG_OUT_* (include/bevyray_amd.h): the frame is written in the colour target's own format
+// part_of_strip: the context's strip table on this device (frame strip -> part), or null: strip s belongs to part s % n_parts
 hipError_t launch_deinterleave(const float* tiles, void* frame, uint32_t width, uint32_t height, uint32_t n_parts,
-                               uint32_t tile_rows, uint32_t out_format, hipStream_t stream);
+                               uint32_t tile_rows, uint32_t out_format, hipStream_t stream, const uint32_t* part_of_strip = nullptr);
 // the strips of parts 1 .. n_parts-1 of a full-frame input (floats_per_pixel 4: colour, 1: depth), each part densely in its tile layout:
 // packed[(part - 1) * tile_rows * width ...]
 hipError_t launch_pack_strips(const float* frame, float* packed, uint32_t width, uint32_t height, uint32_t n_parts, uint32_t tile_rows,

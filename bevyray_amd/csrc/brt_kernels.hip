@@ -157,12 +157,13 @@ template <> struct OutPixel<BRT_FLAG_OUT_RGBA16F> {
 
 template <uint32_t FMT>
 __global__ void k_deinterleave(const float4* __restrict__ tiles, typename OutPixel<FMT>::type* __restrict__ frame, uint32_t width,
-                               uint32_t height, uint32_t n_parts, uint32_t tile_rows) {
+                               uint32_t height, uint32_t n_parts, uint32_t tile_rows, const uint32_t* __restrict__ part_of_strip) {
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t y = blockIdx.y;
     if (x >= width || y >= height) return;
     const uint32_t strip = y / 8u, r = y - strip * 8u;
-    const uint32_t part = strip % n_parts, k = strip / n_parts;
+    // (a strip table -- brt_set_strip_table -- permutes the parts inside every group of n_parts strips: the local strip is the group)
+    const uint32_t part = part_of_strip ? part_of_strip[strip] : strip % n_parts, k = strip / n_parts;
     frame[(size_t)y * width + x] = OutPixel<FMT>::make(tiles[((size_t)part * tile_rows + (k * 8u + r)) * width + x]);
 }
 
@@ -326,18 +327,18 @@ hipError_t launch_passthrough(const FrameParams& fp, float* out_tile, const floa
 
 template <uint32_t FMT>
 static void launch_deinterleave_t(const float* tiles, void* frame, uint32_t width, uint32_t height, uint32_t n_parts, uint32_t tile_rows,
-                                  hipStream_t stream) {
+                                  const uint32_t* part_of_strip, hipStream_t stream) {
     hipLaunchKernelGGL(k_deinterleave<FMT>, dim3((width + 255u) / 256u, height), dim3(256), 0, stream, reinterpret_cast<const float4*>(tiles),
-                       reinterpret_cast<typename OutPixel<FMT>::type*>(frame), width, height, n_parts, tile_rows);
+                       reinterpret_cast<typename OutPixel<FMT>::type*>(frame), width, height, n_parts, tile_rows, part_of_strip);
 }
 hipError_t launch_deinterleave(const float* tiles, void* frame, uint32_t width, uint32_t height, uint32_t n_parts,
-                               uint32_t tile_rows, uint32_t out_format, hipStream_t stream) {
+                               uint32_t tile_rows, uint32_t out_format, hipStream_t stream, const uint32_t* part_of_strip) {
     if (width == 0 || height == 0) return hipSuccess;
     switch (out_format) {
-        case BRT_FLAG_OUT_RGBA32F: launch_deinterleave_t<BRT_FLAG_OUT_RGBA32F>(tiles, frame, width, height, n_parts, tile_rows, stream); break;
-        case BRT_FLAG_OUT_RGBA8_UNORM_SRGB: launch_deinterleave_t<BRT_FLAG_OUT_RGBA8_UNORM_SRGB>(tiles, frame, width, height, n_parts, tile_rows, stream); break;
-        case BRT_FLAG_OUT_RGBA16F: launch_deinterleave_t<BRT_FLAG_OUT_RGBA16F>(tiles, frame, width, height, n_parts, tile_rows, stream); break;
-        case BRT_FLAG_OUT_RGBA8_UNORM: launch_deinterleave_t<BRT_FLAG_OUT_RGBA8_UNORM>(tiles, frame, width, height, n_parts, tile_rows, stream); break;
+        case BRT_FLAG_OUT_RGBA32F: launch_deinterleave_t<BRT_FLAG_OUT_RGBA32F>(tiles, frame, width, height, n_parts, tile_rows, part_of_strip, stream); break;
+        case BRT_FLAG_OUT_RGBA8_UNORM_SRGB: launch_deinterleave_t<BRT_FLAG_OUT_RGBA8_UNORM_SRGB>(tiles, frame, width, height, n_parts, tile_rows, part_of_strip, stream); break;
+        case BRT_FLAG_OUT_RGBA16F: launch_deinterleave_t<BRT_FLAG_OUT_RGBA16F>(tiles, frame, width, height, n_parts, tile_rows, part_of_strip, stream); break;
+        case BRT_FLAG_OUT_RGBA8_UNORM: launch_deinterleave_t<BRT_FLAG_OUT_RGBA8_UNORM>(tiles, frame, width, height, n_parts, tile_rows, part_of_strip, stream); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -172,7 +172,9 @@ struct FrameParams {
     float near_, far_, fallback_far;
     float spp_f;                     // f32(sample_count)
     // work decomposition
-    uint32_t part, n_parts;          // interleaved strips: strip s -> part s % n_parts
+    uint32_t part, n_parts;          // interleaved strips: strip s -> part s % n_parts, unless ...
+    const uint32_t* strip_of;        // ... a strip table is set (brt_set_strip_table): frame strip of this part's k-th local strip (local_strips entries;
+                                     // a strip index past the frame: padding), or null
     uint32_t tiles_x;                // ceil(width / 8)
     uint32_t local_strips;           // strips owned by this part (padded count)
     uint32_t queue_size;             // local_strips * tiles_x * 64

@@ -40,7 +40,7 @@ BRT_DEV PixelCoord slot_to_pixel(const FrameParams& fp, uint32_t q, uint32_t til
     c.px = tx * 8u + (t & 7u);
     const uint32_t r = t >> 3;
     c.local_row = strip * 8u + r;
-    c.py = (strip * fp.n_parts + fp.part) * 8u + r;
+    c.py = (fp.strip_of ? fp.strip_of[strip] : strip * fp.n_parts + fp.part) * 8u + r;
     c.tile = tile;
     c.t = t;
     c.inside = (c.px < fp.width) && (c.py < fp.height);

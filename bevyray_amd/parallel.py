@@ -16,17 +16,34 @@ import numpy as np
 from .raytracing import STRIP_ROWS, tile_rows
 
 
-def frame_rows_of_part(height: int, part: int, n_parts: int) -> np.ndarray:
-    """Frame row of every tile row of `part` (-1 for padding rows past the frame)."""
+def check_strip_table(table, height: int, n_parts: int) -> np.ndarray:
+    """A strip table (include/bevyray_amd.h brt_set_strip_table): table[s] = the part of frame strip s, a permutation of the parts inside
+    every group of n_parts consecutive strips.  Returns it as an array, raises ValueError if it is not one."""
+    t = np.asarray(table, np.int64)
+    strips = (height + STRIP_ROWS - 1) // STRIP_ROWS
+    if t.shape != (strips,) or t.min(initial=0) < 0 or t.max(initial=0) >= n_parts:
+        raise ValueError("strip table: one part < n_parts per strip of the frame")
+    for g in range(0, strips, n_parts):
+        grp = t[g:g + n_parts]
+        if len(set(grp.tolist())) != len(grp):
+            raise ValueError(f"strip table: group {g // n_parts} holds a part twice")
+    return t
+
+
+def frame_rows_of_part(height: int, part: int, n_parts: int, table=None) -> np.ndarray:
+    """Frame row of every tile row of `part` (-1 for padding rows past the frame).  table: a strip table (brt_set_strip_table /
+    brt_plan_strips), or None: strip s belongs to part s % n_parts.  Either way the part's k-th local strip lies in group k."""
     rows = np.full(tile_rows(height, n_parts), -1, np.int64)
     strips = (height + STRIP_ROWS - 1) // STRIP_ROWS
-    k = 0
-    for s in range(part, strips, n_parts):
+    t = None if table is None else check_strip_table(table, height, n_parts)
+    for s in range(strips):
+        if (s % n_parts if t is None else int(t[s])) != part:
+            continue
+        k = s // n_parts
         for r in range(STRIP_ROWS):
             y = s * STRIP_ROWS + r
             if y < height:
                 rows[k * STRIP_ROWS + r] = y
-        k += 1
     return rows
 
 
@@ -87,7 +104,7 @@ class RcclGather:
             self.comm = 0
 
 
-def gather_frame(tile, height: int, rank: int, world: int, node=None, group=None, rccl: Optional["RcclGather"] = None):
+def gather_frame(tile, height: int, rank: int, world: int, node=None, group=None, rccl: Optional["RcclGather"] = None, table=None):
     """Gathers the per-rank tiles (torch tensors [tile_rows, W, 4] f32, same shape on every
     rank) on rank 0 and returns the de-interleaved frame [height, W, 4] there (None elsewhere).
 
@@ -137,7 +154,7 @@ def gather_frame(tile, height: int, rank: int, world: int, node=None, group=None
         return frame
     frame = torch.empty((height, width, 4), dtype=torch.float32)
     for p in range(world):
-        rows = frame_rows_of_part(height, p, world)
+        rows = frame_rows_of_part(height, p, world, table)      # (table: the strip table every rank rendered with; the GPU paths take it from the context)
         valid = rows >= 0
         frame[torch.from_numpy(rows[valid])] = tiles[p][torch.from_numpy(np.flatnonzero(valid))]
     return frame

@@ -392,6 +392,24 @@ class RaytracePlugin:
         _lib.check(self._lib.brt_debug_copy_to_host(self._ctx, d_src, out.ctypes.data, out.nbytes), self._ctx)
         return out
 
+    # -- strips by measured cost (one process per GPU) --------------------------------------------------------------------
+    def set_strip_table(self, n_parts: int, part_of_strip) -> None:
+        """brt_set_strip_table: part_of_strip[s] = the part that renders frame strip s (a permutation of the parts inside every group of
+        n_parts consecutive strips); None: back to s % n_parts.  Every rank sets the same table."""
+        if part_of_strip is None:
+            _lib.check(self._lib.brt_set_strip_table(self._ctx, int(n_parts), 0, None), self._ctx)
+            return
+        t = np.ascontiguousarray(part_of_strip, np.uint32)
+        _lib.check(self._lib.brt_set_strip_table(self._ctx, int(n_parts), len(t), t.ctypes.data), self._ctx)
+
+    def plan_strips(self, level, camera, window, width: int, height: int, n_parts: int, probe_spp: int = 4) -> np.ndarray:
+        """brt_plan_strips: renders the frame once at probe_spp samples per pixel with the per-tile ray counts on, deals the strips of
+        every group of n_parts out by cost, installs the table and returns it (deterministic: every rank gets the same one)."""
+        t = np.zeros((height + STRIP_ROWS - 1) // STRIP_ROWS, np.uint32)
+        _lib.check(self._lib.brt_plan_strips(self._ctx, camera.ctypes.data, window.ctypes.data, int(level["level"][0]), width, height,
+                                             int(n_parts), int(probe_spp), t.ctypes.data), self._ctx)
+        return t
+
     # -- the RCCL gather behind the C ABI (one process per GPU) -----------------------------------------------------------
     @staticmethod
     def rccl_unique_id() -> bytes:

@@ -249,6 +249,25 @@ uint32_t brt_tile_rows(uint32_t height, uint32_t n_parts);
 int32_t brt_deinterleave_device(brt_ctx* ctx, const float* d_tiles, uint32_t n_parts,
                                 uint32_t width, uint32_t height, void* d_frame, void* hip_stream, uint32_t flags);
 
+/* ---- strips by measured cost (one process per GPU) ------------------------------------------------------------------------------------
+ * By default strip s of BRT_STRIP_ROWS rows belongs to part s % n_parts (interleaved, because bands are badly
+ * imbalanced).  A STRIP TABLE assigns the strips by their cost instead: part_of_strip[s] = the part that renders frame strip s, a
+ * permutation of the parts inside every group of n_parts consecutive strips -- so every part still has exactly one strip per group (its
+ * k-th local strip lies in group k): tile size and layout, brt_tile_rows and the ONE gather stay as they are, only the two lookups
+ * "local strip -> frame strip" (trace kernel) and "frame strip -> part" (assembly) go through the table.  Pixels cannot change: a
+ * pixel's seed depends on its frame coordinates only (raytrace.wgsl:95).
+ *   brt_set_strip_table   installs the table for frames of n_strips = ceil(height / 8) strips split n_parts ways (NULL: back to s % n_parts);
+ *                         brt_render_part_device, brt_deinterleave_device and brt_gather_rccl of such frames use it; EVERY rank must set
+ *                         the same table.  BRT_ERR_INVALID_ARGUMENT if a group holds a part twice.  (brt_render / brt_render_device -- one
+ *                         context over N devices -- keep s % n_parts.)
+ *   brt_plan_strips       makes a table from measured costs and installs it: the frame of this camera is rendered once at `probe_spp`
+ *                         samples per pixel on the context's first device with the per-tile ray counts switched on; per group the dearest
+ *                         strip goes to the part with the least so far.  Deterministic: every rank of a job computes the same table from
+ *                         the same integers, no second collective.  out_part_of_strip (n_strips words) may be NULL. */
+int32_t brt_set_strip_table(brt_ctx* ctx, uint32_t n_parts, uint32_t n_strips, const uint32_t* part_of_strip);
+int32_t brt_plan_strips(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level, uint32_t width, uint32_t height,
+                        uint32_t n_parts, uint32_t probe_spp, uint32_t* out_part_of_strip);
+
 /* ---- the one collective of the path: one process per GPU, one RCCL gather per frame -----------------
  * For a host that runs one process per GPU (instead of one N-device context, brt_render_device): every rank renders its part
  * with brt_render_part_device, then all ranks call brt_gather_rccl -- ONE ncclGather (rccl.h:745) of the tiles to rank 0, and on

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--parts", type=int, nargs="*", default=[1, 2, 4, 8, 16])
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--knob", nargs="*", default=[], help="tuning knobs NAME=VALUE")
+    ap.add_argument("--plan", type=int, default=0, help="strips by measured cost: brt_plan_strips with this many probe samples per pixel (0: strip s -> part s %% n)")
     a = ap.parse_args()
     with brt.RaytracePlugin([0]) as p:
         for kv in a.knob:
@@ -43,6 +44,12 @@ def main():
             one = None
             for n in a.parts:
                 rows = brt.tile_rows(H, n)
+                if a.plan and n > 1:
+                    t = p.plan_strips(lvl, cam, win, W, H, n, probe_spp=a.plan)          # strips by measured cost (installs the table)
+                    moved = int(sum(1 for s_, q in enumerate(t) if q != s_ % n))
+                    print(f"   (strip table from a {a.plan}-spp probe: {moved} of {len(t)} strips leave their s % n part)", flush=True)
+                else:
+                    p.set_strip_table(n, None)
                 tile = torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda")
                 torch.cuda.synchronize()
                 reps = a.reps if c == 2 else max(2, a.reps - 1)

@@ -28,15 +28,29 @@ def _pattern(rows, width):
     return t.contiguous()
 
 
-def _worker(rank, world, port, width, height, out_path):
+def _table(height, world, seed):
+    """a strip table (brt_set_strip_table): the parts shuffled inside every group of `world` strips; seed None: no table"""
+    if seed is None:
+        return None
+    rng = np.random.default_rng(seed)
+    strips = (height + 7) // 8
+    t = np.zeros(strips, np.uint32)
+    for g in range(0, strips, world):
+        n = min(world, strips - g)
+        t[g:g + n] = rng.permutation(world)[:n]
+    return t
+
+
+def _worker(rank, world, port, width, height, out_path, table_seed=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        rows = frame_rows_of_part(height, rank, world)
+        table = _table(height, world, table_seed)          # (every rank makes the same table, as brt_plan_strips does)
+        rows = frame_rows_of_part(height, rank, world, table)
         assert len(rows) == brt.tile_rows(height, world)
         tile = _pattern(rows, width)
-        frame = gather_frame(tile, height, rank, world)
+        frame = gather_frame(tile, height, rank, world, table=table)
         if rank == 0:
             want = _pattern(np.arange(height), width)
             ok = frame is not None and frame.shape == (height, width, 4) and torch.equal(frame, want)
@@ -62,6 +76,40 @@ def test_gather_frame_gloo(tmp_path, world, width, height):
     out = tmp_path / "result.txt"
     mp.spawn(_worker, args=(world, _free_port(), width, height, str(out)), nprocs=world, join=True)
     assert out.read_text() == "ok"
+
+
+@pytest.mark.parametrize("world,width,height,seed", [(2, 24, 45, 1), (3, 16, 100, 2)])
+def test_gather_frame_gloo_with_a_strip_table(tmp_path, world, width, height, seed):
+    """The strips dealt out by a table (brt_set_strip_table / brt_plan_strips: a permutation of the parts inside every group of `world`
+    strips) instead of s % world: same tiles, same single gather, the frame assembled through the table."""
+    out = tmp_path / "result.txt"
+    mp.spawn(_worker, args=(world, _free_port(), width, height, str(out), seed), nprocs=world, join=True)
+    assert out.read_text() == "ok"
+
+
+def test_strip_table_rows_partition_the_frame_and_bad_tables_are_refused():
+    from bevyray_amd.parallel import check_strip_table
+    for height, world, seed in ((45, 2, 3), (100, 3, 4), (1080, 8, 5), (2160, 8, 6), (7, 4, 7)):
+        t = _table(height, world, seed)
+        seen = np.zeros(height, np.int64)
+        for p in range(world):
+            rows = frame_rows_of_part(height, p, world, t)
+            assert len(rows) == brt.tile_rows(height, world)
+            v = rows[rows >= 0]
+            seen[v] += 1
+            # the k-th local strip of a part lies in group k (the tile layout of s % world)
+            k = np.flatnonzero(rows >= 0) // 8
+            assert np.array_equal(v // 8 // world, k)
+        assert np.all(seen == 1)
+        assert np.array_equal(np.concatenate([frame_rows_of_part(height, p, world, None) for p in range(world)]) >= 0,
+                              np.concatenate([frame_rows_of_part(height, p, world, t) for p in range(world)]) >= 0) or height % (8 * world) != 0
+    bad = _table(100, 3, 1).copy(); bad[1] = bad[0]
+    with pytest.raises(ValueError):
+        check_strip_table(bad, 100, 3)
+    with pytest.raises(ValueError):
+        check_strip_table(np.zeros(5, np.uint32), 100, 3)
+    # ... and by the library (CPU: the export needs a context, so only its validation rule is reachable through the C++ helper's twin above;
+    # the GPU suite calls brt_set_strip_table itself)
 
 
 def test_single_rank_is_identity():

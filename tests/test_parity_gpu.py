@@ -437,6 +437,59 @@ def test_parts_assemble_to_the_full_frame(plugin, oracle, n_parts):
     assert_frames_equal(frame.cpu().numpy(), full)
 
 
+@pytest.mark.parametrize("n_parts", [2, 3, 8])
+def test_parts_by_a_strip_table_assemble_to_the_full_frame(oracle, n_parts):
+    """Strips dealt out by a table instead of s % n_parts (brt_set_strip_table; brt_plan_strips makes one from measured costs): every
+    part's tile holds the rows the table says, the tiles assemble to the oracle's frame through brt_deinterleave_device and through
+    the RCCL gather's one-rank form, the rays add up, a table with a part twice in a group is refused, NULL brings s % n_parts back."""
+    import torch
+    from bevyray_amd.parallel import check_strip_table, frame_rows_of_part
+    b = brt.generate_scene(brt.SCENE_COVER, 1)
+    w, h = 200, 149                                  # 19 strips: the last group of every split is partial
+    lvl, cam, win = brt.cover_camera(w, h, 2, 4)
+    want, cnt = oracle.render(b, lvl, cam, win, w, h)
+    rows = brt.tile_rows(h, n_parts)
+    strips = (h + 7) // 8
+    rng = np.random.default_rng(40 + n_parts)
+    shuffled = np.zeros(strips, np.uint32)
+    for g in range(0, strips, n_parts):
+        n = min(n_parts, strips - g)
+        shuffled[g:g + n] = rng.permutation(n_parts)[:n]
+    with brt.RaytracePlugin([0]) as p:
+        p.node.write_buffers(b)
+
+        def render_parts(table):
+            tiles = torch.zeros((n_parts, rows, w, 4), dtype=torch.float32, device="cuda")
+            total = 0
+            for part in range(n_parts):
+                st = p.node.render_part_device(lvl, cam, win, w, h, part, n_parts, tiles[part].data_ptr())
+                total += st["rays"]
+                fr = frame_rows_of_part(h, part, n_parts, table)
+                t = tiles[part].cpu().numpy()
+                assert_frames_equal(t[fr >= 0], want[fr[fr >= 0]])
+                assert np.all(t[fr < 0] == 0.0)                                   # padding rows are never written
+                assert st["paths"] == int((fr >= 0).sum()) * w * 2
+            assert total == cnt["rays"]
+            frame = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+            p.node.deinterleave_device(tiles.data_ptr(), n_parts, w, h, frame.data_ptr())
+            torch.cuda.synchronize()
+            assert_frames_equal(frame.cpu().numpy(), want)
+
+        render_parts(None)
+        p.set_strip_table(n_parts, shuffled)
+        render_parts(shuffled)
+        planned = p.plan_strips(lvl, cam, win, w, h, n_parts, probe_spp=2)
+        check_strip_table(planned, h, n_parts)
+        assert np.array_equal(planned, p.plan_strips(lvl, cam, win, w, h, n_parts, probe_spp=2))      # deterministic
+        render_parts(planned)
+        bad = shuffled.copy(); bad[1] = bad[0]
+        with pytest.raises(brt.BrtError) as e:
+            p.set_strip_table(n_parts, bad)
+        assert e.value.code == -1
+        p.set_strip_table(n_parts, None)
+        render_parts(None)
+
+
 def test_multi_device_context_on_one_gpu(oracle):
     # brt_create([0, 0, 0]): three sub-contexts on the same GPU exercise the strip split + copy-out
     b = brt.generate_scene(brt.SCENE_COVER, 1)
