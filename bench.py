@@ -79,6 +79,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc pass (N = 1 only)")
     ap.add_argument("--no-extras", action="store_true", help="skip first-frame / reseeded / moving-camera / config-4 measurements")
     ap.add_argument("--no-configs", action="store_true", help="skip the config 3 / config 5 blocks (N = 1)")
+    ap.add_argument("--plan-strips", type=int, default=0, help="N > 1: deal the strips out to the ranks by measured cost (brt_plan_strips with this many "
+                    "probe samples per pixel, outside the timed region; 0: strip s -> rank s %% N).  Config 4 in 8 shares 91.9 -> 89.1 ms, the headline config unchanged")
     ap.add_argument("--sync-steps", action="store_true", help="timed steps through the synchronous form of brt_render_part_device (a host round "
                                                               "trip per frame) instead of enqueueing them on the stream")
     return ap.parse_args(argv)
@@ -209,6 +211,12 @@ def main():
         cam_fn = brt.rtiow_camera if scene_kind == brt.SCENE_RTIOW_FINAL else brt.cover_camera   # configs 3 / 4: the book's view
         lvl, cam, win = cam_fn(W, H, spp, bounces, brt.Raytracing.Pure, wl["random_seed"])
         node.write_buffers(upload)              # scene resident in HBM before anything is timed
+        if stub is None and world > 1:
+            # every rank computes the same table from the same probe frame (deterministic): no second collective
+            if args.plan_strips > 0:
+                plugin.plan_strips(lvl, cam, win, W, H, world, args.plan_strips)
+            else:
+                plugin.set_strip_table(world, None)
         rows = brt.tile_rows(H, world)
         tile = torch.zeros((rows, W, 4), dtype=torch.float32, device=dev)
         sync()                                  # the zero fill ran on torch's stream, the trace kernel has its own
@@ -447,7 +455,8 @@ def main():
                        "bvh": "built by the callee (brt_upload_scene without a BVH: binned SAH, INTEGRATION.md section 3); "
                               "`caller_ploc_tree_ms` = the same frame in the caller's PLOC tree",
                        "scene_seed": WORKLOAD["scene_seed"], "random_seed": WORKLOAD["random_seed"], "level": "Pure",
-                       "parallelism": f"interleaved 8-row strips over {world} GPU(s), one RCCL gather per frame"},
+                       "parallelism": (f"8-row strips over {world} GPU(s), " + ("dealt out by measured cost (brt_plan_strips)" if args.plan_strips > 0 and world > 1 else "strip s -> rank s % N") +
+                                       ", one RCCL gather per frame")},
             "n_ranks_seen": ranks_seen, "device_ordinals": ordinals,
             "rays_per_frame": head["total_rays"] / args.steps, "paths_per_frame": W * H * spp,
             "mpaths_per_s": W * H * spp * args.steps / head["elapsed"] / 1e6,
