@@ -1258,6 +1258,11 @@ BRT_DEV void walk_wave_top_asm(uint32_t& cur, uint32_t& spa, float& closest, uin
 // order, same ties, same t: pixels and counters do not change.  The rays' stacks stay where they are (the row reads and writes its
 // source lane's column of the wave's stack array), so a walk that was suspended by the wide loop is finished here as it stands.
 // Rays travel through 80 bytes of LDS scratch per row: { o, a | 1/d, closest | d, closest id | granule offsets, cur | stack top }.
+// EXEC: unlike the other hand-written loops this one WIDENS the execution mask (to the 16 n lanes of its rows, whatever lanes were active at the
+// call) and restores it at the end.  What it writes there are only its own temporaries -- asm outputs and the clobbered v100 - v113 --, which by
+// the compiler's own liveness hold no value across this statement; the call sits in the round loop of the kernel, where no other side of a
+// divergent branch is pending whose values could live in those registers for the lanes that are inactive here (suite, fuzz and sequence soaks
+// run through it: profiles/r06/fuzz_soak.txt).
 #ifndef BRT_WALK_ROWS
 #define BRT_WALK_ROWS BRT_HAND_ASM
 #endif
