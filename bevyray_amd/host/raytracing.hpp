@@ -216,6 +216,17 @@ public:
     // the reading of `||` in raytrace.wgsl:269 (BRT_POLICY_OR_SHORT_CIRCUIT or 0); scheduling knobs (never change a pixel)
     void set_policy(uint32_t flags) { check(brt_set_policy(ctx_, flags), ctx_); }
     void set_tuning(const char* name, uint32_t value) { check(brt_set_tuning(ctx_, name, value), ctx_); }
+    // one process per GPU: the strips dealt out to the ranks by measured cost instead of s % world (brt_plan_strips: every rank computes
+    // the same table from the same probe frame; an empty vector to set_strip_table: back to s % world)
+    std::vector<uint32_t> plan_strips(const std::pair<RaytraceLevelExtract, CameraExtract>& view, const WindowExtract& window, uint32_t width,
+                                      uint32_t height, uint32_t world, uint32_t probe_spp = 4) {
+        std::vector<uint32_t> table((height + BRT_STRIP_ROWS - 1u) / BRT_STRIP_ROWS);
+        check(brt_plan_strips(ctx_, &view.second, &window, view.first.level, width, height, world, probe_spp, table.data()), ctx_);
+        return table;
+    }
+    void set_strip_table(uint32_t world, const std::vector<uint32_t>& part_of_strip) {
+        check(brt_set_strip_table(ctx_, world, static_cast<uint32_t>(part_of_strip.size()), part_of_strip.empty() ? nullptr : part_of_strip.data()), ctx_);
+    }
     // the colour target's memory, exported by the host's graphics API as a file descriptor (pipeline.rs:191-203 renders straight
     // into post_process.destination): a device pointer that run_device / gather accept as the frame (brt_import_frame_fd)
     void* import_frame(int32_t fd, uint64_t bytes, uint32_t handle_type = BRT_EXTMEM_OPAQUE_FD) {
