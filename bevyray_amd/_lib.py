@@ -78,6 +78,7 @@ _PROTOTYPES = {
     "brt_tile_rows": (_U32, [_U32, _U32]),
     "brt_set_strip_table": (_I32, [_VP, _U32, _U32, _VP]),
     "brt_plan_strips": (_I32, [_VP, _VP, _VP, _U32, _U32, _U32, _U32, _U32, _VP]),
+    "brt_host_plan_strips": (_I32, [_VP, _U32, _U32, _VP]),
     "brt_deinterleave_device": (_I32, [_VP, _VP, _U32, _U32, _U32, _VP, _VP, _U32]),
     "brt_rccl_unique_id": (_I32, [_VP]),
     "brt_rccl_comm_create": (_I32, [_VP, _VP, _I32, _I32, C.POINTER(_VP)]),

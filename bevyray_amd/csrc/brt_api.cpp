@@ -1738,23 +1738,10 @@ int32_t brt_plan_strips(brt_ctx* ctx, const void* camera80, const void* window16
     HIP_TRY(ctx, hipMemcpyAsync(cost.data(), dc.d_tile_cost, (size_t)n_tiles * 4u, hipMemcpyDeviceToHost, dc.stream));
     HIP_TRY(ctx, hipStreamSynchronize(dc.stream));
     dc.costs_valid = false;                                     // (the cost buffer no longer holds a view's measurement)
-    std::vector<uint64_t> strip_cost(strips, 0), load(n_parts, 0);
+    std::vector<uint64_t> strip_cost(strips, 0);
     for (uint32_t t = 0; t < n_tiles; t++) strip_cost[t / fp.tiles_x] += cost[t];
-    // groups from the dearest down (their strips matter most for the balance), inside a group the dearest strip to the part with the
-    // least so far; ties by index: a function of the integers alone
-    std::vector<uint32_t> groups((strips + n_parts - 1u) / n_parts), table(strips, 0u);
-    std::vector<uint64_t> gcost(groups.size(), 0);
-    for (uint32_t s = 0; s < strips; s++) gcost[s / n_parts] += strip_cost[s];
-    for (uint32_t g = 0; g < groups.size(); g++) groups[g] = g;
-    std::stable_sort(groups.begin(), groups.end(), [&](uint32_t a, uint32_t b) { return gcost[a] > gcost[b]; });
-    for (uint32_t g : groups) {
-        std::vector<uint32_t> ss, ps(n_parts);
-        for (uint32_t s = g * n_parts; s < strips && s < (g + 1u) * n_parts; s++) ss.push_back(s);
-        for (uint32_t p = 0; p < n_parts; p++) ps[p] = p;
-        std::stable_sort(ss.begin(), ss.end(), [&](uint32_t a, uint32_t b) { return strip_cost[a] > strip_cost[b]; });
-        std::stable_sort(ps.begin(), ps.end(), [&](uint32_t a, uint32_t b) { return load[a] < load[b]; });
-        for (size_t i = 0; i < ss.size(); i++) { table[ss[i]] = ps[i]; load[ps[i]] += strip_cost[ss[i]]; }
-    }
+    std::vector<uint32_t> table(strips, 0u);
+    plan_strip_table(strip_cost.data(), strips, n_parts, table.data());          // the rule: brt_host.cpp
     if (out_part_of_strip) std::memcpy(out_part_of_strip, table.data(), (size_t)strips * 4u);
     ctx->strip_epoch++;
     ctx->strip_part = table;

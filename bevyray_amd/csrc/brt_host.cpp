@@ -685,11 +685,35 @@ uint32_t tree_level_for(float scene_scale, const std::vector<float>& big_spheres
     return k < 1.0 ? 1u : (k > (double)kTreeLevelMax ? kTreeLevelMax : (uint32_t)k);
 }
 
+void plan_strip_table(const uint64_t* strip_cost, uint32_t n_strips, uint32_t n_parts, uint32_t* out) {
+    std::vector<uint64_t> load(n_parts, 0), gcost((n_strips + n_parts - 1u) / n_parts, 0);
+    std::vector<uint32_t> groups(gcost.size());
+    for (uint32_t s = 0; s < n_strips; s++) gcost[s / n_parts] += strip_cost[s];
+    for (uint32_t g = 0; g < groups.size(); g++) groups[g] = g;
+    std::stable_sort(groups.begin(), groups.end(), [&](uint32_t a, uint32_t b) { return gcost[a] > gcost[b]; });
+    for (uint32_t g : groups) {
+        std::vector<uint32_t> ss, ps(n_parts);
+        for (uint32_t s = g * n_parts; s < n_strips && s < (g + 1u) * n_parts; s++) ss.push_back(s);
+        for (uint32_t p = 0; p < n_parts; p++) ps[p] = p;
+        std::stable_sort(ss.begin(), ss.end(), [&](uint32_t a, uint32_t b) { return strip_cost[a] > strip_cost[b]; });
+        std::stable_sort(ps.begin(), ps.end(), [&](uint32_t a, uint32_t b) { return load[a] < load[b]; });
+        for (size_t i = 0; i < ss.size(); i++) { out[ss[i]] = ps[i]; load[ps[i]] += strip_cost[ss[i]]; }
+    }
+}
+
 }  // namespace brt
 
 using namespace brt;
 
 extern "C" {
+
+int32_t brt_host_plan_strips(const uint64_t* strip_cost, uint32_t n_strips, uint32_t n_parts, uint32_t* out_part_of_strip) {
+    return guard(nullptr, [&]() -> int32_t {
+    if (!strip_cost || !out_part_of_strip || n_strips == 0u || n_parts == 0u || n_parts > 64u) return fail(BRT_ERR_INVALID_ARGUMENT, "null pointer / n_parts must be 1..64");
+    plan_strip_table(strip_cost, n_strips, n_parts, out_part_of_strip);
+    return BRT_OK;
+    });
+}
 
 int32_t brt_build_bvh(const void* models, uint32_t n_models, void* out_nodes, uint32_t capacity, uint32_t* out_n_nodes) {
     return guard(nullptr, [&]() -> int32_t {

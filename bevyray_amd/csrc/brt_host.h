@@ -100,4 +100,9 @@ struct TileOrder {
 };
 void build_tile_order(const uint32_t* ray_sum, const uint32_t* longest, uint32_t n_tiles, const TileOrderParams& p, TileOrder* out);
 
+// Strips to parts by measured cost (brt_plan_strips; exported for tests as brt_host_plan_strips): inside every group of n_parts consecutive
+// strips a permutation of the parts -- groups from the dearest down, in a group the dearest strip to the part with the least so far, ties by
+// index: a function of the integers alone, so every rank of a job computes the same table.
+void plan_strip_table(const uint64_t* strip_cost, uint32_t n_strips, uint32_t n_parts, uint32_t* out_part_of_strip);
+
 }  // namespace brt

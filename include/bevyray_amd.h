@@ -267,6 +267,8 @@ int32_t brt_deinterleave_device(brt_ctx* ctx, const float* d_tiles, uint32_t n_p
 int32_t brt_set_strip_table(brt_ctx* ctx, uint32_t n_parts, uint32_t n_strips, const uint32_t* part_of_strip);
 int32_t brt_plan_strips(brt_ctx* ctx, const void* camera80, const void* window16, uint32_t level, uint32_t width, uint32_t height,
                         uint32_t n_parts, uint32_t probe_spp, uint32_t* out_part_of_strip);
+/* the assignment rule of brt_plan_strips on given costs (host arithmetic, no device: what the CPU tests hold it to) */
+int32_t brt_host_plan_strips(const uint64_t* strip_cost, uint32_t n_strips, uint32_t n_parts, uint32_t* out_part_of_strip);
 
 /* ---- the one collective of the path: one process per GPU, one RCCL gather per frame -----------------
  * For a host that runs one process per GPU (instead of one N-device context, brt_render_device): every rank renders its part

@@ -108,8 +108,30 @@ def test_strip_table_rows_partition_the_frame_and_bad_tables_are_refused():
         check_strip_table(bad, 100, 3)
     with pytest.raises(ValueError):
         check_strip_table(np.zeros(5, np.uint32), 100, 3)
-    # ... and by the library (CPU: the export needs a context, so only its validation rule is reachable through the C++ helper's twin above;
-    # the GPU suite calls brt_set_strip_table itself)
+
+
+def test_planned_strip_tables_are_valid_and_balance_the_parts():
+    """The rule of brt_plan_strips on given costs (brt_host_plan_strips, host arithmetic): a valid table -- a permutation of the parts inside
+    every group --, deterministic, and on costs that fall off from the bottom of the frame to the top (ground below, sky above, as the
+    benchmark views) the dearest part is no dearer than under s % n_parts and within one strip of the mean."""
+    from bevyray_amd import _lib
+    from bevyray_amd.parallel import check_strip_table
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    for height, world in ((1080, 8), (2160, 8), (1080, 3), (45, 2), (149, 4)):
+        strips = (height + 7) // 8
+        cost = (np.linspace(1.0, 6.0, strips) ** 2 * 1e6 * rng.uniform(0.8, 1.25, strips)).astype(np.uint64)
+        t = np.zeros(strips, np.uint32)
+        assert lib.brt_host_plan_strips(cost.ctypes.data, strips, world, t.ctypes.data) == 0
+        check_strip_table(t, height, world)
+        t2 = np.zeros(strips, np.uint32)
+        assert lib.brt_host_plan_strips(cost.ctypes.data, strips, world, t2.ctypes.data) == 0 and np.array_equal(t, t2)
+        planned = np.array([cost[t == p].sum() for p in range(world)], np.float64)
+        inter = np.array([cost[np.arange(strips) % world == p].sum() for p in range(world)], np.float64)
+        assert planned.sum() == inter.sum()
+        assert planned.max() <= inter.max()
+        assert planned.max() - planned.mean() <= float(cost.max())
+    assert lib.brt_host_plan_strips(None, 10, 2, t.ctypes.data) == -1
 
 
 def test_single_rank_is_identity():
