@@ -113,6 +113,7 @@ struct LaunchPlan {
     uint32_t lds_pairs;          // SCENE_LDS_TOP: pair records staged in LDS
     uint32_t block, grid, wg_per_cu;
     uint32_t pool_cap;           // records of the drain pool per workgroup (0: none)
+    uint32_t rows;               // 1: with the scratch of the row-mode walk (SCENE_LDS)
     size_t lds_bytes;
     uint32_t variant;            // brt_stats::kernel_variant of the launch
     uint32_t measured;           // the launch measured the tile costs
@@ -155,18 +156,22 @@ LaunchPlan plan_launch(const Knobs& kn, const DeviceCtx& dc, const FrameParams& 
     if (!force_global && !force_top && dc.view.desc16) {
         struct Cand { uint32_t block, per_cu; };
         const Cand cands[] = {{1024, 1}, {512, 2}, {512, 3}, {1024, 2}, {512, 1}, {256, 1}};
-        for (int with_pool = 1; with_pool >= 0 && lp.scene_mode != SCENE_LDS; with_pool--) {
+        // (what is given up first when the scene is large: the 5 KB of the thin waves' row-mode scratch, then the drain pool -- never the
+        //  LDS-resident scene itself for either of them)
+        for (int opt = 0; opt < 4 && lp.scene_mode != SCENE_LDS; opt++) {
+            const int with_pool = opt < 2 ? 1 : 0, with_rows = (opt & 1) == 0 ? 1 : 0;
             for (const Cand& c : cands) {
                 if (block_env && c.block != block_env) continue;
                 if (wg_env && c.per_cu != wg_env) continue;
                 const uint32_t pool = with_pool ? pool_of(c.block) : 0u;
-                const size_t need = trace_lds_bytes(dc.view, SCENE_LDS, c.block, pool);
+                const size_t need = trace_lds_bytes(dc.view, SCENE_LDS, c.block, pool, 0, with_rows != 0);
                 if (need * c.per_cu <= dc.max_lds && c.per_cu * (c.block / 64) <= max_waves_cu) {
                     lp.scene_mode = SCENE_LDS;
                     lp.block = c.block;
                     lp.wg_per_cu = c.per_cu;
                     lp.lds_bytes = need;
                     lp.pool_cap = pool;
+                    lp.rows = (uint32_t)with_rows;
                     break;
                 }
             }
@@ -513,6 +518,7 @@ int32_t launch_part(brt_ctx* ctx, DeviceCtx& dc, const FrameParams& fp, const fl
             tl.block = lp.block;
             tl.lds_bytes = lp.lds_bytes;
             tl.frame.pool_cap = lp.pool_cap;
+            tl.frame.rows_on = lp.scene_mode == SCENE_LDS ? lp.rows : 0u;
             if (tl.frame.wgq_batch == 0u) {
                 // queue slots a workgroup takes at a time: at most half a pixel per lane, and small enough that every
                 // workgroup comes back for at least 8 batches -- a rank that renders 1/8 of the frame has one tile

@@ -30,7 +30,8 @@ struct TraceLaunch {
     hipStream_t stream;
 };
 
-size_t trace_lds_bytes(const DeviceSceneView& sv, int scene_mode, uint32_t block, uint32_t pool_cap, uint32_t hist_words = 0);
+// rows: with the scratch of the row-mode walk of thin waves (SCENE_LDS only; FrameParams::rows_on)
+size_t trace_lds_bytes(const DeviceSceneView& sv, int scene_mode, uint32_t block, uint32_t pool_cap, uint32_t hist_words = 0, bool rows = false);
 constexpr uint32_t POOL_RECORD_BYTES = 96;   // one path in the drain pool (k_trace_persistent)
 // sampler stage (k_trace_persistent<.., SRV>): a 32-byte mailbox entry per lane of every trace wave + 16 control words + a door per wave
 constexpr uint32_t SRV_WAVES = 2;

@@ -279,7 +279,7 @@ __global__ void k_debug_eval(uint32_t op, const float* __restrict__ in, float* _
 
 // ---- host-callable launchers ----------------------------------------------------------------------
 
-size_t trace_lds_bytes(const DeviceSceneView& sv, int scene_mode, uint32_t block, uint32_t pool_cap, uint32_t hist_words) {
+size_t trace_lds_bytes(const DeviceSceneView& sv, int scene_mode, uint32_t block, uint32_t pool_cap, uint32_t hist_words, bool rows) {
     size_t bytes = 0;
     if (scene_mode == SCENE_LDS) {
         bytes += pair_array_bytes(sv.n_pairs) + (size_t)sv.n_models * 16;
@@ -290,7 +290,7 @@ size_t trace_lds_bytes(const DeviceSceneView& sv, int scene_mode, uint32_t block
     bytes += (size_t)(block / 64) * (sv.stack_entries + 2) * 64 * (sv.desc16 ? 2 : 4);   // + 2: DONE sentinel, one spare entry
     bytes = (bytes + 15) & ~(size_t)15;
     bytes += WGQ_BYTES;                                                                  // workgroup share of the pixel queue
-    if (scene_mode == SCENE_LDS && BRT_WALK_ROWS) bytes += (size_t)(block / 64) * ROWS_SCRATCH_BYTES;   // row-mode walk of thin waves
+    if (scene_mode == SCENE_LDS && BRT_WALK_ROWS && rows) bytes += (size_t)(block / 64) * ROWS_SCRATCH_BYTES;   // row-mode walk of thin waves
     if (pool_cap) bytes += 16 + (size_t)pool_cap * POOL_RECORD_BYTES;                    // drain pool: control words + records
     bytes += (size_t)hist_words * 4;                                                     // pre-pass: visits per pair record (FrameParams::record_hits)
     return bytes;

@@ -221,6 +221,8 @@ struct FrameParams {
     uint32_t* record_hits;
     uint32_t raster_dense;           // 1: the raster inputs hold this part's strips only, in the tile's own layout (row k * 8 + r = frame row
                                      // (k * n_parts + part) * 8 + r): what a device of an N-device context is sent; 0: the full frame
+    uint32_t rows_on;                // 1: the launch's LDS holds the scratch of the row-mode walk of thin waves (brt_device.h walk_rows_asm; plan_launch leaves it
+                                     // out when the scene only fits the LDS without it)
     uint32_t tunable;                // 1: some knob above differs from its default -> the TUNABLE kernel instantiation
     uint32_t policy_flags;           // TUNABLE only; bit 0: `||` of raytrace.wgsl:269 short-circuits (alternative policy)
 };

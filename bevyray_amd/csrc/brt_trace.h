@@ -617,7 +617,7 @@ __global__ __launch_bounds__(BRT_BLOCK) void k_trace_persistent(DeviceSceneView 
     off = (off + 15u) & ~15u;
     uint32_t* const wgq = reinterpret_cast<uint32_t*>(lds + off);
     off += WGQ_BYTES;
-    if (MODE == SCENE_LDS && BRT_WALK_ROWS) {      // every wave's scratch for the row-mode walk of a thin wave (walk_rows_asm)
+    if (MODE == SCENE_LDS && BRT_WALK_ROWS && fp.rows_on != 0u) {      // every wave's scratch for the row-mode walk of a thin wave (walk_rows_asm)
         sc.rows_scratch = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + off) + wave * ROWS_SCRATCH_BYTES;
         off += n_waves * ROWS_SCRATCH_BYTES;
     }
